@@ -1,0 +1,208 @@
+/*
+ * mvo_hip.h -- C ABI of libmvo_hip, the MI355X (gfx950) implementation of the reference's
+ * sliding-window refinement solver.
+ *
+ * Drop-in boundary: the reference has no plugin/FFI layer; its operator API for this path is
+ * the C++ member
+ *
+ *   void IterativeRefinement::refine(std::vector<RefinementFrame>&, unsigned numberToRefine,
+ *        unsigned numberToNote, int maxNumthreads, int maxNumIterations,
+ *        double functionTolerance, double gradientTolerance, double parameterTolerance,
+ *        bool useLossFunction, double lowestLength, double highestLength, const Frame&)
+ *        -- mvo/src/algorithms/IterativeRefinement.hpp:181-192, called from
+ *           mvo/src/pipeline/Refiner.cpp:85-92.
+ *
+ * Everything below is what a binding for that call needs: plain pointers and sizes, no C++
+ * types, no exceptions, no logging.  The header is C99 and pedantic-clean C++11 (the reference
+ * compiles with -std=c++11 -Wall -Werror -pedantic -Wextra, mvo/CMakeLists.txt:4,71).
+ *
+ * Conventions (identical to the reference):
+ *   - frames[i], i = 0 newest ... N-1 oldest (Refiner.cpp:62-68); N = numberToNote,
+ *     M = numberToRefine, 1 <= M < N (IterativeRefinement.cpp:28-30), M <= 5
+ *     (IterativeRefinement.cpp:384-451, default: assert(false)).
+ *   - residual blocks are grouped by frame pair in the reference's loop order
+ *     "for a in [0,M): for b in [a,N-1)" (IterativeRefinement.cpp:116,134); pair p owns blocks
+ *     [pair_offsets[p], pair_offsets[p+1]); m0 = unit ray in frame a, m1 = unit ray in frame
+ *     b+1 (IterativeRefinement.cpp:152-154).
+ */
+#ifndef MVO_HIP_H
+#define MVO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVO_HIP_MAX_REFINE 5    /* IterativeRefinement.cpp:384-451 */
+#define MVO_HIP_MAX_FRAMES 256  /* mvo/cfg/mvo.cfg:43 allows numberToNote <= 100 */
+
+/* status codes returned by every entry point */
+#define MVO_HIP_OK 0
+#define MVO_HIP_ERR_INVALID_ARGUMENT 1 /* the reference's assert()s, IterativeRefinement.cpp:28-30,379 */
+#define MVO_HIP_ERR_UNSUPPORTED 2      /* M > 5: the reference's "default: assert(false)" */
+#define MVO_HIP_ERR_OUT_OF_MEMORY 3
+#define MVO_HIP_ERR_DEVICE 4           /* a HIP runtime call failed */
+#define MVO_HIP_ERR_NO_DEVICE 5        /* no gfx950 device: there is NO CPU fallback */
+#define MVO_HIP_ERR_STATE 6            /* solve/download without a prior upload */
+
+/* IterativeRefinement::RefinementFrame (IterativeRefinement.hpp:171-175).
+ * R: cv::Matx33d row-major (IterativeRefinement.cpp:320-324); vec: unit baseline direction
+ * frame i -> i+1 in world axes; scale: baseline length. 104 bytes, no padding. */
+typedef struct mvo_hip_frame {
+  double R[9];
+  double vec[3];
+  double scale;
+} mvo_hip_frame;
+
+/* The scalar arguments of refine() (IterativeRefinement.hpp:183-191) plus fixLength, which the
+ * reference reads via nowFrame.getParameters() (IterativeRefinement.cpp:105).
+ * Tolerances are the already-converted 10^-x values (Refiner.cpp:72-74). */
+typedef struct mvo_hip_options {
+  int32_t max_num_iterations;  /* maxNumIterations   -> Solver::Options::max_num_iterations */
+  int32_t num_threads;         /* maxNumthreads: accepted for signature parity, unused on GPU */
+  double function_tolerance;
+  double gradient_tolerance;
+  double parameter_tolerance;
+  int32_t use_loss_function;   /* ceres::CauchyLoss(0.5), IterativeRefinement.cpp:85-88 */
+  int32_t fix_length;          /* SetParameterBlockConstant(scale), IterativeRefinement.cpp:105-107 */
+  double lowest_length;        /* lowestLength  (MIN_LEN of scaleTemplated) */
+  double highest_length;       /* highestLength (MAX_LEN of scaleTemplated) */
+  /* library extension, 0 = reference behaviour.
+   * MVO_HIP_ASSEMBLY_AUTO  : no loss -> per-pair second moments are folded once and the LM loop
+   *                          never touches observations again; loss -> one pass per evaluation.
+   * MVO_HIP_ASSEMBLY_PASSES: always one observation pass per evaluation (what Ceres does). */
+  int32_t assembly_mode;
+  int32_t reserved;
+} mvo_hip_options;
+
+#define MVO_HIP_ASSEMBLY_AUTO 0
+#define MVO_HIP_ASSEMBLY_PASSES 1
+
+/* What IterativeRefinement.cpp:111-183 gathers from nowFrame: replaces the
+ * std::list<std::vector<Eigen::Vector3d>> "features" (IterativeRefinement.cpp:111,147-165). */
+typedef struct mvo_hip_observations {
+  uint32_t n_pairs;              /* must equal M(N-1) - M(M-1)/2 */
+  uint32_t reserved;
+  const uint64_t *pair_offsets;  /* n_pairs + 1 entries, CSR over residual blocks */
+  const double *m0;              /* 3 doubles per residual block (x,y,z interleaved), unit norm */
+  const double *m1;              /* likewise, ray in frame b+1 */
+} mvo_hip_observations;
+
+/* ceres::Solver::Summary subset (IterativeRefinement.cpp:231-237,248). */
+#define MVO_HIP_CONVERGENCE 0
+#define MVO_HIP_NO_CONVERGENCE 1
+#define MVO_HIP_FAILURE 2
+
+#define MVO_HIP_REASON_NONE 0
+#define MVO_HIP_REASON_MAX_ITERATIONS 1
+#define MVO_HIP_REASON_GRADIENT_TOLERANCE 2
+#define MVO_HIP_REASON_PARAMETER_TOLERANCE 3
+#define MVO_HIP_REASON_FUNCTION_TOLERANCE 4
+#define MVO_HIP_REASON_MIN_RADIUS 5
+#define MVO_HIP_REASON_INVALID_STEPS 6
+#define MVO_HIP_REASON_LINEAR_SOLVER 7
+
+typedef struct mvo_hip_summary {
+  int32_t termination;           /* MVO_HIP_CONVERGENCE / NO_CONVERGENCE / FAILURE */
+  int32_t reason;
+  int32_t iterations;            /* index of the last finalized Ceres iteration */
+  int32_t num_successful_steps;
+  int32_t num_unsuccessful_steps;
+  int32_t reserved;
+  double initial_cost;
+  double final_cost;
+} mvo_hip_summary;
+
+/* one row per ceres::IterationSummary; optional debugging aid */
+typedef struct mvo_hip_iteration {
+  double cost;
+  double cost_change;
+  double gradient_max_norm;
+  double step_norm;
+  double relative_decrease;
+  double trust_region_radius;
+  int32_t step_is_valid;
+  int32_t step_is_successful;
+} mvo_hip_iteration;
+
+/* device-side timing of the last mvo_hip_solve(), measured with HIP events on the library's
+ * own stream (the reference's only instrumentation is DUR_REF, Refiner.cpp:40,118) */
+typedef struct mvo_hip_timing {
+  double upload_seconds;          /* host wall time of the last upload (tables + H2D) */
+  double solve_seconds;           /* host wall time of the last solve, launch -> results on host */
+  double device_seconds;          /* first kernel start -> last kernel end */
+  double assembly_seconds;        /* sum over launches of the observation-pass kernels */
+  int32_t assembly_launches;
+  int32_t lm_launches;
+  uint64_t residual_blocks;       /* per launch of the assembly kernel */
+  uint64_t assembly_bytes;        /* algorithmic bytes per launch of the dominant assembly kernel */
+  double assembly_first_seconds;  /* the fold launch alone (reads m0,m1; writes c in pass mode) */
+} mvo_hip_timing;
+
+typedef struct mvo_hip_context *mvo_hip_handle;
+
+/* Owns one HIP stream, the device buffers and pinned staging memory; not re-entrant per handle
+ * (the reference calls refine() from one thread only, mvo/src/mvo.cpp:37).  The capacities are
+ * hints: buffers grow on demand.  Fails with MVO_HIP_ERR_NO_DEVICE when no GPU is present. */
+int mvo_hip_create(int device_ordinal, uint32_t max_windows, uint32_t max_frames,
+                   uint64_t max_observations, mvo_hip_handle *out);
+void mvo_hip_destroy(mvo_hip_handle h);
+
+/* Replaces IterativeRefinement::refine (IterativeRefinement.cpp:15-250) from the solver set-up
+ * (:63-109) to the write-back (:240-246): frames[0..M) receive the refined vec and scale, even
+ * after FAILURE, exactly as the reference does.  summary may be NULL. */
+int mvo_hip_refine(mvo_hip_handle h, mvo_hip_frame *frames, uint32_t M, uint32_t N,
+                   const mvo_hip_options *options, const mvo_hip_observations *observations,
+                   mvo_hip_summary *summary);
+
+/* n_windows independent refine() calls of identical (M, N) in one launch sequence
+ * (multi-sequence replay; no reference counterpart beyond calling refine() in a loop).
+ * frames: n_windows * N records, window-major.  observations / summaries: one per window. */
+int mvo_hip_refine_batch(mvo_hip_handle h, uint32_t n_windows, mvo_hip_frame *frames, uint32_t M,
+                         uint32_t N, const mvo_hip_options *options,
+                         const mvo_hip_observations *observations, mvo_hip_summary *summaries);
+
+/* Split-phase form of the same call, so that callers (and bench.py) can keep the observations
+ * resident in HBM: upload = IterativeRefinement.cpp:36-43,111-183 (packing + gathering),
+ * solve = :63-109,231-233, download = :240-246.  solve() may be repeated; every solve restarts
+ * from the uploaded initial values. */
+int mvo_hip_upload(mvo_hip_handle h, uint32_t n_windows, const mvo_hip_frame *frames, uint32_t M,
+                   uint32_t N, const mvo_hip_options *options,
+                   const mvo_hip_observations *observations);
+int mvo_hip_solve(mvo_hip_handle h);
+int mvo_hip_download(mvo_hip_handle h, mvo_hip_frame *frames, mvo_hip_summary *summaries);
+
+/* Debug/parity entry point: the raw residual r_i and the raw local Jacobian row of every
+ * residual block at the initial point -- what ceres::Problem::Evaluate would return for the
+ * problem built at IterativeRefinement.cpp:95-183 with apply_loss_function = false.
+ * jacobian is row-major n_obs x 3M, columns of refined frame k are (d/da, d/db, d/dt) with
+ * (a,b) the ParametrizedBaseLine chart (IterativeRefinement.cpp:334-346) and t the sigmoid
+ * parameter of scaleTemplated (:298-309).  Any output pointer may be NULL. */
+int mvo_hip_eval(mvo_hip_handle h, const mvo_hip_frame *frames, uint32_t M, uint32_t N,
+                 const mvo_hip_options *options, const mvo_hip_observations *observations,
+                 double *residuals, double *jacobian, double *cost);
+
+/* Debug/parity: per-pair second moments S_p = sum_i c_i c_i^T (xx,xy,xz,yy,yz,zz) of the last
+ * upload, window-major, n_windows * n_pairs * 6 doubles. */
+int mvo_hip_pair_moments(mvo_hip_handle h, double *moments);
+
+/* Iteration trace of window 0 of the next solves: capacity rows are recorded (0 disables). */
+int mvo_hip_set_trace(mvo_hip_handle h, int32_t capacity);
+int mvo_hip_get_trace(mvo_hip_handle h, mvo_hip_iteration *rows, int32_t capacity, int32_t *n_rows);
+
+int mvo_hip_get_timing(mvo_hip_handle h, mvo_hip_timing *out);
+
+/* scalar helpers exported for bindings and tests (host code, libm):
+ * reverseScale (IterativeRefinement.cpp:348-368) and scaleTemplated<double> (:298-309). */
+double mvo_hip_reverse_scale(double length, double highest_length, double lowest_length);
+double mvo_hip_scale(double t, double highest_length, double lowest_length);
+uint32_t mvo_hip_num_pairs(uint32_t M, uint32_t N);
+const char *mvo_hip_status_string(int status);
+const char *mvo_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVO_HIP_H */

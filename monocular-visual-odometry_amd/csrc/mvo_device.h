@@ -1,0 +1,144 @@
+// mvo_device.h -- device-side records and scalar math shared by the gfx950 kernels.
+//
+// Reference = /root/reference/mvo/src/algorithms/IterativeRefinement.cpp ("IR.cpp").
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <float.h>
+
+#define MVO_MAXM 5
+#define MVO_MAXC 15
+#define MVO_FRAME_DOUBLES 13  // R(9) vec(3) scale(1): mvo_hip_frame
+
+// ---- tables built on the host at upload -------------------------------------------------
+struct WinDev {
+  uint32_t frame_off;  // first frame record of the window
+  uint32_t pair_off;   // first PairDev of the window
+  uint32_t N, M, P;
+  uint32_t pad[3];
+};
+
+struct PairDev {
+  uint32_t slot_begin, slot_end;  // partial-sum slots owned by this pair
+  uint32_t a, b;                  // frame indices within the window (IR.cpp:116,134)
+};
+
+// One wave-tile: a run of residual blocks of ONE frame pair, processed by one wavefront.
+struct TileDev {
+  uint32_t pair;       // global pair index (into PairDev / pair_u)
+  uint32_t win;        // window index
+  uint32_t src_start;  // first residual block in the caller-ordered AoS ray arrays
+  uint32_t c_start;    // first element in the padded SoA planes of c (multiple of 2)
+  uint32_t count;      // residual blocks in this tile
+  uint32_t slot;       // partial-sum slot this tile adds into (never spans workgroups)
+  uint32_t f0, f1;     // global frame records of R0 = frames[a].R and R1 = frames[b+1].R
+};
+
+struct SolveParams {
+  double ftol, gtol, ptol;
+  double min_len, max_len;
+  int32_t max_it;
+  int32_t use_loss;
+  int32_t fix_length;
+  int32_t pass_mode;   // 1: every evaluation is an observation pass (k_pass)
+  int32_t trace_cap;
+  int32_t pad;
+};
+
+struct TraceRec {  // == mvo_hip_iteration
+  double cost, cost_change, gradient_max_norm, step_norm, relative_decrease, trust_region_radius;
+  int32_t step_is_valid, step_is_successful;
+};
+
+enum { PH_START = 0, PH_EVAL_X0 = 1, PH_EVAL_CAND = 2 };
+
+// Per-window Levenberg-Marquardt state; lives in HBM between launches (pass mode) and in LDS
+// while k_lm runs.  sizeof is a multiple of 8.
+struct LmState {
+  double x_vec[MVO_MAXM][3], x_t[MVO_MAXM];  // accepted point (global parameters)
+  double c_vec[MVO_MAXM][3], c_t[MVO_MAXM];  // candidate
+  double b_vec[MVO_MAXM][3], b_t[MVO_MAXM];  // lowest-cost iterate = what Ceres hands back
+  double H[MVO_MAXC * MVO_MAXC];             // J^T J at x (active columns, row stride MAXC)
+  double g[MVO_MAXC];                        // J^T r at x
+  double jscale[MVO_MAXC], diag[MVO_MAXC], delta[MVO_MAXC];
+  double x_cost, x_norm, min_cost, model_cost_change;
+  double radius, decrease_factor, grad_max_norm;
+  double initial_cost, final_cost;
+  double se_min, se_cur, se_ref, se_cand, se_acc_ref, se_acc_cand;  // TrustRegionStepEvaluator
+  int32_t se_nonmono, reuse_diagonal;
+  int32_t iteration, num_invalid;
+  int32_t nsucc, nunsucc;
+  int32_t status;  // 0 running, 1 terminated
+  int32_t termination, reason;
+  int32_t phase;
+  int32_t ntrace, pad;
+};
+
+struct LmResult {
+  double vec[MVO_MAXM][3];
+  double t[MVO_MAXM];
+  double initial_cost, final_cost;
+  int32_t termination, reason, iterations, nsucc, nunsucc, pad;
+};
+
+// ---- scalar math ----------------------------------------------------------------------
+
+// IR.cpp:298-309 scaleTemplated<double>
+__device__ __forceinline__ double d_scale(double t, double max_len, double min_len) {
+  const double e = exp(-1.0 * t);
+  if (isinf(e)) return min_len;
+  return min_len + ((max_len - min_len) / (1.0 + e));
+}
+
+// derivative as Ceres' Jet arithmetic yields it (0 in the Inf branch)
+__device__ __forceinline__ double d_dscale(double t, double max_len, double min_len) {
+  const double e = exp(-1.0 * t);
+  if (isinf(e)) return 0.0;
+  const double g = 1.0 + e;
+  return (-(max_len - min_len) / (g * g)) * (-e);
+}
+
+// IR.cpp:282-296 + :334-346: x (+) (a,b) = (B*A)*x
+__device__ __forceinline__ void d_plus(const double x[3], double a, double b, double out[3]) {
+  const double da = 1.0 + a * a, db = 1.0 + b * b;
+  const double ca = (1.0 - a * a) / da, sa = (2.0 * a) / da, msa = (-2.0 * a) / da;
+  const double cb = (1.0 - b * b) / db, sb = (2.0 * b) / db, msb = (-2.0 * b) / db;
+  // A = [ca msa 0; sa ca 0; 0 0 1], B = [cb 0 sb; 0 1 0; msb 0 cb]; BA = B*A
+  const double BA[9] = {cb * ca, cb * msa, sb,
+                        sa, ca, 0.0,
+                        msb * ca, msb * msa, cb};
+  out[0] = BA[0] * x[0] + BA[1] * x[1] + BA[2] * x[2];
+  out[1] = BA[3] * x[0] + BA[4] * x[1] + BA[5] * x[2];
+  out[2] = BA[6] * x[0] + BA[7] * x[1] + BA[8] * x[2];
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Summed baseline of pair (a,b) at the point (zvec, zs): IR.cpp:137-144 (offset quirk: only
+// frame b itself is added when b >= M) and IR.cpp:466-577 (s_a v_a + ... left to right),
+// then IR.cpp:254-255 (add offset, normalise).  fr = the window's frame records.
+__device__ __forceinline__ void pair_unit_baseline(const double* __restrict__ fr, int M, int a, int b,
+                                                   const double (*zvec)[3], const double* zs,
+                                                   double u[3], double& nb) {
+  const int kmax = b < M - 1 ? b : M - 1;
+  double bx = 0.0, by = 0.0, bz = 0.0;
+  for (int k = a; k <= kmax; ++k) {
+    const double tx = zs[k] * zvec[k][0], ty = zs[k] * zvec[k][1], tz = zs[k] * zvec[k][2];
+    if (k == a) { bx = tx; by = ty; bz = tz; } else { bx += tx; by += ty; bz += tz; }
+  }
+  if (b >= M) {
+    const double* f = fr + MVO_FRAME_DOUBLES * b;
+    bx += f[12] * f[9];
+    by += f[12] * f[10];
+    bz += f[12] * f[11];
+  }
+  nb = sqrt(bx * bx + by * by + bz * bz);
+  u[0] = bx / nb;
+  u[1] = by / nb;
+  u[2] = bz / nb;
+}

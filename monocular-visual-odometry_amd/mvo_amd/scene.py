@@ -1,0 +1,220 @@
+"""Seeded synthetic scene / trajectory generator for the sliding-window refinement path.
+
+Produces exactly what the reference's ``IterativeRefinement::refine`` consumes
+(/root/reference/mvo/src/algorithms/IterativeRefinement.cpp:15-183):
+
+* ``frames``  -- N records (R row-major 3x3, unit baseline ``vec`` to the previous frame,
+  ``scale``), index 0 = newest (Refiner.cpp:62-68);
+* residual blocks in the reference's pair order ``for a < M: for b in [a, N-1)``
+  (IterativeRefinement.cpp:116,134), CSR ``pair_offsets`` plus unit rays ``m0`` (frame a) and
+  ``m1`` (frame b+1) as ``Frame::getCorrespondingFeatures`` + ``normFeatures`` would return
+  them (Frame.hpp:258-302, FeatureOperations.cpp:117-122): a track contributes to pair (a, b)
+  iff it is alive in frame a and reaches back to frame b+1.
+
+The recipe follows SURVEY.md section 8(d).  Everything is deterministic in ``seed``.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+LOWEST_LENGTH = 0.25  # mvo/cfg/mvo.cfg:45
+HIGHEST_LENGTH = 2.0  # mvo/cfg/mvo.cfg:46
+
+
+def num_pairs(M: int, N: int) -> int:
+    return M * (N - 1) - M * (M - 1) // 2
+
+
+def pair_list(M: int, N: int):
+    return [(a, b) for a in range(M) for b in range(a, N - 1)]
+
+
+@dataclass
+class Window:
+    N: int
+    M: int
+    frames: np.ndarray  # [N, 13] float64: R(9) vec(3) scale(1)  (== the C-ABI frame record)
+    pair_offsets: np.ndarray  # [P+1] uint64
+    m0: np.ndarray  # [n_obs, 3] float64 unit rays in frame a
+    m1: np.ndarray  # [n_obs, 3] float64 unit rays in frame b+1
+    true_vec: np.ndarray  # [N, 3]
+    true_scale: np.ndarray  # [N]
+    bearing_observations: int = 0
+    meta: dict = field(default_factory=dict)
+
+    @property
+    def n_pairs(self) -> int:
+        return len(self.pair_offsets) - 1
+
+    @property
+    def n_residual_blocks(self) -> int:
+        return int(self.pair_offsets[-1])
+
+
+def _small_rotation(rng, sigma_rad):
+    w = rng.normal(0.0, sigma_rad, 3)
+    th = np.linalg.norm(w)
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    if th < 1e-300:
+        return np.eye(3)
+    return np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th**2 * (K @ K)
+
+
+def _rotate_about_random_axis(rng, v, angle_rad):
+    """Rotate unit vector v by angle about a random axis perpendicular to it."""
+    r = rng.normal(size=3)
+    axis = np.cross(v, r)
+    axis /= np.linalg.norm(axis)
+    return v * np.cos(angle_rad) + np.cross(axis, v) * np.sin(angle_rad)
+
+
+def make_window(
+    N: int,
+    M: int,
+    n_landmarks: int,
+    seed: int,
+    span="full",
+    noise_sigma: float = 1e-3,
+    outlier_fraction: float = 0.0,
+    init_angle_deg: float = 3.0,
+    init_scale_jitter: float = 0.2,
+    min_abs_vx: float = 0.2,
+) -> Window:
+    """Build one window.
+
+    span: "full" (every landmark seen in every frame) |
+          ("anchored", lo_span, hi_span): alive from the newest frame, length U[lo,hi] |
+          ("sliding", length): contiguous spans of `length` frames, start uniform so that about
+          half of the landmarks are alive in the newest M frames.
+    """
+    assert 1 <= M < N
+    rng = np.random.Generator(np.random.MT19937(seed))
+
+    # --- trajectory -------------------------------------------------------------------
+    true_scale = rng.uniform(0.4, 1.6, N)
+    d = np.stack(
+        [0.35 + rng.uniform(0.0, 0.3, N), rng.normal(0.0, 0.1, N), np.ones(N)], axis=1
+    )
+    true_vec = d / np.linalg.norm(d, axis=1, keepdims=True)
+    assert np.all(np.abs(true_vec[:, 0]) >= min_abs_vx - 1e-12)
+    pos = np.zeros((N + 1, 3))
+    for i in range(N):
+        pos[i + 1] = pos[i] + true_scale[i] * true_vec[i]
+    R = np.empty((N, 3, 3))
+    R[0] = _small_rotation(rng, np.deg2rad(2.0))
+    for i in range(1, N):
+        R[i] = _small_rotation(rng, np.deg2rad(2.0)) @ R[i - 1]
+
+    # --- landmark visibility spans [lo, hi] (frame indices, lo = newest) -----------------
+    L = n_landmarks
+    if span == "full":
+        lo = np.zeros(L, dtype=np.int64)
+        hi = np.full(L, N - 1, dtype=np.int64)
+    elif span[0] == "anchored":
+        lo = np.zeros(L, dtype=np.int64)
+        ln = rng.integers(span[1], span[2] + 1, L)
+        hi = np.minimum(lo + ln - 1, N - 1)
+    elif span[0] == "sliding":
+        ln = int(span[1])
+        lo = rng.integers(0, max(1, min(2 * M, N - ln) + 1), L)
+        hi = np.minimum(lo + ln - 1, N - 1)
+    else:
+        raise ValueError(span)
+    bearing_obs = int(np.sum(hi - lo + 1))
+    active = np.nonzero((lo < M) & (hi > lo))[0]
+    lo_a, hi_a = lo[active], hi[active]
+    La = len(active)
+
+    # --- landmarks: frustum 60 x 45 deg, depth U[4,40] ahead of the oldest frame of the span
+    z = rng.uniform(4.0, 40.0, La)
+    xc = z * np.tan(np.deg2rad(rng.uniform(-30.0, 30.0, La)))
+    yc = z * np.tan(np.deg2rad(rng.uniform(-22.5, 22.5, La)))
+    cam = np.stack([xc, yc, z], axis=1)
+    X = pos[hi_a] + np.einsum("lij,lj->li", R[hi_a], cam)
+
+    # --- bearings with tangent-plane noise, one per (frame, landmark) --------------------
+    rays = np.empty((N, La, 3))
+    for i in range(N):
+        v = (X - pos[i]) @ R[i]  # R_i^T (X - p_i)
+        v /= np.linalg.norm(v, axis=1, keepdims=True)
+        if noise_sigma > 0:
+            t1 = np.cross(v, np.array([0.0, 1.0, 0.0]))
+            t1 /= np.linalg.norm(t1, axis=1, keepdims=True)
+            t2 = np.cross(v, t1)
+            e = rng.normal(0.0, noise_sigma, (La, 2))
+            v = v + e[:, :1] * t1 + e[:, 1:] * t2
+            v /= np.linalg.norm(v, axis=1, keepdims=True)
+        rays[i] = v
+
+    # --- residual blocks in reference pair order ---------------------------------------
+    pairs = pair_list(M, N)
+    offs = np.zeros(len(pairs) + 1, dtype=np.uint64)
+    m0_parts, m1_parts = [], []
+    for p, (a, b) in enumerate(pairs):
+        ids = np.nonzero((lo_a <= a) & (hi_a >= b + 1))[0]
+        m0_parts.append(rays[a, ids])
+        m1_parts.append(rays[b + 1, ids])
+        offs[p + 1] = offs[p] + np.uint64(len(ids))
+    m0 = np.ascontiguousarray(np.concatenate(m0_parts, axis=0)) if m0_parts else np.zeros((0, 3))
+    m1 = np.ascontiguousarray(np.concatenate(m1_parts, axis=0)) if m1_parts else np.zeros((0, 3))
+
+    if outlier_fraction > 0 and len(m1):
+        n = len(m1)
+        bad = rng.random(n) < outlier_fraction
+        nb = int(bad.sum())
+        zz = np.ones(nb)
+        xx = np.tan(np.deg2rad(rng.uniform(-30.0, 30.0, nb)))
+        yy = np.tan(np.deg2rad(rng.uniform(-22.5, 22.5, nb)))
+        r = np.stack([xx, yy, zz], axis=1)
+        m1[bad] = r / np.linalg.norm(r, axis=1, keepdims=True)
+
+    # --- initial guess ----------------------------------------------------------------
+    frames = np.zeros((N, 13))
+    frames[:, :9] = R.reshape(N, 9)
+    frames[:, 9:12] = true_vec
+    frames[:, 12] = true_scale
+    for k in range(M):
+        frames[k, 9:12] = _rotate_about_random_axis(rng, true_vec[k], np.deg2rad(init_angle_deg))
+        s = true_scale[k] * rng.uniform(1.0 - init_scale_jitter, 1.0 + init_scale_jitter)
+        frames[k, 12] = float(np.clip(s, LOWEST_LENGTH + 0.01, HIGHEST_LENGTH - 0.01))
+
+    return Window(
+        N=N, M=M, frames=frames, pair_offsets=offs, m0=m0, m1=m1, true_vec=true_vec,
+        true_scale=true_scale, bearing_observations=bearing_obs,
+        meta=dict(seed=seed, n_landmarks=n_landmarks, span=span, noise_sigma=noise_sigma,
+                  outlier_fraction=outlier_fraction),
+    )
+
+
+# ---------------------------------------------------------------------------------------
+# BASELINE.json configs.  seed = 1000 + config index (+ window id).
+# ---------------------------------------------------------------------------------------
+def config1(seed: int = 1001) -> Window:
+    """N=10, M=5, 300 landmarks all visible: 3 000 bearing obs, 35 pairs, 10 500 blocks."""
+    return make_window(10, 5, 300, seed, span="full")
+
+
+def config2(seed: int = 1002, outlier_fraction: float = 0.0) -> Window:
+    """N=30, M=5, 5 000 landmarks, spans of 20 frames: ~100k bearing obs."""
+    return make_window(30, 5, 5000, seed, span=("sliding", 20), outlier_fraction=outlier_fraction)
+
+
+def config3_window(window_id: int, seed: int = 1003) -> Window:
+    """One of the 4 096 independent config-1-shaped windows."""
+    return make_window(10, 5, 300, seed + window_id, span="full")
+
+
+def config4(seed: int = 1004, n_active: int = 20000, outlier_fraction: float = 0.0) -> Window:
+    """N=200, M=5, 985 pairs; `n_active` landmarks anchored at the newest frame with span
+    U[2,199] (the other ~180k landmarks of the 200k scene never reach the newest M frames and
+    therefore generate no residual blocks in the reference's formulation)."""
+    return make_window(200, 5, n_active, seed, span=("anchored", 2, 199),
+                       outlier_fraction=outlier_fraction)
+
+
+def reference_defaults_window(seed: int = 7, n_features: int = 60) -> Window:
+    """The reference's shipped defaults: numberToNote=3, numberToRefine=2, <=60 features
+    (mvo/cfg/mvo.cfg:13,42-43)."""
+    return make_window(3, 2, n_features, seed, span="full")
