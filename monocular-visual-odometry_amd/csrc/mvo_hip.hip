@@ -1,0 +1,649 @@
+// mvo_hip.hip -- host side of libmvo_hip: the C ABI declared in include/mvo_hip.h.
+//
+// Replaces IterativeRefinement::refine (/root/reference/mvo/src/algorithms/
+// IterativeRefinement.cpp:15-250, "IR.cpp") from the solver set-up to the write-back.
+// There is no CPU fallback: without a HIP device every entry point fails.
+#include "../../include/mvo_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <vector>
+
+#include "mvo_kernels.h"
+
+static_assert(sizeof(mvo_hip_frame) == MVO_FRAME_DOUBLES * sizeof(double), "frame record layout");
+static_assert(sizeof(TraceRec) == sizeof(mvo_hip_iteration), "trace record layout");
+static_assert(sizeof(LmState) % 8 == 0, "LmState is copied as doubles");
+static_assert(MVO_HIP_MAX_REFINE == MVO_MAXM, "M limit");
+
+namespace {
+
+#define HIP_TRY(expr)                                   \
+  do {                                                  \
+    hipError_t e_ = (expr);                             \
+    if (e_ != hipSuccess) {                             \
+      h->last_hip_error = e_;                           \
+      return e_ == hipErrorOutOfMemory ? MVO_HIP_ERR_OUT_OF_MEMORY : MVO_HIP_ERR_DEVICE; \
+    }                                                   \
+  } while (0)
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <class T>
+  T* as() const { return static_cast<T*>(p); }
+};
+
+constexpr int kMaxTimedLaunches = 128;
+
+}  // namespace
+
+struct mvo_hip_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipError_t last_hip_error = hipSuccess;
+  // device buffers
+  DevBuf d_frames, d_initx, d_wins, d_pairs, d_tiles, d_m0, d_m1, d_c, d_partial, d_pair_u, d_states,
+      d_results, d_status, d_done, d_trace, d_res, d_jac;
+  // pinned host mirror of small results
+  LmResult* h_results = nullptr;
+  size_t h_results_cap = 0;
+  int32_t* h_done = nullptr;
+  // problem description of the last upload
+  bool uploaded = false;
+  uint32_t W = 0, M = 0, N = 0, P = 0;
+  uint64_t n_obs = 0;      // residual blocks (all windows)
+  uint64_t c_elems = 0;    // padded plane length
+  uint32_t n_tiles = 0, n_slots = 0;
+  uint32_t tile_size = 0;
+  mvo_hip_options opt{};
+  bool pass_mode = false;
+  std::vector<mvo_hip_frame> h_frames;  // copy of the uploaded frames (write-back base)
+  std::vector<PairDev> h_pairs;
+  // trace
+  int32_t trace_cap = 0;
+  // timing
+  hipEvent_t ev[2 * kMaxTimedLaunches + 2] = {};
+  bool events_ready = false;
+  mvo_hip_timing timing{};
+};
+
+namespace {
+
+double host_scale(double t, double max_len, double min_len) {
+  double e = std::exp(-1.0 * t);
+  if (std::isinf(e)) return min_len;
+  return min_len + ((max_len - min_len) / (1.0 + e));
+}
+
+// IR.cpp:348-368
+double host_reverse_scale(double length, double max_len, double min_len) {
+  const double eps = std::numeric_limits<double>::epsilon();
+  if (length <= min_len) return host_reverse_scale(min_len + (length * eps) + eps, max_len, min_len);
+  if (length >= max_len) return host_reverse_scale(max_len - (length * eps + eps), max_len, min_len);
+  return -1.0 * std::log((max_len - length) / (length - min_len));
+}
+
+uint32_t num_pairs(uint32_t M, uint32_t N) { return M * (N - 1) - (M * (M - 1)) / 2; }
+
+int validate(uint32_t n_windows, const void* frames, uint32_t M, uint32_t N, const mvo_hip_options* opt,
+             const mvo_hip_observations* obs) {
+  if (!frames || !opt || !obs || n_windows == 0) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  if (M == 0 || N <= M) return MVO_HIP_ERR_INVALID_ARGUMENT;  // IR.cpp:29-30
+  if (M > MVO_HIP_MAX_REFINE) return MVO_HIP_ERR_UNSUPPORTED; // IR.cpp:450
+  if (N > MVO_HIP_MAX_FRAMES) return MVO_HIP_ERR_UNSUPPORTED;
+  if (opt->max_num_iterations < 0) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  if (!(opt->highest_length > opt->lowest_length)) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  const uint32_t P = num_pairs(M, N);
+  uint64_t total = 0;
+  for (uint32_t w = 0; w < n_windows; ++w) {
+    const mvo_hip_observations& o = obs[w];
+    if (o.n_pairs != P || !o.pair_offsets) return MVO_HIP_ERR_INVALID_ARGUMENT;
+    if (o.pair_offsets[0] != 0) return MVO_HIP_ERR_INVALID_ARGUMENT;
+    for (uint32_t p = 0; p < P; ++p)
+      if (o.pair_offsets[p + 1] < o.pair_offsets[p]) return MVO_HIP_ERR_INVALID_ARGUMENT;
+    if (o.pair_offsets[P] > 0 && (!o.m0 || !o.m1)) return MVO_HIP_ERR_INVALID_ARGUMENT;
+    total += o.pair_offsets[P];
+  }
+  if (total + 64ull * P * n_windows >= (1ull << 31)) return MVO_HIP_ERR_UNSUPPORTED;
+  return MVO_HIP_OK;
+}
+
+SolveParams make_params(const mvo_hip_context* h) {
+  SolveParams prm{};
+  prm.ftol = h->opt.function_tolerance;
+  prm.gtol = h->opt.gradient_tolerance;
+  prm.ptol = h->opt.parameter_tolerance;
+  prm.min_len = h->opt.lowest_length;
+  prm.max_len = h->opt.highest_length;
+  prm.max_it = h->opt.max_num_iterations;
+  prm.use_loss = h->opt.use_loss_function ? 1 : 0;
+  prm.fix_length = h->opt.fix_length ? 1 : 0;
+  prm.pass_mode = h->pass_mode ? 1 : 0;
+  prm.trace_cap = h->trace_cap;
+  return prm;
+}
+
+int ensure_events(mvo_hip_context* h) {
+  if (h->events_ready) return MVO_HIP_OK;
+  for (auto& e : h->ev) HIP_TRY(hipEventCreate(&e));
+  h->events_ready = true;
+  return MVO_HIP_OK;
+}
+
+int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint32_t M, uint32_t N,
+              const mvo_hip_options* opt, const mvo_hip_observations* obs) {
+  const auto t_begin = std::chrono::steady_clock::now();
+  int rc = validate(W, frames, M, N, opt, obs);
+  if (rc != MVO_HIP_OK) return rc;
+  HIP_TRY(hipSetDevice(h->device));
+  h->uploaded = false;
+  const uint32_t P = num_pairs(M, N);
+  h->W = W;
+  h->M = M;
+  h->N = N;
+  h->P = P;
+  h->opt = *opt;
+  h->pass_mode = opt->use_loss_function || opt->assembly_mode == MVO_HIP_ASSEMBLY_PASSES;
+
+  uint64_t n_obs = 0;
+  for (uint32_t w = 0; w < W; ++w) n_obs += obs[w].pair_offsets[P];
+  h->n_obs = n_obs;
+  // tile size: enough wave-tiles to fill 256 CUs x 32 waves a few times over
+  uint32_t tile = 1024;
+  while (tile > 128 && n_obs / tile < 16384) tile >>= 1;
+  h->tile_size = tile;
+
+  std::vector<WinDev> wins(W);
+  std::vector<PairDev>& pairs = h->h_pairs;
+  pairs.assign((size_t)W * P, PairDev{});
+  std::vector<TileDev> tiles;
+  tiles.reserve((size_t)(n_obs / tile) + (size_t)W * P + 8);
+  std::vector<double> initx((size_t)W * MVO_MAXM * 4, 0.0);
+  uint64_t src = 0, cpos = 0;
+  uint32_t slot = 0;
+  for (uint32_t w = 0; w < W; ++w) {
+    wins[w].frame_off = w * N;
+    wins[w].pair_off = w * P;
+    wins[w].N = N;
+    wins[w].M = M;
+    wins[w].P = P;
+    for (uint32_t k = 0; k < M; ++k) {
+      const mvo_hip_frame& f = frames[(size_t)w * N + k];
+      double* x = &initx[((size_t)w * MVO_MAXM + k) * 4];
+      x[0] = f.vec[0];
+      x[1] = f.vec[1];
+      x[2] = f.vec[2];
+      x[3] = host_reverse_scale(f.scale, opt->highest_length, opt->lowest_length);  // IR.cpp:102
+    }
+    uint32_t p = 0;
+    for (uint32_t a = 0; a < M; ++a)
+      for (uint32_t b = a; b < N - 1; ++b, ++p) {
+        PairDev& pd = pairs[(size_t)w * P + p];
+        pd.a = a;
+        pd.b = b;
+        const uint64_t cnt = obs[w].pair_offsets[p + 1] - obs[w].pair_offsets[p];
+        pd.slot_begin = slot;
+        uint32_t cur_slot = 0;
+        for (uint64_t done = 0; done < cnt; done += tile) {
+          TileDev t{};
+          t.pair = w * P + p;
+          t.win = w;
+          t.src_start = (uint32_t)(src + done);
+          t.c_start = (uint32_t)(cpos + done);
+          t.count = (uint32_t)((cnt - done) < tile ? (cnt - done) : tile);
+          t.f0 = w * N + a;      // IR.cpp:172  R0 = frames[frame0].R
+          t.f1 = w * N + b + 1;  // IR.cpp:171  R1 = frames[frame1 + 1].R
+          // a slot never spans workgroups: new slot at a workgroup boundary or a new pair
+          if (done == 0 || (tiles.size() % FOLD_WAVES) == 0) cur_slot = slot++;
+          t.slot = cur_slot;
+          tiles.push_back(t);
+        }
+        pd.slot_end = slot;
+        src += cnt;
+        cpos += (cnt + 31) & ~31ull;  // pair segments of c start on 256-byte boundaries
+      }
+  }
+  h->n_tiles = (uint32_t)tiles.size();
+  h->n_slots = slot;
+  h->c_elems = cpos + 32;
+
+  h->h_frames.assign(frames, frames + (size_t)W * N);
+
+  HIP_TRY(h->d_frames.reserve(sizeof(mvo_hip_frame) * (size_t)W * N));
+  HIP_TRY(h->d_initx.reserve(sizeof(double) * initx.size()));
+  HIP_TRY(h->d_wins.reserve(sizeof(WinDev) * W));
+  HIP_TRY(h->d_pairs.reserve(sizeof(PairDev) * pairs.size()));
+  HIP_TRY(h->d_tiles.reserve(sizeof(TileDev) * (tiles.size() + 1)));
+  HIP_TRY(h->d_m0.reserve(sizeof(double) * 3 * (n_obs + 1)));
+  HIP_TRY(h->d_m1.reserve(sizeof(double) * 3 * (n_obs + 1)));
+  if (h->pass_mode) HIP_TRY(h->d_c.reserve(sizeof(double) * 3 * h->c_elems));
+  HIP_TRY(h->d_partial.reserve(sizeof(double) * 8 * ((size_t)slot + 1)));
+  HIP_TRY(h->d_pair_u.reserve(sizeof(double) * 4 * pairs.size()));
+  HIP_TRY(h->d_states.reserve(sizeof(LmState) * W));
+  HIP_TRY(h->d_results.reserve(sizeof(LmResult) * W));
+  HIP_TRY(h->d_status.reserve(sizeof(int32_t) * W));
+  HIP_TRY(h->d_done.reserve(sizeof(int32_t) * 4));
+  if (h->h_results_cap < W) {
+    if (h->h_results) (void)hipHostFree(h->h_results);
+    h->h_results = nullptr;
+    h->h_results_cap = 0;
+    HIP_TRY(hipHostMalloc((void**)&h->h_results, sizeof(LmResult) * W, hipHostMallocDefault));
+    h->h_results_cap = W;
+  }
+  if (!h->h_done) HIP_TRY(hipHostMalloc((void**)&h->h_done, sizeof(int32_t) * 4, hipHostMallocDefault));
+
+  hipStream_t s = h->stream;
+  HIP_TRY(hipMemcpyAsync(h->d_frames.p, frames, sizeof(mvo_hip_frame) * (size_t)W * N, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(h->d_initx.p, initx.data(), sizeof(double) * initx.size(), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(h->d_wins.p, wins.data(), sizeof(WinDev) * W, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(h->d_pairs.p, pairs.data(), sizeof(PairDev) * pairs.size(), hipMemcpyHostToDevice, s));
+  if (!tiles.empty())
+    HIP_TRY(hipMemcpyAsync(h->d_tiles.p, tiles.data(), sizeof(TileDev) * tiles.size(), hipMemcpyHostToDevice, s));
+  uint64_t pos = 0;
+  for (uint32_t w = 0; w < W; ++w) {
+    const uint64_t cnt = obs[w].pair_offsets[P];
+    if (cnt) {
+      HIP_TRY(hipMemcpyAsync(h->d_m0.as<double>() + 3 * pos, obs[w].m0, sizeof(double) * 3 * cnt,
+                             hipMemcpyHostToDevice, s));
+      HIP_TRY(hipMemcpyAsync(h->d_m1.as<double>() + 3 * pos, obs[w].m1, sizeof(double) * 3 * cnt,
+                             hipMemcpyHostToDevice, s));
+    }
+    pos += cnt;
+  }
+  HIP_TRY(hipStreamSynchronize(s));  // the staging vectors above die with this scope
+  h->uploaded = true;
+  h->timing.upload_seconds =
+      std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+  return MVO_HIP_OK;
+}
+
+template <int NT>
+hipError_t launch_lm(mvo_hip_context* h, const SolveParams& prm) {
+  const size_t dyn = sizeof(double) * 10 * (size_t)h->P;
+  static size_t configured = 0;
+  if (dyn > configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lm<NT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+    if (e != hipSuccess) return e;
+    configured = dyn;
+  }
+  hipLaunchKernelGGL(k_lm<NT>, dim3(h->W), dim3(NT), dyn, h->stream, prm, h->d_wins.as<WinDev>(),
+                     h->d_frames.as<double>(), h->d_initx.as<double>(), h->d_pairs.as<PairDev>(),
+                     h->d_partial.as<double>(), h->d_states.as<LmState>(), h->d_results.as<LmResult>(),
+                     h->d_pair_u.as<double>(), h->d_status.as<int32_t>(), h->d_trace.as<TraceRec>(),
+                     h->d_done.as<int32_t>());
+  return hipGetLastError();
+}
+
+hipError_t launch_lm_any(mvo_hip_context* h, const SolveParams& prm) {
+  return h->P <= 64 ? launch_lm<64>(h, prm) : launch_lm<256>(h, prm);
+}
+
+int do_solve(mvo_hip_context* h) {
+  if (!h->uploaded) return MVO_HIP_ERR_STATE;
+  const auto t_begin = std::chrono::steady_clock::now();
+  HIP_TRY(hipSetDevice(h->device));
+  int rc = ensure_events(h);
+  if (rc != MVO_HIP_OK) return rc;
+  hipStream_t s = h->stream;
+  const SolveParams prm = make_params(h);
+  if (h->trace_cap > 0) HIP_TRY(h->d_trace.reserve(sizeof(TraceRec) * (size_t)h->trace_cap));
+
+  HIP_TRY(hipMemsetAsync(h->d_states.p, 0, sizeof(LmState) * h->W, s));
+  HIP_TRY(hipMemsetAsync(h->d_status.p, 0, sizeof(int32_t) * h->W, s));
+  HIP_TRY(hipMemsetAsync(h->d_done.p, 0, sizeof(int32_t) * 4, s));
+
+  const uint32_t fold_blocks = (h->n_tiles + FOLD_WAVES - 1) / FOLD_WAVES;
+  int n_timed = 0;
+  auto timed_begin = [&]() -> hipError_t {
+    return n_timed < kMaxTimedLaunches ? hipEventRecord(h->ev[2 + 2 * n_timed], s) : hipSuccess;
+  };
+  auto timed_end = [&]() -> hipError_t {
+    hipError_t e = n_timed < kMaxTimedLaunches ? hipEventRecord(h->ev[3 + 2 * n_timed], s) : hipSuccess;
+    ++n_timed;
+    return e;
+  };
+
+  HIP_TRY(hipEventRecord(h->ev[0], s));
+  int lm_launches = 0, asm_launches = 0;
+  if (!h->pass_mode) {
+    // one fold+moment pass, then the whole LM loop in a single launch
+    if (fold_blocks) {
+      HIP_TRY(timed_begin());
+      hipLaunchKernelGGL((k_fold<false, true>), dim3(fold_blocks), dim3(FOLD_THREADS), 0, s,
+                         h->d_tiles.as<TileDev>(), h->n_tiles, h->d_frames.as<double>(), h->d_m0.as<double>(),
+                         h->d_m1.as<double>(), (double*)nullptr, (size_t)0, h->d_partial.as<double>());
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(timed_end());
+      ++asm_launches;
+    }
+    HIP_TRY(launch_lm_any(h, prm));
+    ++lm_launches;
+  } else {
+    if (fold_blocks) {
+      HIP_TRY(timed_begin());
+      hipLaunchKernelGGL((k_fold<true, false>), dim3(fold_blocks), dim3(FOLD_THREADS), 0, s,
+                         h->d_tiles.as<TileDev>(), h->n_tiles, h->d_frames.as<double>(), h->d_m0.as<double>(),
+                         h->d_m1.as<double>(), h->d_c.as<double>(), (size_t)h->c_elems, h->d_partial.as<double>());
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(timed_end());
+      ++asm_launches;
+    }
+    HIP_TRY(launch_lm_any(h, prm));  // PH_START: publishes u(x0)
+    ++lm_launches;
+    // at most max_it + 1 evaluations (x0 and one candidate per iteration); enqueue them in
+    // chunks without any host round-trip inside a chunk, and look at the done counter between
+    const int total_evals = h->opt.max_num_iterations + 1;
+    const int chunk = 12;
+    int issued = 0;
+    while (issued < total_evals) {
+      const int n = (total_evals - issued) < chunk ? (total_evals - issued) : chunk;
+      for (int i = 0; i < n; ++i) {
+        if (fold_blocks) {
+          HIP_TRY(timed_begin());
+          if (prm.use_loss)
+            hipLaunchKernelGGL((k_pass<true>), dim3(fold_blocks), dim3(FOLD_THREADS), 0, s,
+                               h->d_tiles.as<TileDev>(), h->n_tiles, h->d_c.as<double>(), (size_t)h->c_elems,
+                               h->d_pair_u.as<double>(), h->d_status.as<int32_t>(), h->d_partial.as<double>());
+          else
+            hipLaunchKernelGGL((k_pass<false>), dim3(fold_blocks), dim3(FOLD_THREADS), 0, s,
+                               h->d_tiles.as<TileDev>(), h->n_tiles, h->d_c.as<double>(), (size_t)h->c_elems,
+                               h->d_pair_u.as<double>(), h->d_status.as<int32_t>(), h->d_partial.as<double>());
+          HIP_TRY(hipGetLastError());
+          HIP_TRY(timed_end());
+          ++asm_launches;
+        }
+        HIP_TRY(launch_lm_any(h, prm));
+        ++lm_launches;
+      }
+      issued += n;
+      if (issued < total_evals) {
+        HIP_TRY(hipMemcpyAsync(h->h_done, h->d_done.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if ((uint32_t)h->h_done[0] >= h->W) break;
+      }
+    }
+  }
+  HIP_TRY(hipEventRecord(h->ev[1], s));
+  HIP_TRY(hipMemcpyAsync(h->h_results, h->d_results.p, sizeof(LmResult) * h->W, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(h->h_done, h->d_done.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if ((uint32_t)h->h_done[0] != h->W) return MVO_HIP_ERR_DEVICE;  // every window must have terminated
+
+  mvo_hip_timing& tm = h->timing;
+  tm.solve_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
+  tm.device_seconds = ms * 1e-3;
+  tm.assembly_seconds = 0.0;
+  tm.assembly_first_seconds = 0.0;
+  const int nt = n_timed < kMaxTimedLaunches ? n_timed : kMaxTimedLaunches;
+  double pass_seconds = 0.0;
+  for (int i = 0; i < nt; ++i) {
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev[2 + 2 * i], h->ev[3 + 2 * i]));
+    if (i == 0) tm.assembly_first_seconds = ms * 1e-3;
+    else pass_seconds += ms * 1e-3;
+  }
+  tm.assembly_launches = asm_launches;
+  tm.lm_launches = lm_launches;
+  tm.residual_blocks = h->n_obs;
+  if (!h->pass_mode) {
+    tm.assembly_seconds = tm.assembly_first_seconds;
+    tm.assembly_bytes = 48ull * h->n_obs;  // k_fold<moments>: read m0, m1
+  } else {
+    tm.assembly_seconds = pass_seconds;    // k_pass launches only (the fold is reported apart)
+    tm.assembly_launches = nt > 0 ? nt - 1 : 0;
+    tm.assembly_bytes = 24ull * h->n_obs;  // k_pass: read c
+  }
+  return MVO_HIP_OK;
+}
+
+int do_download(mvo_hip_context* h, mvo_hip_frame* frames, mvo_hip_summary* summaries) {
+  if (!h->uploaded) return MVO_HIP_ERR_STATE;
+  for (uint32_t w = 0; w < h->W; ++w) {
+    const LmResult& r = h->h_results[w];
+    if (frames) {
+      // IR.cpp:240-246: refined frames get scale = s(t) and the optimised direction
+      for (uint32_t k = 0; k < h->M; ++k) {
+        mvo_hip_frame& f = frames[(size_t)w * h->N + k];
+        f.scale = host_scale(r.t[k], h->opt.highest_length, h->opt.lowest_length);
+        f.vec[0] = r.vec[k][0];
+        f.vec[1] = r.vec[k][1];
+        f.vec[2] = r.vec[k][2];
+      }
+    }
+    if (summaries) {
+      mvo_hip_summary& sm = summaries[w];
+      sm.termination = r.termination;
+      sm.reason = r.reason;
+      sm.iterations = r.iterations;
+      sm.num_successful_steps = r.nsucc;
+      sm.num_unsuccessful_steps = r.nunsucc;
+      sm.reserved = 0;
+      sm.initial_cost = r.initial_cost;
+      sm.final_cost = r.final_cost;
+    }
+  }
+  return MVO_HIP_OK;
+}
+
+}  // namespace
+
+// =========================================================================================
+// C ABI
+// =========================================================================================
+extern "C" {
+
+int mvo_hip_create(int device_ordinal, uint32_t max_windows, uint32_t max_frames, uint64_t max_observations,
+                   mvo_hip_handle* out) {
+  if (!out) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return MVO_HIP_ERR_NO_DEVICE;
+  if (device_ordinal < 0 || device_ordinal >= count) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  mvo_hip_context* h = new (std::nothrow) mvo_hip_context();
+  if (!h) return MVO_HIP_ERR_OUT_OF_MEMORY;
+  h->device = device_ordinal;
+  if (hipSetDevice(device_ordinal) != hipSuccess ||
+      hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete h;
+    return MVO_HIP_ERR_DEVICE;
+  }
+  // capacity hints: pre-size the large buffers so that the first refine() allocates nothing big
+  if (max_observations) {
+    (void)h->d_m0.reserve(sizeof(double) * 3 * (max_observations + 1));
+    (void)h->d_m1.reserve(sizeof(double) * 3 * (max_observations + 1));
+  }
+  if (max_windows && max_frames) (void)h->d_frames.reserve(sizeof(mvo_hip_frame) * (size_t)max_windows * max_frames);
+  *out = h;
+  return MVO_HIP_OK;
+}
+
+void mvo_hip_destroy(mvo_hip_handle h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  DevBuf* bufs[] = {&h->d_frames, &h->d_initx, &h->d_wins, &h->d_pairs, &h->d_tiles, &h->d_m0, &h->d_m1,
+                    &h->d_c, &h->d_partial, &h->d_pair_u, &h->d_states, &h->d_results, &h->d_status,
+                    &h->d_done, &h->d_trace, &h->d_res, &h->d_jac};
+  for (DevBuf* b : bufs) b->release();
+  if (h->h_results) (void)hipHostFree(h->h_results);
+  if (h->h_done) (void)hipHostFree(h->h_done);
+  if (h->events_ready)
+    for (auto& e : h->ev) (void)hipEventDestroy(e);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int mvo_hip_upload(mvo_hip_handle h, uint32_t n_windows, const mvo_hip_frame* frames, uint32_t M, uint32_t N,
+                   const mvo_hip_options* options, const mvo_hip_observations* observations) {
+  if (!h) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  return do_upload(h, n_windows, frames, M, N, options, observations);
+}
+
+int mvo_hip_solve(mvo_hip_handle h) {
+  if (!h) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  return do_solve(h);
+}
+
+int mvo_hip_download(mvo_hip_handle h, mvo_hip_frame* frames, mvo_hip_summary* summaries) {
+  if (!h) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  return do_download(h, frames, summaries);
+}
+
+int mvo_hip_refine_batch(mvo_hip_handle h, uint32_t n_windows, mvo_hip_frame* frames, uint32_t M, uint32_t N,
+                         const mvo_hip_options* options, const mvo_hip_observations* observations,
+                         mvo_hip_summary* summaries) {
+  if (!h) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  int rc = do_upload(h, n_windows, frames, M, N, options, observations);
+  if (rc != MVO_HIP_OK) return rc;
+  rc = do_solve(h);
+  if (rc != MVO_HIP_OK) return rc;
+  return do_download(h, frames, summaries);
+}
+
+int mvo_hip_refine(mvo_hip_handle h, mvo_hip_frame* frames, uint32_t M, uint32_t N,
+                   const mvo_hip_options* options, const mvo_hip_observations* observations,
+                   mvo_hip_summary* summary) {
+  return mvo_hip_refine_batch(h, 1, frames, M, N, options, observations, summary);
+}
+
+int mvo_hip_eval(mvo_hip_handle h, const mvo_hip_frame* frames, uint32_t M, uint32_t N,
+                 const mvo_hip_options* options, const mvo_hip_observations* observations, double* residuals,
+                 double* jacobian, double* cost) {
+  if (!h) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  int rc = do_upload(h, 1, frames, M, N, options, observations);
+  if (rc != MVO_HIP_OK) return rc;
+  const uint64_t n = h->n_obs;
+  const bool want_res = residuals || cost;
+  if (want_res) HIP_TRY(h->d_res.reserve(sizeof(double) * (n + 1)));
+  if (jacobian) HIP_TRY(h->d_jac.reserve(sizeof(double) * (n + 1) * 3 * M));
+  const uint32_t blocks = (h->n_tiles + FOLD_WAVES - 1) / FOLD_WAVES;
+  if (blocks) {
+    hipLaunchKernelGGL(k_eval, dim3(blocks), dim3(FOLD_THREADS), 0, h->stream, make_params(h),
+                       h->d_tiles.as<TileDev>(), h->n_tiles, h->d_wins.as<WinDev>(), h->d_pairs.as<PairDev>(),
+                       h->d_frames.as<double>(), h->d_initx.as<double>(), h->d_m0.as<double>(),
+                       h->d_m1.as<double>(), want_res ? h->d_res.as<double>() : (double*)nullptr,
+                       jacobian ? h->d_jac.as<double>() : (double*)nullptr);
+    HIP_TRY(hipGetLastError());
+  }
+  std::vector<double> tmp;
+  double* rdst = residuals;
+  if (!rdst && cost) {
+    tmp.resize(n);
+    rdst = tmp.data();
+  }
+  if (rdst && n) HIP_TRY(hipMemcpyAsync(rdst, h->d_res.p, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+  if (jacobian && n)
+    HIP_TRY(hipMemcpyAsync(jacobian, h->d_jac.p, sizeof(double) * n * 3 * M, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (cost) {
+    double c = 0.0;
+    for (uint64_t i = 0; i < n; ++i) c += 0.5 * rdst[i] * rdst[i];
+    *cost = c;
+  }
+  return MVO_HIP_OK;
+}
+
+int mvo_hip_pair_moments(mvo_hip_handle h, double* moments) {
+  if (!h || !moments) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  if (!h->uploaded) return MVO_HIP_ERR_STATE;
+  HIP_TRY(hipSetDevice(h->device));
+  const uint32_t blocks = (h->n_tiles + FOLD_WAVES - 1) / FOLD_WAVES;
+  if (blocks) {
+    hipLaunchKernelGGL((k_fold<false, true>), dim3(blocks), dim3(FOLD_THREADS), 0, h->stream,
+                       h->d_tiles.as<TileDev>(), h->n_tiles, h->d_frames.as<double>(), h->d_m0.as<double>(),
+                       h->d_m1.as<double>(), (double*)nullptr, (size_t)0, h->d_partial.as<double>());
+    HIP_TRY(hipGetLastError());
+  }
+  std::vector<double> part((size_t)h->n_slots * 8 + 8);
+  if (h->n_slots)
+    HIP_TRY(hipMemcpyAsync(part.data(), h->d_partial.p, sizeof(double) * 8 * h->n_slots, hipMemcpyDeviceToHost,
+                           h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  for (size_t p = 0; p < h->h_pairs.size(); ++p) {
+    double S[6] = {0, 0, 0, 0, 0, 0};
+    for (uint32_t sl = h->h_pairs[p].slot_begin; sl < h->h_pairs[p].slot_end; ++sl)
+      for (int v = 0; v < 6; ++v) S[v] += part[(size_t)sl * 8 + v];
+    std::memcpy(moments + 6 * p, S, sizeof S);
+  }
+  return MVO_HIP_OK;
+}
+
+int mvo_hip_set_trace(mvo_hip_handle h, int32_t capacity) {
+  if (!h || capacity < 0) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  h->trace_cap = capacity;
+  return MVO_HIP_OK;
+}
+
+int mvo_hip_get_trace(mvo_hip_handle h, mvo_hip_iteration* rows, int32_t capacity, int32_t* n_rows) {
+  if (!h || !n_rows) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  if (!h->uploaded) return MVO_HIP_ERR_STATE;
+  const int32_t produced = h->h_results[0].iterations + 1;
+  *n_rows = produced;
+  int32_t n = produced < h->trace_cap ? produced : h->trace_cap;
+  if (n > capacity) n = capacity;
+  if (rows && n > 0) {
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpy(rows, h->d_trace.p, sizeof(mvo_hip_iteration) * (size_t)n, hipMemcpyDeviceToHost));
+  }
+  return MVO_HIP_OK;
+}
+
+int mvo_hip_get_timing(mvo_hip_handle h, mvo_hip_timing* out) {
+  if (!h || !out) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  *out = h->timing;
+  return MVO_HIP_OK;
+}
+
+double mvo_hip_reverse_scale(double length, double highest_length, double lowest_length) {
+  return host_reverse_scale(length, highest_length, lowest_length);
+}
+
+double mvo_hip_scale(double t, double highest_length, double lowest_length) {
+  return host_scale(t, highest_length, lowest_length);
+}
+
+uint32_t mvo_hip_num_pairs(uint32_t M, uint32_t N) {
+  if (M == 0 || N <= M) return 0;
+  return num_pairs(M, N);
+}
+
+const char* mvo_hip_status_string(int status) {
+  switch (status) {
+    case MVO_HIP_OK: return "ok";
+    case MVO_HIP_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case MVO_HIP_ERR_UNSUPPORTED: return "unsupported problem shape (numberToRefine > 5, too many frames or observations)";
+    case MVO_HIP_ERR_OUT_OF_MEMORY: return "out of device memory";
+    case MVO_HIP_ERR_DEVICE: return "HIP runtime error";
+    case MVO_HIP_ERR_NO_DEVICE: return "no HIP device (libmvo_hip has no CPU fallback)";
+    case MVO_HIP_ERR_STATE: return "no problem uploaded";
+    default: return "unknown status";
+  }
+}
+
+const char* mvo_hip_version(void) { return "libmvo_hip 0.1 (gfx950)"; }
+
+}  // extern "C"

@@ -1,0 +1,315 @@
+"""ctypes binding of libmvo_hip's C ABI (include/mvo_hip.h).
+
+This is plumbing for tests and bench.py; the product is the shared library.  There is no CPU
+fallback anywhere in this module: if libmvo_hip.so is missing, or no HIP device is present,
+calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG_ROOT, "libmvo_hip.so")
+
+OK = 0
+ERR_INVALID_ARGUMENT = 1
+ERR_UNSUPPORTED = 2
+ERR_OUT_OF_MEMORY = 3
+ERR_DEVICE = 4
+ERR_NO_DEVICE = 5
+ERR_STATE = 6
+
+ASSEMBLY_AUTO = 0
+ASSEMBLY_PASSES = 1
+
+EXPORTED_SYMBOLS = [
+    "mvo_hip_create", "mvo_hip_destroy", "mvo_hip_refine", "mvo_hip_refine_batch", "mvo_hip_upload",
+    "mvo_hip_solve", "mvo_hip_download", "mvo_hip_eval", "mvo_hip_pair_moments", "mvo_hip_set_trace",
+    "mvo_hip_get_trace", "mvo_hip_get_timing", "mvo_hip_reverse_scale", "mvo_hip_scale",
+    "mvo_hip_num_pairs", "mvo_hip_status_string", "mvo_hip_version",
+]
+
+
+class Options(C.Structure):
+    _fields_ = [
+        ("max_num_iterations", C.c_int32),
+        ("num_threads", C.c_int32),
+        ("function_tolerance", C.c_double),
+        ("gradient_tolerance", C.c_double),
+        ("parameter_tolerance", C.c_double),
+        ("use_loss_function", C.c_int32),
+        ("fix_length", C.c_int32),
+        ("lowest_length", C.c_double),
+        ("highest_length", C.c_double),
+        ("assembly_mode", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+class Observations(C.Structure):
+    _fields_ = [
+        ("n_pairs", C.c_uint32),
+        ("reserved", C.c_uint32),
+        ("pair_offsets", C.POINTER(C.c_uint64)),
+        ("m0", C.POINTER(C.c_double)),
+        ("m1", C.POINTER(C.c_double)),
+    ]
+
+
+class Summary(C.Structure):
+    _fields_ = [
+        ("termination", C.c_int32),
+        ("reason", C.c_int32),
+        ("iterations", C.c_int32),
+        ("num_successful_steps", C.c_int32),
+        ("num_unsuccessful_steps", C.c_int32),
+        ("reserved", C.c_int32),
+        ("initial_cost", C.c_double),
+        ("final_cost", C.c_double),
+    ]
+
+
+class Iteration(C.Structure):
+    _fields_ = [
+        ("cost", C.c_double),
+        ("cost_change", C.c_double),
+        ("gradient_max_norm", C.c_double),
+        ("step_norm", C.c_double),
+        ("relative_decrease", C.c_double),
+        ("trust_region_radius", C.c_double),
+        ("step_is_valid", C.c_int32),
+        ("step_is_successful", C.c_int32),
+    ]
+
+
+class Timing(C.Structure):
+    _fields_ = [
+        ("upload_seconds", C.c_double),
+        ("solve_seconds", C.c_double),
+        ("device_seconds", C.c_double),
+        ("assembly_seconds", C.c_double),
+        ("assembly_launches", C.c_int32),
+        ("lm_launches", C.c_int32),
+        ("residual_blocks", C.c_uint64),
+        ("assembly_bytes", C.c_uint64),
+        ("assembly_first_seconds", C.c_double),
+    ]
+
+
+class MvoHipError(RuntimeError):
+    def __init__(self, status, what):
+        self.status = status
+        super().__init__(f"{what}: status {status} ({status_string(status)})")
+
+
+_LIB = None
+
+
+def load():
+    """dlopen libmvo_hip.so (in-tree).  Raises if it has not been built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(
+                f"{LIB_PATH} is missing: build it with `make -C {_PKG_ROOT}` "
+                "(python __graft_entry__.py does). There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        L.mvo_hip_create.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(C.c_void_p)]
+        L.mvo_hip_destroy.argtypes = [C.c_void_p]
+        L.mvo_hip_destroy.restype = None
+        L.mvo_hip_refine.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(Options),
+                                     C.POINTER(Observations), C.POINTER(Summary)]
+        L.mvo_hip_refine_batch.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32,
+                                           C.POINTER(Options), C.POINTER(Observations), C.POINTER(Summary)]
+        L.mvo_hip_upload.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32,
+                                     C.POINTER(Options), C.POINTER(Observations)]
+        L.mvo_hip_solve.argtypes = [C.c_void_p]
+        L.mvo_hip_download.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Summary)]
+        L.mvo_hip_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(Options),
+                                   C.POINTER(Observations), C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+        L.mvo_hip_pair_moments.argtypes = [C.c_void_p, C.c_void_p]
+        L.mvo_hip_set_trace.argtypes = [C.c_void_p, C.c_int32]
+        L.mvo_hip_get_trace.argtypes = [C.c_void_p, C.POINTER(Iteration), C.c_int32, C.POINTER(C.c_int32)]
+        L.mvo_hip_get_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
+        L.mvo_hip_reverse_scale.argtypes = [C.c_double] * 3
+        L.mvo_hip_reverse_scale.restype = C.c_double
+        L.mvo_hip_scale.argtypes = [C.c_double] * 3
+        L.mvo_hip_scale.restype = C.c_double
+        L.mvo_hip_num_pairs.argtypes = [C.c_uint32, C.c_uint32]
+        L.mvo_hip_num_pairs.restype = C.c_uint32
+        L.mvo_hip_status_string.argtypes = [C.c_int]
+        L.mvo_hip_status_string.restype = C.c_char_p
+        L.mvo_hip_version.restype = C.c_char_p
+        _LIB = L
+    return _LIB
+
+
+def status_string(status):
+    return load().mvo_hip_status_string(int(status)).decode()
+
+
+def make_options(max_num_iterations=50, function_tolerance=1e-6, gradient_tolerance=1e-10,
+                 parameter_tolerance=1e-8, use_loss_function=False, fix_length=False,
+                 lowest_length=0.25, highest_length=2.0, num_threads=4, assembly_mode=ASSEMBLY_AUTO):
+    """Defaults: mvo/cfg/mvo.cfg:39-53 after Refiner.cpp:72-74's 10^-x conversion."""
+    return Options(max_num_iterations, num_threads, function_tolerance, gradient_tolerance,
+                   parameter_tolerance, int(use_loss_function), int(fix_length), lowest_length,
+                   highest_length, assembly_mode, 0)
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class _Packed:
+    """Keeps the numpy buffers behind an Observations[] array alive."""
+
+    def __init__(self, windows):
+        self.keep = []
+        self.arr = (Observations * len(windows))()
+        for i, w in enumerate(windows):
+            offs = np.ascontiguousarray(w.pair_offsets, dtype=np.uint64)
+            m0 = np.ascontiguousarray(w.m0, dtype=np.float64)
+            m1 = np.ascontiguousarray(w.m1, dtype=np.float64)
+            self.keep += [offs, m0, m1]
+            self.arr[i].n_pairs = len(offs) - 1
+            self.arr[i].pair_offsets = offs.ctypes.data_as(C.POINTER(C.c_uint64))
+            self.arr[i].m0 = _dp(m0)
+            self.arr[i].m1 = _dp(m1)
+
+
+class Solver:
+    """One mvo_hip_handle (one GPU, one stream)."""
+
+    def __init__(self, device=0, max_windows=0, max_frames=0, max_observations=0):
+        self._lib = load()
+        self._h = C.c_void_p()
+        rc = self._lib.mvo_hip_create(int(device), max_windows, max_frames, max_observations, C.byref(self._h))
+        if rc != OK:
+            self._h = None
+            raise MvoHipError(rc, "mvo_hip_create")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mvo_hip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- the reference's operator: refine() ------------------------------------------------
+    def refine(self, window, options=None):
+        """-> (frames_out[N,13], Summary). window: mvo_amd.scene.Window-like."""
+        opt = options or make_options()
+        frames = np.ascontiguousarray(window.frames, dtype=np.float64).copy()
+        pk = _Packed([window])
+        summ = Summary()
+        rc = self._lib.mvo_hip_refine(self._h, frames.ctypes.data, window.M, window.N, C.byref(opt), pk.arr,
+                                      C.byref(summ))
+        if rc != OK:
+            raise MvoHipError(rc, "mvo_hip_refine")
+        return frames, summ
+
+    def refine_batch(self, windows, options=None):
+        opt = options or make_options()
+        W = len(windows)
+        M, N = windows[0].M, windows[0].N
+        frames = np.ascontiguousarray(np.concatenate([w.frames for w in windows], axis=0), dtype=np.float64)
+        pk = _Packed(windows)
+        summ = (Summary * W)()
+        rc = self._lib.mvo_hip_refine_batch(self._h, W, frames.ctypes.data, M, N, C.byref(opt), pk.arr, summ)
+        if rc != OK:
+            raise MvoHipError(rc, "mvo_hip_refine_batch")
+        return frames.reshape(W, N, 13), list(summ)
+
+    # -- split phase ----------------------------------------------------------------------
+    def upload(self, windows, options=None):
+        opt = options or make_options()
+        self._W, self._M, self._N = len(windows), windows[0].M, windows[0].N
+        self._frames0 = np.ascontiguousarray(np.concatenate([w.frames for w in windows], axis=0),
+                                             dtype=np.float64)
+        pk = _Packed(windows)
+        rc = self._lib.mvo_hip_upload(self._h, self._W, self._frames0.ctypes.data, self._M, self._N,
+                                      C.byref(opt), pk.arr)
+        if rc != OK:
+            raise MvoHipError(rc, "mvo_hip_upload")
+
+    def solve(self):
+        rc = self._lib.mvo_hip_solve(self._h)
+        if rc != OK:
+            raise MvoHipError(rc, "mvo_hip_solve")
+
+    def download(self):
+        frames = self._frames0.copy()
+        summ = (Summary * self._W)()
+        rc = self._lib.mvo_hip_download(self._h, frames.ctypes.data, summ)
+        if rc != OK:
+            raise MvoHipError(rc, "mvo_hip_download")
+        return frames.reshape(self._W, self._N, 13), list(summ)
+
+    # -- debug / parity -------------------------------------------------------------------
+    def evaluate(self, window, options=None):
+        """-> (residuals[n], jacobian[n,3M], cost) at the initial point (raw, no loss)."""
+        opt = options or make_options()
+        frames = np.ascontiguousarray(window.frames, dtype=np.float64)
+        pk = _Packed([window])
+        n = int(window.pair_offsets[-1])
+        res = np.zeros(n)
+        jac = np.zeros((n, 3 * window.M))
+        cost = C.c_double(0.0)
+        rc = self._lib.mvo_hip_eval(self._h, frames.ctypes.data, window.M, window.N, C.byref(opt), pk.arr,
+                                    res.ctypes.data, jac.ctypes.data, C.byref(cost))
+        if rc != OK:
+            raise MvoHipError(rc, "mvo_hip_eval")
+        return res, jac, cost.value
+
+    def pair_moments(self):
+        out = np.zeros((self._W * num_pairs(self._M, self._N), 6))
+        rc = self._lib.mvo_hip_pair_moments(self._h, out.ctypes.data)
+        if rc != OK:
+            raise MvoHipError(rc, "mvo_hip_pair_moments")
+        return out
+
+    def set_trace(self, capacity):
+        rc = self._lib.mvo_hip_set_trace(self._h, int(capacity))
+        if rc != OK:
+            raise MvoHipError(rc, "mvo_hip_set_trace")
+
+    def trace(self, capacity=256):
+        rows = (Iteration * capacity)()
+        n = C.c_int32(0)
+        rc = self._lib.mvo_hip_get_trace(self._h, rows, capacity, C.byref(n))
+        if rc != OK:
+            raise MvoHipError(rc, "mvo_hip_get_trace")
+        return [{f[0]: getattr(rows[i], f[0]) for f in Iteration._fields_} for i in range(min(n.value, capacity))]
+
+    def timing(self):
+        t = Timing()
+        rc = self._lib.mvo_hip_get_timing(self._h, C.byref(t))
+        if rc != OK:
+            raise MvoHipError(rc, "mvo_hip_get_timing")
+        return {f[0]: getattr(t, f[0]) for f in Timing._fields_}
+
+
+def num_pairs(M, N):
+    return int(load().mvo_hip_num_pairs(M, N))
+
+
+def reverse_scale(length, highest=2.0, lowest=0.25):
+    return load().mvo_hip_reverse_scale(length, highest, lowest)
+
+
+def scale(t, highest=2.0, lowest=0.25):
+    return load().mvo_hip_scale(t, highest, lowest)
