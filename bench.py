@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of libmvo_hip's sliding-window refinement on MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload config2|config3|config4|config5]
+
+A "step" is one complete refine() of the workload with the observations already resident in HBM
+(mvo_hip_upload done before the timed region; mvo_hip_solve + mvo_hip_download inside it):
+fold/moment pass or observation passes, the device-resident LM loop, results back on the host.
+
+Default workload = BASELINE.json configs[1]: one synthetic 30-keyframe window, 5 000 landmarks,
+~100k bearing observations, fp64, exactly 10 LM iterations (tolerances 0).  With N > 1 every rank
+owns one such window (independent windows, no data-path collective): weak scaling.
+
+One JSON line on stdout (rank 0).  `roofline` describes the dominant observation-pass kernel of
+the workload, timed with HIP events on the library's own stream inside the timed region;
+`roofline_large` is the same kernel measured at config-4 size (~9.7M residual blocks, larger than
+the 256 MiB Infinity Cache) because a 6 MB problem cannot exercise HBM; `cpu_baseline` is the CPU
+oracle (a scalar port of the reference algorithm; the reference itself needs Ceres and cannot be
+built here) timed on this node on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "monocular-visual-odometry_amd"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 achievable
+
+
+def build_workload(name, rank):
+    from mvo_amd import capi, scene
+
+    fixed10 = dict(max_num_iterations=10, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
+    if name == "config2":
+        ws = [scene.config2(seed=1002 + rank)]
+        opt = capi.make_options(**fixed10)
+        desc = "config2: 1 window/GPU, N=30 M=5, 5000 landmarks, fixed 10 LM iterations, no loss"
+    elif name == "config5":
+        ws = [scene.config2(seed=1005 + rank, outlier_fraction=0.2)]
+        opt = capi.make_options(use_loss_function=True, **fixed10)
+        desc = "config5: config2 data with 20% outliers, Cauchy(0.5) IRLS, fixed 10 LM iterations"
+    elif name == "config3":
+        n = int(os.environ.get("MVO_BENCH_WINDOWS", "4096"))
+        ws = [scene.config3_window(rank * n + i) for i in range(n)]
+        opt = capi.make_options(**fixed10)
+        desc = f"config3: {n} independent windows/GPU, N=10 M=5, 300 landmarks each, fixed 10 LM iterations"
+    elif name == "config4":
+        ws = [scene.config4(seed=1004 + rank)]
+        opt = capi.make_options(**fixed10)
+        desc = "config4 (one GPU's worth): N=200 M=5, 985 pairs, ~9.7M residual blocks, fixed 10 LM iterations"
+    elif name == "config4r":
+        ws = [scene.config4(seed=1004 + rank, outlier_fraction=0.2)]
+        opt = capi.make_options(use_loss_function=True, **fixed10)
+        desc = "config4 data with 20% outliers, Cauchy(0.5) IRLS, fixed 10 LM iterations"
+    else:
+        raise SystemExit(f"unknown workload {name}")
+    return ws, opt, desc
+
+
+def roofline_of(timing):
+    """achieved = algorithmic bytes per launch / average launch duration of the pass kernel."""
+    n = max(1, timing["assembly_launches"])
+    dur = timing["assembly_seconds"] / n
+    if dur <= 0 or timing["assembly_bytes"] == 0:
+        return None
+    gbs = timing["assembly_bytes"] / dur / 1e9
+    return {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+            "bytes_per_launch": int(timing["assembly_bytes"]), "avg_launch_us": round(dur * 1e6, 3),
+            "launches_per_step": int(timing["assembly_launches"])}
+
+
+def cpu_baseline(ws, opt_kw, use_loss):
+    """The CPU oracle on the same workload (bounded: one window, the same fixed 10 iterations)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import mvo_oracle_py as orc
+
+    w = ws[0]
+    opt = orc.make_options(use_loss_function=use_loss, **opt_kw)
+    sample = w
+    note = "the whole window"
+    if w.n_residual_blocks > 600_000:  # keep the CPU leg to ~10-30 s: every 16th block of each pair
+        import numpy as np
+        from mvo_amd import scene
+
+        offs, a0, a1 = [0], [], []
+        for p in range(w.n_pairs):
+            lo, hi = int(w.pair_offsets[p]), int(w.pair_offsets[p + 1])
+            a0.append(w.m0[lo:hi:16])
+            a1.append(w.m1[lo:hi:16])
+            offs.append(offs[-1] + len(a0[-1]))
+        sample = scene.Window(**{**w.__dict__, "m0": np.ascontiguousarray(np.concatenate(a0)),
+                                 "m1": np.ascontiguousarray(np.concatenate(a1)),
+                                 "pair_offsets": np.array(offs, dtype=np.uint64)})
+        note = "every 16th residual block of each pair"
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        f, s, _ = orc.refine(sample, opt)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > 10.0 or reps >= 50:
+            break
+    its = s.iterations * reps
+    return {"value": round(its / el, 3), "unit": "LM iterations/s", "cores": 1, "kind": "port",
+            "sample": f"{reps} solve(s) of {note} ({sample.n_residual_blocks} residual blocks, "
+                      f"{s.iterations} LM iterations each) in {el:.2f} s on one host core",
+            "residual_blocks_per_s": round(sample.n_residual_blocks * its / el, 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="config2")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-large", action="store_true", help="skip the config-4-size roofline leg")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: libmvo_hip has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from mvo_amd import capi
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ws, opt, desc = build_workload(args.workload, rank)
+    solver = capi.Solver(local_rank)
+    t0 = time.perf_counter()
+    solver.upload(ws, opt)
+    upload_s = time.perf_counter() - t0
+
+    for _ in range(args.warmup):
+        solver.solve()
+        solver.download()
+    barrier()
+    t0 = time.perf_counter()
+    asm_s, asm_n, dev_s, first_s = 0.0, 0, 0.0, 0.0
+    for _ in range(args.steps):
+        solver.solve()
+        frames, summ = solver.download()
+        tm = solver.timing()
+        asm_s += tm["assembly_seconds"]
+        asm_n += tm["assembly_launches"]
+        dev_s += tm["device_seconds"]
+        first_s += tm["assembly_first_seconds"]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    n_windows = len(ws)
+    its_per_step = sum(s.iterations for s in summ)
+    blocks = sum(w.n_residual_blocks for w in ws)
+    bearings = sum(w.bearing_observations for w in ws)
+    total_its = its_per_step * args.steps * world
+    tm["assembly_seconds"], tm["assembly_launches"] = asm_s, asm_n
+    roof = roofline_of(tm)
+
+    out = {
+        "metric": "lm_iterations_per_sec",
+        "value": round(total_its / elapsed, 3),
+        "unit": "LM iterations/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": desc, "windows_per_gpu": n_windows, "residual_blocks_per_gpu": blocks,
+                   "bearing_observations_per_gpu": bearings, "pairs_per_window": ws[0].n_pairs,
+                   "lm_iterations_per_window": its_per_step // n_windows,
+                   "parallelism": f"{world} x independent windows, no collective"},
+        # every LM iteration evaluates all residual blocks and their Jacobian rows (through the
+        # per-pair moments in the no-loss case, through one observation pass otherwise)
+        "residual_jacobian_obs_per_sec": round(blocks * (its_per_step / n_windows) * args.steps * world / elapsed, 1),
+        "windows_per_sec": round(n_windows * args.steps * world / elapsed, 3),
+        "device_ms_per_step": round(dev_s / args.steps * 1e3, 5),
+        "fold_kernel_us": round(first_s / args.steps * 1e6, 3),
+        "upload_seconds_pcie_inclusive": round(upload_s, 6),
+        "roofline": roof,
+    }
+
+    if rank == 0 and world == 1 and not args.no_large and args.workload in ("config2", "config5"):
+        # the same pass kernels at a size HBM actually sees (config 4, one GPU)
+        robust = args.workload == "config5"
+        big_ws, big_opt, big_desc = build_workload("config4r" if robust else "config4", 0)
+        solver.upload(big_ws, big_opt)
+        asm_s, asm_n, k = 0.0, 0, 0
+        t1 = time.perf_counter()
+        for i in range(6):
+            solver.solve()
+            _, bs = solver.download()
+            if i == 0:
+                continue
+            tb = solver.timing()
+            asm_s += tb["assembly_seconds"]
+            asm_n += tb["assembly_launches"]
+            k += 1
+        big_elapsed = (time.perf_counter() - t1) * k / 6
+        tb["assembly_seconds"], tb["assembly_launches"] = asm_s, asm_n
+        rl = roofline_of(tb)
+        rl["workload"] = big_desc
+        rl["residual_blocks"] = big_ws[0].n_residual_blocks
+        rl["ms_per_solve"] = round(big_elapsed / k * 1e3, 4)
+        rl["kernel"] = "k_pass<robust>" if robust else "k_fold<moments>"
+        out["roofline_large"] = rl
+        del big_ws
+
+    if rank == 0 and world == 1 and not args.no_cpu:
+        kw = dict(max_num_iterations=10, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
+        out["cpu_baseline"] = cpu_baseline(ws, kw, bool(opt.use_loss_function))
+    else:
+        out["cpu_baseline"] = None
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    solver.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

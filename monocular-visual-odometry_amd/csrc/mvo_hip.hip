@@ -172,7 +172,13 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
   h->n_obs = n_obs;
   // tile size: enough wave-tiles to fill 256 CUs x 32 waves a few times over
   uint32_t tile = 1024;
-  while (tile > 128 && n_obs / tile < 16384) tile >>= 1;
+  for (; tile > 128; tile >>= 1) {
+    uint64_t n_tiles = 0;
+    for (uint32_t w = 0; w < W; ++w)
+      for (uint32_t p = 0; p < P; ++p)
+        n_tiles += (obs[w].pair_offsets[p + 1] - obs[w].pair_offsets[p] + tile - 1) / tile;
+    if (n_tiles >= 16384) break;
+  }
   h->tile_size = tile;
 
   std::vector<WinDev> wins(W);

@@ -1,0 +1,32 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "monocular-visual-odometry_amd"), os.path.join(ROOT, "oracle"), os.path.dirname(__file__)):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import mvo_oracle_py as orc
+
+    orc.lib()  # builds oracle/libmvo_oracle.so on first use if it is missing
+    return orc
+
+
+@pytest.fixture(scope="session")
+def solver():
+    """One mvo_hip handle for the whole GPU session; fails loudly when the library or the GPU
+    is missing (there is no CPU fallback to hide behind)."""
+    from mvo_amd import capi
+
+    s = capi.Solver(0)
+    yield s
+    s.close()

@@ -1,0 +1,123 @@
+"""GPU tests at BASELINE.json's full sizes.  Config 2 is small enough for the oracle; configs 3-5
+are checked through size-independent properties (linearity of the moments, permutation
+invariance inside a pair, idempotence, agreement of the two assembly modes, batch == parts)."""
+import numpy as np
+import pytest
+
+from _util import FIXED10, refined, rel_inf
+from mvo_amd import capi, scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _subset(w, pick):
+    """Window with, per pair, the residual blocks selected by pick(lo, hi) -> index array."""
+    offs, a0, a1 = [0], [], []
+    for p in range(w.n_pairs):
+        lo, hi = int(w.pair_offsets[p]), int(w.pair_offsets[p + 1])
+        idx = pick(lo, hi)
+        a0.append(w.m0[idx])
+        a1.append(w.m1[idx])
+        offs.append(offs[-1] + len(idx))
+    return scene.Window(**{**w.__dict__, "m0": np.ascontiguousarray(np.concatenate(a0)),
+                           "m1": np.ascontiguousarray(np.concatenate(a1)),
+                           "pair_offsets": np.array(offs, dtype=np.uint64)})
+
+
+def test_config2_full_size_against_oracle(solver, oracle):
+    w = scene.config2()
+    assert w.N == 30 and w.M == 5 and w.n_pairs == 135 and w.bearing_observations == 100000
+    r, J, c = solver.evaluate(w)
+    ro, Jo, co = oracle.evaluate(w)
+    assert rel_inf(r, ro) < 1e-9 and rel_inf(J, Jo) < 1e-9
+    for mode in (capi.ASSEMBLY_AUTO, capi.ASSEMBLY_PASSES):
+        fg, sg = solver.refine(w, capi.make_options(assembly_mode=mode, **FIXED10))
+        fo, so, _ = oracle.refine(w, oracle.make_options(**FIXED10))
+        assert sg.iterations == 10
+        assert np.abs(refined(fg, 5) - refined(fo, 5)).max() < 1e-6
+        assert abs(sg.final_cost - so.final_cost) <= 1e-9 * so.initial_cost
+
+
+def test_config5_outliers_cauchy_against_oracle(solver, oracle):
+    w = scene.config2(outlier_fraction=0.2)
+    kw = dict(use_loss_function=True, **FIXED10)
+    fg, sg = solver.refine(w, capi.make_options(**kw))
+    fo, so, _ = oracle.refine(w, oracle.make_options(**kw))
+    assert np.abs(refined(fg, 5) - refined(fo, 5)).max() < 1e-6
+    assert abs(sg.final_cost - so.final_cost) <= 1e-9 * so.initial_cost
+
+
+@pytest.fixture(scope="module")
+def big():
+    w = scene.config4()
+    assert w.n_pairs == 985 and w.n_residual_blocks > 9_000_000
+    assert all(int(w.pair_offsets[p + 1]) > int(w.pair_offsets[p]) for p in range(w.n_pairs))
+    return w
+
+
+def test_config4_moments_linearity_and_permutation(solver, big):
+    solver.upload([big])
+    S = solver.pair_moments()
+    even = _subset(big, lambda lo, hi: np.arange(lo, hi, 2))
+    odd = _subset(big, lambda lo, hi: np.arange(lo + 1, hi, 2))
+    solver.upload([even])
+    Se = solver.pair_moments()
+    solver.upload([odd])
+    So = solver.pair_moments()
+    assert rel_inf(Se + So, S) < 1e-12                       # S is additive over observations
+    rng = np.random.default_rng(0)
+    perm = _subset(big, lambda lo, hi: lo + rng.permutation(hi - lo))
+    solver.upload([perm])
+    assert rel_inf(solver.pair_moments(), S) < 1e-12         # order inside a pair is irrelevant
+    # trace(S_p) = sum |c|^2 <= number of blocks, since |c| = |sin(angle)| <= 1 for unit rays
+    cnt = np.diff(big.pair_offsets.astype(np.int64))
+    tr = S[:, 0] + S[:, 3] + S[:, 5]
+    assert np.all(tr > 0) and np.all(tr <= cnt * (1 + 1e-12))
+
+
+def test_config4_modes_agree_and_solve_is_idempotent(solver, big):
+    res = {}
+    for mode in (capi.ASSEMBLY_AUTO, capi.ASSEMBLY_PASSES):
+        solver.upload([big], capi.make_options(assembly_mode=mode, **FIXED10))
+        solver.solve()
+        f1, s1 = solver.download()
+        solver.solve()
+        f2, s2 = solver.download()
+        assert np.array_equal(f1, f2)                        # fixed summation order, no atomics
+        assert s1[0].iterations == 10
+        res[mode] = (f1[0], s1[0])
+        t = solver.timing()
+        assert t["residual_blocks"] == big.n_residual_blocks
+    fa, sa = res[capi.ASSEMBLY_AUTO]
+    fp, sp = res[capi.ASSEMBLY_PASSES]
+    assert np.abs(refined(fa, 5) - refined(fp, 5)).max() < 1e-6
+    assert abs(sa.final_cost - sp.final_cost) <= 1e-8 * sa.initial_cost
+    assert abs(sa.initial_cost - sp.initial_cost) <= 1e-10 * sa.initial_cost
+    assert sa.final_cost < sa.initial_cost
+
+
+def test_config4_robust_cost_is_consistent(solver, big):
+    """Cauchy: rho(s) <= s, so the robust initial cost is below the plain one, and with
+    max_num_iterations = 0 nothing moves."""
+    solver.upload([big], capi.make_options(max_num_iterations=0))
+    solver.solve()
+    _, s_plain = solver.download()
+    solver.upload([big], capi.make_options(max_num_iterations=0, use_loss_function=True))
+    solver.solve()
+    f, s_rob = solver.download()
+    assert 0 < s_rob[0].initial_cost < s_plain[0].initial_cost
+    assert np.array_equal(refined(f[0], 5)[:, :3], refined(big.frames, 5)[:, :3])
+
+
+def test_config3_batch_equals_its_parts(solver, oracle):
+    """4096-window recipe at 512 windows: every window's result is what the same window gives in
+    a smaller batch (tiles never mix windows; only the tile size, hence the summation order, may
+    differ), and samples match the oracle."""
+    ws = [scene.config3_window(i) for i in range(512)]
+    fb, sb = solver.refine_batch(ws, capi.make_options(**FIXED10))
+    fa, sa = solver.refine_batch(ws[:256], capi.make_options(**FIXED10))
+    fc, sc = solver.refine_batch(ws[256:], capi.make_options(**FIXED10))
+    assert np.abs(fb[:256] - fa).max() < 1e-9 and np.abs(fb[256:] - fc).max() < 1e-9
+    for i in (3, 300, 511):
+        fo, so, _ = oracle.refine(ws[i], oracle.make_options(**FIXED10))
+        assert np.abs(refined(fb[i], 5) - refined(fo, 5)).max() < 1e-6

@@ -1,0 +1,253 @@
+"""GPU parity tests: libmvo_hip (through its C ABI) against the CPU oracle and the committed
+golden vectors.  Tolerances (BASELINE.json north_star): residuals and Jacobians within 1e-9
+relative to the vector's infinity norm; refined baselines within 1e-6 after a fixed iteration
+count; per-pair moments within 1e-12.  Nothing here reads /root/reference.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from _util import FIXED10, GOLDEN_CASES, TIGHT, load_golden, refined, rel_inf
+from mvo_amd import capi, scene
+
+pytestmark = pytest.mark.gpu
+
+TOL_RJ = 1e-9       # residual / Jacobian, relative to ||.||_inf
+TOL_MOMENT = 1e-12  # per-pair S_p
+TOL_FINAL = 1e-6    # refined vec / scale after a fixed iteration count
+
+
+def shapes():
+    return {
+        "defaults_n3m2": lambda: scene.reference_defaults_window(),          # mvo.cfg:42-43
+        "minimal_n2m1": lambda: scene.make_window(2, 1, 50, seed=21),
+        "n6m3": lambda: scene.make_window(6, 3, 120, seed=11),
+        "n6m5": lambda: scene.make_window(6, 5, 70, seed=12),                # N = M + 1
+        "config1": lambda: scene.config1(),
+        "ragged": lambda: scene.make_window(12, 4, 200, seed=13, span=("anchored", 2, 12)),
+        "n40m5_sliding": lambda: scene.make_window(40, 5, 600, seed=14, span=("sliding", 15)),
+    }
+
+
+# ------------------------------------------------------------------ residual / Jacobian / moments
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_eval_matches_golden_vectors(solver, case):
+    w, z = load_golden(case)
+    r, J, cost = solver.evaluate(w)
+    assert rel_inf(r, z["r0"]) < TOL_RJ
+    assert rel_inf(J, z["J0"]) < TOL_RJ
+    assert abs(cost - float(z["cost0"])) < 1e-12 * float(z["cost0"])
+    solver.upload([w])
+    assert rel_inf(solver.pair_moments(), z["S"]) < TOL_MOMENT
+
+
+@pytest.mark.parametrize("name", list(shapes()))
+def test_eval_and_moments_match_oracle(solver, oracle, name):
+    w = shapes()[name]()
+    r, J, cost = solver.evaluate(w)
+    ro, Jo, co = oracle.evaluate(w)
+    assert rel_inf(r, ro) < TOL_RJ
+    assert rel_inf(J, Jo) < TOL_RJ
+    assert abs(cost - co) <= 1e-12 * co
+    solver.upload([w])
+    S, So = solver.pair_moments(), oracle.pair_moments(w)
+    assert rel_inf(S, So) < TOL_MOMENT
+
+
+# ------------------------------------------------------------------ refine(): fixed iteration count
+@pytest.mark.parametrize("mode", [capi.ASSEMBLY_AUTO, capi.ASSEMBLY_PASSES])
+@pytest.mark.parametrize("name", list(shapes()))
+def test_refine_fixed_iterations_matches_oracle(solver, oracle, name, mode):
+    w = shapes()[name]()
+    fg, sg = solver.refine(w, capi.make_options(assembly_mode=mode, **FIXED10))
+    fo, so, _ = oracle.refine(w, oracle.make_options(**FIXED10))
+    assert np.abs(refined(fg, w.M) - refined(fo, w.M)).max() < TOL_FINAL
+    assert abs(sg.initial_cost - so.initial_cost) <= 1e-9 * so.initial_cost
+    assert abs(sg.final_cost - so.final_cost) <= 1e-8 * so.initial_cost
+    # frames that are not refined are never written (IterativeRefinement.cpp:240-246)
+    assert np.array_equal(fg[w.M:], w.frames[w.M:])
+    assert np.array_equal(fg[:, :9], w.frames[:, :9])
+
+
+@pytest.mark.parametrize("name", ["n6m3", "config1", "ragged"])
+def test_iteration_trace_matches_oracle(solver, oracle, name):
+    """Same accept/reject sequence, same costs and radii, iteration by iteration."""
+    w = shapes()[name]()
+    for mode in (capi.ASSEMBLY_AUTO, capi.ASSEMBLY_PASSES):
+        solver.set_trace(64)
+        fg, sg = solver.refine(w, capi.make_options(assembly_mode=mode, **FIXED10))
+        tg = solver.trace(64)
+        solver.set_trace(0)
+        fo, so, to = oracle.refine(w, oracle.make_options(**FIXED10))
+        assert len(tg) == len(to) == 11 and sg.iterations == so.iterations == 10
+        for a, b in zip(tg, to):
+            assert a["step_is_successful"] == b["step_is_successful"]
+            assert abs(a["cost"] - b["cost"]) <= 1e-8 * to[0]["cost"]
+            assert abs(a["trust_region_radius"] - b["trust_region_radius"]) <= 1e-6 * b["trust_region_radius"]
+        assert (sg.termination, sg.reason) == (so.termination, so.reason)
+        assert sg.num_successful_steps == so.num_successful_steps
+
+
+@pytest.mark.parametrize("use_loss,fix", [(True, False), (False, True), (True, True)])
+def test_refine_loss_and_fixed_length(solver, oracle, use_loss, fix):
+    for w in (scene.config1(), scene.make_window(7, 5, 300, seed=5, outlier_fraction=0.2)):
+        kw = dict(use_loss_function=use_loss, fix_length=fix, **FIXED10)
+        fg, sg = solver.refine(w, capi.make_options(**kw))
+        fo, so, _ = oracle.refine(w, oracle.make_options(**kw))
+        assert np.abs(refined(fg, w.M) - refined(fo, w.M)).max() < TOL_FINAL
+        assert abs(sg.final_cost - so.final_cost) <= 1e-8 * so.initial_cost
+        if fix:  # SetParameterBlockConstant(scale): lengths come back unchanged
+            assert np.abs(refined(fg, w.M)[:, 3] - refined(w.frames, w.M)[:, 3]).max() < 1e-15
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_converged_minimiser_matches_scipy_golden(solver, case):
+    w, z = load_golden(case)
+    for mode in (capi.ASSEMBLY_AUTO, capi.ASSEMBLY_PASSES):
+        opt = capi.make_options(use_loss_function=bool(z["use_loss"]), fix_length=bool(z["fix_length"]),
+                                assembly_mode=mode, **TIGHT)
+        f, s = solver.refine(w, opt)
+        assert abs(s.final_cost - float(z["cost_star"])) <= 1e-8 * float(z["cost_star"])
+        assert np.abs(refined(f, w.M)[:, :3] - z["vec_star"]).max() < TOL_FINAL
+        assert np.abs(refined(f, w.M)[:, 3] - z["scale_star"]).max() < 2e-5  # weakly observable lengths
+
+
+def test_default_options_terminate_like_the_oracle(solver, oracle):
+    """The reference's shipped tolerances (mvo.cfg:39-53): convergence test, not iteration cap."""
+    for w in (scene.config1(), scene.make_window(7, 5, 200, seed=5), scene.reference_defaults_window(3)):
+        fg, sg = solver.refine(w, capi.make_options())
+        fo, so, _ = oracle.refine(w, oracle.make_options())
+        assert sg.termination == so.termination == capi.OK  # CONVERGENCE
+        assert abs(sg.iterations - so.iterations) <= 1
+        assert abs(sg.final_cost - so.final_cost) <= 1e-6 * so.final_cost
+        assert np.abs(refined(fg, w.M)[:, :3] - refined(fo, w.M)[:, :3]).max() < 1e-4
+
+
+# ------------------------------------------------------------------ batches
+def test_batch_matches_single_and_oracle(solver, oracle):
+    ws = [scene.config3_window(i) for i in range(48)]
+    fb, sb = solver.refine_batch(ws, capi.make_options(**FIXED10))
+    for i in (0, 1, 17, 47):
+        fo, so, _ = oracle.refine(ws[i], oracle.make_options(**FIXED10))
+        assert np.abs(refined(fb[i], 5) - refined(fo, 5)).max() < TOL_FINAL
+        f1, s1 = solver.refine(ws[i], capi.make_options(**FIXED10))
+        assert np.abs(refined(fb[i], 5) - refined(f1, 5)).max() < 1e-9
+        assert sb[i].iterations == so.iterations == 10
+
+
+def test_batch_robust_with_early_finishers(solver, oracle):
+    """Windows that converge early must not disturb the others (device-side status flags)."""
+    ws = [scene.make_window(6, 3, 40 + 10 * i, seed=300 + i) for i in range(12)]
+    kw = dict(use_loss_function=True, max_num_iterations=30)
+    fb, sb = solver.refine_batch(ws, capi.make_options(**kw))
+    its = set()
+    for i, w in enumerate(ws):
+        fo, so, _ = oracle.refine(w, oracle.make_options(**kw))
+        assert sb[i].termination == so.termination
+        assert abs(sb[i].iterations - so.iterations) <= 1
+        assert np.abs(refined(fb[i], 3)[:, :3] - refined(fo, 3)[:, :3]).max() < 1e-4
+        its.add(sb[i].iterations)
+    assert len(its) > 1  # they really did stop at different iterations
+
+
+# ------------------------------------------------------------------ edge cases
+def test_empty_and_partially_empty_windows(solver, oracle):
+    w = scene.make_window(5, 2, 30, seed=4)
+    e = scene.Window(**{**w.__dict__, "m0": w.m0[:0], "m1": w.m1[:0],
+                        "pair_offsets": np.zeros_like(w.pair_offsets)})
+    f, s = solver.refine(e, capi.make_options())
+    assert s.initial_cost == 0.0 and s.termination == capi.OK
+    assert np.array_equal(refined(f, 2)[:, :3], refined(w.frames, 2)[:, :3])
+    r, J, c = solver.evaluate(e)
+    assert r.size == 0 and c == 0.0
+    # drop the observations of every second pair
+    offs = [0]
+    keep0, keep1 = [], []
+    for p in range(w.n_pairs):
+        lo, hi = int(w.pair_offsets[p]), int(w.pair_offsets[p + 1])
+        if p % 2 == 0:
+            keep0.append(w.m0[lo:hi])
+            keep1.append(w.m1[lo:hi])
+            offs.append(offs[-1] + hi - lo)
+        else:
+            offs.append(offs[-1])
+    h = scene.Window(**{**w.__dict__, "m0": np.concatenate(keep0), "m1": np.concatenate(keep1),
+                        "pair_offsets": np.array(offs, dtype=np.uint64)})
+    fg, sg = solver.refine(h, capi.make_options(**FIXED10))
+    fo, so, _ = oracle.refine(h, oracle.make_options(**FIXED10))
+    assert np.abs(refined(fg, 2) - refined(fo, 2)).max() < TOL_FINAL
+
+
+def test_single_observation_and_odd_sizes(solver, oracle):
+    for L in (1, 2, 63, 64, 65, 127, 129):
+        w = scene.make_window(4, 2, L, seed=50 + L)
+        r, J, _ = solver.evaluate(w)
+        ro, Jo, _ = oracle.evaluate(w)
+        assert rel_inf(r, ro) < TOL_RJ and rel_inf(J, Jo) < TOL_RJ
+        for mode in (capi.ASSEMBLY_AUTO, capi.ASSEMBLY_PASSES):
+            kw = dict(max_num_iterations=3, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
+            fg, sg = solver.refine(w, capi.make_options(assembly_mode=mode, **kw))
+            fo, so, _ = oracle.refine(w, oracle.make_options(**kw))
+            assert abs(sg.initial_cost - so.initial_cost) <= 1e-9 * max(so.initial_cost, 1e-300)
+            if L >= 63:  # with 1-2 features the problem is rank deficient: only costs are comparable
+                assert np.abs(refined(fg, 2) - refined(fo, 2)).max() < TOL_FINAL
+
+
+def test_zero_iterations_and_out_of_range_lengths(solver, oracle):
+    w = scene.make_window(5, 2, 30, seed=4)
+    f, s = solver.refine(w, capi.make_options(max_num_iterations=0))
+    assert s.iterations == 0 and s.termination == 1 and s.reason == 1
+    assert np.array_equal(refined(f, 2)[:, :3], refined(w.frames, 2)[:, :3])
+    # lengths outside (lowestLength, highestLength) are clamped by reverseScale (IR.cpp:350-363)
+    w.frames[0, 12] = 5.0
+    w.frames[1, 12] = 0.01
+    fg, sg = solver.refine(w, capi.make_options(**FIXED10))
+    fo, so, _ = oracle.refine(w, oracle.make_options(**FIXED10))
+    assert np.abs(refined(fg, 2) - refined(fo, 2)).max() < TOL_FINAL
+    assert np.all(refined(fg, 2)[:, 3] >= 0.25) and np.all(refined(fg, 2)[:, 3] <= 2.0)
+
+
+def test_error_behaviour(solver):
+    w = scene.make_window(8, 2, 10, seed=1)
+    lib = capi.load()
+    frames = np.ascontiguousarray(w.frames)
+    pk = capi._Packed([w])
+    opt = capi.make_options()
+    summ = capi.Summary()
+
+    def call(M, N, obs=pk.arr, o=opt):
+        return lib.mvo_hip_refine(solver._h, frames.ctypes.data, M, N, C.byref(o), obs, C.byref(summ))
+
+    assert call(0, 8) == capi.ERR_INVALID_ARGUMENT           # assert(numberToRefine > 0)
+    assert call(8, 8) == capi.ERR_INVALID_ARGUMENT           # assert(numberToNote > numberToRefine)
+    assert call(6, 8) == capi.ERR_UNSUPPORTED                # default: assert(false)
+    assert call(3, 8) == capi.ERR_INVALID_ARGUMENT           # n_pairs does not match (M, N)
+    bad = capi._Packed([w])
+    offs = bad.keep[0]
+    offs[3] = offs[4] + 1                                    # non-monotone CSR
+    assert call(2, 8, bad.arr) == capi.ERR_INVALID_ARGUMENT
+    o2 = capi.make_options(lowest_length=2.0, highest_length=0.25)
+    assert call(2, 8, pk.arr, o2) == capi.ERR_INVALID_ARGUMENT
+    assert lib.mvo_hip_refine(None, frames.ctypes.data, 2, 8, C.byref(opt), pk.arr, C.byref(summ)) == capi.ERR_INVALID_ARGUMENT
+    # and the handle is still usable afterwards
+    f, s = solver.refine(w, opt)
+    assert s.termination in (0, 1)
+
+
+def test_download_before_upload_is_an_error():
+    with capi.Solver(0) as s2:
+        assert capi.load().mvo_hip_solve(s2._h) == capi.ERR_STATE
+
+
+def test_split_phase_is_repeatable(solver):
+    """solve() restarts from the uploaded initial values: two solves are bitwise identical."""
+    w = scene.config1()
+    solver.upload([w], capi.make_options(use_loss_function=True, **FIXED10))
+    solver.solve()
+    f1, s1 = solver.download()
+    solver.solve()
+    f2, s2 = solver.download()
+    assert np.array_equal(f1, f2) and s1[0].final_cost == s2[0].final_cost
+    t = solver.timing()
+    assert t["assembly_launches"] == 11 and t["residual_blocks"] == w.n_residual_blocks
