@@ -72,7 +72,7 @@ def roofline_of(timing):
     return {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
             "bytes_per_launch": int(timing["assembly_bytes"]), "avg_launch_us": round(dur * 1e6, 3),
-            "launches_per_step": int(timing["assembly_launches"])}
+            "launches_timed": int(timing["assembly_launches"])}
 
 
 def cpu_baseline(ws, opt_kw, use_loss):

@@ -213,7 +213,7 @@ struct LmShared {
   LmState st;
   double zvec[MVO_MAXM][3], zt[MVO_MAXM], zs[MVO_MAXM], zsp[MVO_MAXM];
   double G[MVO_MAXM][9];  // G[k][3*row + col]: columns (s_k jl0, s_k jl1, s'_k v_k)
-  double cls[MVO_MAXM * MVO_MAXM][10];
+  double cls[MVO_MAXM * (MVO_MAXM + 1)][10];  // class (a, j = min(b, M))
   double Hz[MVO_MAXC * MVO_MAXC], gz[MVO_MAXC];  // full 3M system at z
   double A[MVO_MAXC * MVO_MAXC], rhs[MVO_MAXC], step[MVO_MAXC];
   double cost_z;
@@ -598,51 +598,83 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, const WinDev* __rest
       o[9] = prm.pass_mode ? 0.5 * S[6] : 0.5 * uSu;
     }
     __syncthreads();
-    // class (a, kmax) sums in pair order: kmax < M-1 -> the single pair b = kmax;
-    // kmax = M-1 -> pairs b = M-1 .. N-2
-    for (int item = tid; item < M * M * 10; item += NT) {
-      const int a = item / (M * 10), kmax = (item / 10) % M, v = item % 10;
+    // Class sums in pair order.  Class (a, j), j = min(b, M): j < M is the single pair b = j,
+    // j = M collects the pairs b = M .. N-2 (those with a fixed-frame offset).  The free frames
+    // of a class are a .. min(j, M-1).
+    const int MC = M + 1;
+    for (int item = tid; item < M * MC * 10; item += NT) {
+      const int a = item / (MC * 10), j = (item / 10) % MC, v = item % 10;
       double acc = 0.0;
-      if (kmax >= a) {
-        const int b0 = kmax, b1 = (kmax == M - 1) ? N - 2 : kmax;
-        const int p0 = pair_index(N, a, b0);
-        for (int b = b0; b <= b1; ++b) acc += pairbuf[(size_t)(p0 + (b - b0)) * 10 + v];
+      if (j >= a) {
+        const int b0 = j, b1 = (j == M) ? N - 2 : j;
+        if (b0 <= N - 2) {
+          const int p0 = pair_index(N, a, b0);
+          for (int b = b0; b <= b1; ++b) acc += pairbuf[(size_t)(p0 + (b - b0)) * 10 + v];
+        }
       }
-      sh.cls[a * M + kmax][v] = acc;
+      sh.cls[a * MC + j][v] = acc;
     }
     __syncthreads();
     for (int item = tid; item < M * M + M + 1; item += NT) {
       if (item < M * M) {
         const int k = item / M, l = item % M;
         if (l >= k) {
+          // W = sum of T over the pairs whose free frames contain k and l: a <= k, min(j,M-1) >= l.
+          // The pair (k,k) is kept apart: its baseline is s_k v_k alone, so r does not depend on
+          // t_k at all (IR.cpp:466-471 normalises the scale away) and its scale row/column is
+          // exactly zero instead of rounding noise of the size of S.
           double W[6] = {0, 0, 0, 0, 0, 0};
           for (int a = 0; a <= k; ++a)
-            for (int kmax = l; kmax < M; ++kmax)
-              for (int v = 0; v < 6; ++v) W[v] += sh.cls[a * M + kmax][v];
-          const double Wm[9] = {W[0], W[1], W[2], W[1], W[3], W[4], W[2], W[4], W[5]};
-          // block = G_k^T W G_l
-          double WG[9];
-          for (int r = 0; r < 3; ++r)
-            for (int c = 0; c < 3; ++c)
-              WG[3 * r + c] = Wm[3 * r] * sh.G[l][c] + Wm[3 * r + 1] * sh.G[l][3 + c] + Wm[3 * r + 2] * sh.G[l][6 + c];
+            for (int j = l; j <= M; ++j) {
+              if (k == l && a == k && j == k) continue;
+              for (int v = 0; v < 6; ++v) W[v] += sh.cls[a * MC + j][v];
+            }
+          double blk[9];
+          {
+            const double Wm[9] = {W[0], W[1], W[2], W[1], W[3], W[4], W[2], W[4], W[5]};
+            double WG[9];
+            for (int r = 0; r < 3; ++r)
+              for (int c = 0; c < 3; ++c)
+                WG[3 * r + c] = Wm[3 * r] * sh.G[l][c] + Wm[3 * r + 1] * sh.G[l][3 + c] + Wm[3 * r + 2] * sh.G[l][6 + c];
+            for (int i = 0; i < 3; ++i)
+              for (int jj = 0; jj < 3; ++jj)
+                blk[3 * i + jj] = sh.G[k][i] * WG[jj] + sh.G[k][3 + i] * WG[3 + jj] + sh.G[k][6 + i] * WG[6 + jj];
+          }
+          if (k == l) {
+            const double* Ts = sh.cls[k * MC + k];
+            const double Wm[9] = {Ts[0], Ts[1], Ts[2], Ts[1], Ts[3], Ts[4], Ts[2], Ts[4], Ts[5]};
+            double WG[9];
+            for (int r = 0; r < 3; ++r)
+              for (int c = 0; c < 3; ++c)
+                WG[3 * r + c] = Wm[3 * r] * sh.G[k][c] + Wm[3 * r + 1] * sh.G[k][3 + c] + Wm[3 * r + 2] * sh.G[k][6 + c];
+            for (int i = 0; i < 2; ++i)
+              for (int jj = 0; jj < 2; ++jj)
+                blk[3 * i + jj] += sh.G[k][i] * WG[jj] + sh.G[k][3 + i] * WG[3 + jj] + sh.G[k][6 + i] * WG[6 + jj];
+          }
           for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j) {
-              const double val = sh.G[k][i] * WG[j] + sh.G[k][3 + i] * WG[3 + j] + sh.G[k][6 + i] * WG[6 + j];
-              sh.Hz[(3 * k + i) * MVO_MAXC + 3 * l + j] = val;
-              sh.Hz[(3 * l + j) * MVO_MAXC + 3 * k + i] = val;
+            for (int jj = 0; jj < 3; ++jj) {
+              sh.Hz[(3 * k + i) * MVO_MAXC + 3 * l + jj] = blk[3 * i + jj];
+              sh.Hz[(3 * l + jj) * MVO_MAXC + 3 * k + i] = blk[3 * i + jj];
             }
         }
       } else if (item < M * M + M) {
         const int k = item - M * M;
         double y[3] = {0, 0, 0};
         for (int a = 0; a <= k; ++a)
-          for (int kmax = k; kmax < M; ++kmax)
-            for (int v = 0; v < 3; ++v) y[v] += sh.cls[a * M + kmax][6 + v];
-        for (int i = 0; i < 3; ++i) sh.gz[3 * k + i] = sh.G[k][i] * y[0] + sh.G[k][3 + i] * y[1] + sh.G[k][6 + i] * y[2];
+          for (int j = k; j <= M; ++j) {
+            if (a == k && j == k) continue;
+            for (int v = 0; v < 3; ++v) y[v] += sh.cls[a * MC + j][6 + v];
+          }
+        const double* qs = &sh.cls[k * MC + k][6];
+        for (int i = 0; i < 3; ++i) {
+          double gi = sh.G[k][i] * y[0] + sh.G[k][3 + i] * y[1] + sh.G[k][6 + i] * y[2];
+          if (i < 2) gi += sh.G[k][i] * qs[0] + sh.G[k][3 + i] * qs[1] + sh.G[k][6 + i] * qs[2];
+          sh.gz[3 * k + i] = gi;
+        }
       } else {
         double c = 0.0;
         for (int a = 0; a < M; ++a)
-          for (int kmax = a; kmax < M; ++kmax) c += sh.cls[a * M + kmax][9];
+          for (int j = a; j <= M; ++j) c += sh.cls[a * MC + j][9];
         sh.cost_z = c;
       }
     }

@@ -208,9 +208,9 @@ def config3_window(window_id: int, seed: int = 1003) -> Window:
 
 def config4(seed: int = 1004, n_active: int = 20000, outlier_fraction: float = 0.0) -> Window:
     """N=200, M=5, 985 pairs; `n_active` landmarks anchored at the newest frame with span
-    U[2,199] (the other ~180k landmarks of the 200k scene never reach the newest M frames and
+    U[2,200] (the other ~180k landmarks of the 200k scene never reach the newest M frames and
     therefore generate no residual blocks in the reference's formulation)."""
-    return make_window(200, 5, n_active, seed, span=("anchored", 2, 199),
+    return make_window(200, 5, n_active, seed, span=("anchored", 2, 200),
                        outlier_fraction=outlier_fraction)
 
 

@@ -223,7 +223,8 @@ def test_error_behaviour(solver):
     assert call(8, 8) == capi.ERR_INVALID_ARGUMENT           # assert(numberToNote > numberToRefine)
     assert call(6, 8) == capi.ERR_UNSUPPORTED                # default: assert(false)
     assert call(3, 8) == capi.ERR_INVALID_ARGUMENT           # n_pairs does not match (M, N)
-    bad = capi._Packed([w])
+    wb = scene.Window(**{**w.__dict__, "pair_offsets": w.pair_offsets.copy()})
+    bad = capi._Packed([wb])
     offs = bad.keep[0]
     offs[3] = offs[4] + 1                                    # non-monotone CSR
     assert call(2, 8, bad.arr) == capi.ERR_INVALID_ARGUMENT
