@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "mvo_kernels.h"
+#include "mvo_lm.h"
 
 static_assert(sizeof(mvo_hip_frame) == MVO_FRAME_DOUBLES * sizeof(double), "frame record layout");
 static_assert(sizeof(TraceRec) == sizeof(mvo_hip_iteration), "trace record layout");

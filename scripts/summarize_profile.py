@@ -1,0 +1,51 @@
+"""Condenses a scripts/profile.sh output directory into one markdown summary."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+out = sys.argv[1]
+print(f"# rocprofv3 summary ({os.path.basename(out)})\n")
+for d in sorted(glob.glob(os.path.join(out, "kt_*"))):
+    if not os.path.isdir(d):
+        continue
+    name = os.path.basename(d)[3:]
+    print(f"## kernel-trace --stats: bench.py --workload {name}\n")
+    bj = os.path.join(out, f"bench_{name}.json")
+    if os.path.exists(bj) and os.path.getsize(bj):
+        b = json.loads(open(bj).read().strip().splitlines()[-1])
+        print(f"bench line: value={b['value']} {b['unit']}, ms_per_step={b['ms_per_step']}, roofline={json.dumps(b.get('roofline'))}\n")
+    for f in glob.glob(os.path.join(d, "**", "*_kernel_stats.csv"), recursive=True):
+        print("| kernel | calls | total ns | avg ns | % | min ns | max ns |\n|---|---|---|---|---|---|---|")
+        for r in csv.DictReader(open(f)):
+            print(f"| `{r['Name'][:70]}` | {r['Calls']} | {r['TotalDurationNs']} | {float(r['AverageNs']):.0f} | {r['Percentage']} | {r['MinNs']} | {r['MaxNs']} |")
+        print()
+    for f in glob.glob(os.path.join(d, "**", "*_kernel_trace.csv"), recursive=True):
+        acc = collections.defaultdict(list)
+        meta = {}
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"][:70]
+            acc[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+            meta[k] = (r.get("VGPR_Count"), r.get("Accum_VGPR_Count"), r.get("SGPR_Count"), r.get("LDS_Block_Size"), r.get("Grid_Size"), r.get("Workgroup_Size"))
+        print("| kernel | median ns | vgpr | agpr | sgpr | lds | grid | wg |\n|---|---|---|---|---|---|---|---|")
+        for k, v in acc.items():
+            v.sort()
+            m = meta[k]
+            print(f"| `{k}` | {v[len(v)//2]} | {m[0]} | {m[1]} | {m[2]} | {m[3]} | {m[4]} | {m[5]} |")
+        print()
+print("## PMC passes (bench.py --workload config4 / config4r), per dispatch averages\n")
+print("FETCH_SIZE / WRITE_SIZE are in KiB. On gfx950 FETCH_SIZE counts 64 B per 128-B request for wide\ncoalesced reads (MI355X_MICROARCH.md, HBM section): corrected read bytes = 2 x FETCH_SIZE x 1024.\n")
+print("| pass | kernel | dispatches | counter | avg value |\n|---|---|---|---|---|")
+for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
+    if not os.path.isdir(d):
+        continue
+    for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+        acc = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            acc[(r["Kernel_Name"][:60], r["Counter_Name"])].append(float(r["Counter_Value"]))
+        for (k, c), v in acc.items():
+            if k.startswith("__amd"):
+                continue
+            print(f"| {os.path.basename(d)} | `{k}` | {len(v)} | {c} | {sum(v)/len(v):.1f} |")
