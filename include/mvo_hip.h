@@ -174,6 +174,21 @@ int mvo_hip_upload(mvo_hip_handle h, uint32_t n_windows, const mvo_hip_frame *fr
 int mvo_hip_solve(mvo_hip_handle h);
 int mvo_hip_download(mvo_hip_handle h, mvo_hip_frame *frames, mvo_hip_summary *summaries);
 
+/* Observation-partitioned solve of ONE large window over several GPUs (no reference counterpart:
+ * the reference is single-process).  Every rank uploads the same frames and
+ * options and ITS share of each pair's residual blocks.  The per-pair sums (8 doubles per pair:
+ * S xx,xy,xz,yy,yz,zz, sum rho, sum w r^2) are additive over ranks; the caller all-reduces them
+ * (RCCL/torch.distributed) between the calls below, after which every rank takes the identical
+ * LM step.  Each call drains the library's stream before returning.
+ *   no loss : begin -> [all-reduce sums] -> advance (whole LM loop, done = 1)
+ *   loss    : begin -> { pass -> [all-reduce sums] -> advance } until done
+ * partial_sums copies the sums to (direction 0) or from (direction 1) a caller-owned DEVICE
+ * buffer of 8 * n_windows * n_pairs doubles. */
+int mvo_hip_partial_begin(mvo_hip_handle h);
+int mvo_hip_partial_pass(mvo_hip_handle h);
+int mvo_hip_partial_advance(mvo_hip_handle h, int32_t *done);
+int mvo_hip_partial_sums(mvo_hip_handle h, void *device_buffer, uint64_t n_doubles, int direction);
+
 /* Debug/parity entry point: the raw residual r_i and the raw local Jacobian row of every
  * residual block at the initial point -- what ceres::Problem::Evaluate would return for the
  * problem built at IterativeRefinement.cpp:95-183 with apply_loss_function = false.

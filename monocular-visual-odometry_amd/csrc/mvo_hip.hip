@@ -66,7 +66,7 @@ struct mvo_hip_context {
   hipError_t last_hip_error = hipSuccess;
   // device buffers
   DevBuf d_frames, d_initx, d_wins, d_pairs, d_tiles, d_m0, d_m1, d_c, d_partial, d_pair_u, d_states,
-      d_results, d_status, d_done, d_trace, d_res, d_jac;
+      d_results, d_status, d_done, d_trace, d_res, d_jac, d_pairsum, d_pairs_unit;
   // pinned host mirror of small results
   LmResult* h_results = nullptr;
   size_t h_results_cap = 0;
@@ -287,7 +287,7 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
 }
 
 template <int NT>
-hipError_t launch_lm(mvo_hip_context* h, const SolveParams& prm) {
+hipError_t launch_lm(mvo_hip_context* h, const SolveParams& prm, bool from_pair_sums = false) {
   const size_t dyn = sizeof(double) * 10 * (size_t)h->P;
   static size_t configured = 0;
   if (dyn > configured) {
@@ -297,15 +297,103 @@ hipError_t launch_lm(mvo_hip_context* h, const SolveParams& prm) {
     configured = dyn;
   }
   hipLaunchKernelGGL(k_lm<NT>, dim3(h->W), dim3(NT), dyn, h->stream, prm, h->d_wins.as<WinDev>(),
-                     h->d_frames.as<double>(), h->d_initx.as<double>(), h->d_pairs.as<PairDev>(),
-                     h->d_partial.as<double>(), h->d_states.as<LmState>(), h->d_results.as<LmResult>(),
+                     h->d_frames.as<double>(), h->d_initx.as<double>(),
+                     from_pair_sums ? h->d_pairs_unit.as<PairDev>() : h->d_pairs.as<PairDev>(),
+                     from_pair_sums ? h->d_pairsum.as<double>() : h->d_partial.as<double>(),
+                     h->d_states.as<LmState>(), h->d_results.as<LmResult>(),
                      h->d_pair_u.as<double>(), h->d_status.as<int32_t>(), h->d_trace.as<TraceRec>(),
                      h->d_done.as<int32_t>());
   return hipGetLastError();
 }
 
-hipError_t launch_lm_any(mvo_hip_context* h, const SolveParams& prm) {
-  return h->P <= 64 ? launch_lm<64>(h, prm) : launch_lm<256>(h, prm);
+hipError_t launch_lm_any(mvo_hip_context* h, const SolveParams& prm, bool from_pair_sums = false) {
+  return h->P <= 64 ? launch_lm<64>(h, prm, from_pair_sums) : launch_lm<256>(h, prm, from_pair_sums);
+}
+
+// ---- observation-partitioned mode: fold / pass -> per-pair sums -> caller's
+// all-reduce -> LM step from the summed moments.  Every call drains the stream before returning.
+hipError_t launch_reduce_slots(mvo_hip_context* h) {
+  const uint32_t n = h->W * h->P;
+  hipLaunchKernelGGL(k_reduce_slots, dim3((n * 8 + 255) / 256), dim3(256), 0, h->stream,
+                     h->d_pairs.as<PairDev>(), n, h->d_partial.as<double>(), h->d_pairsum.as<double>());
+  return hipGetLastError();
+}
+
+int partial_begin(mvo_hip_context* h) {
+  if (!h->uploaded) return MVO_HIP_ERR_STATE;
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  const uint32_t n = h->W * h->P;
+  HIP_TRY(h->d_pairsum.reserve(sizeof(double) * 8 * (size_t)n));
+  HIP_TRY(h->d_pairs_unit.reserve(sizeof(PairDev) * (size_t)n));
+  std::vector<PairDev> unit(h->h_pairs);
+  for (uint32_t p = 0; p < n; ++p) {
+    unit[p].slot_begin = p;
+    unit[p].slot_end = p + 1;
+  }
+  HIP_TRY(hipMemcpyAsync(h->d_pairs_unit.p, unit.data(), sizeof(PairDev) * n, hipMemcpyHostToDevice, s));
+  if (h->trace_cap > 0) HIP_TRY(h->d_trace.reserve(sizeof(TraceRec) * (size_t)h->trace_cap));
+  HIP_TRY(hipMemsetAsync(h->d_states.p, 0, sizeof(LmState) * h->W, s));
+  HIP_TRY(hipMemsetAsync(h->d_status.p, 0, sizeof(int32_t) * h->W, s));
+  HIP_TRY(hipMemsetAsync(h->d_done.p, 0, sizeof(int32_t) * 4, s));
+  HIP_TRY(hipMemsetAsync(h->d_pairsum.p, 0, sizeof(double) * 8 * (size_t)n, s));
+  const uint32_t fold_blocks = (h->n_tiles + FOLD_WAVES - 1) / FOLD_WAVES;
+  if (!h->pass_mode) {
+    if (fold_blocks) {
+      hipLaunchKernelGGL((k_fold<false, true>), dim3(fold_blocks), dim3(FOLD_THREADS), 0, s,
+                         h->d_tiles.as<TileDev>(), h->n_tiles, h->d_frames.as<double>(), h->d_m0.as<double>(),
+                         h->d_m1.as<double>(), (double*)nullptr, (size_t)0, h->d_partial.as<double>());
+      HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(launch_reduce_slots(h));
+  } else {
+    if (fold_blocks) {
+      hipLaunchKernelGGL((k_fold<true, false>), dim3(fold_blocks), dim3(FOLD_THREADS), 0, s,
+                         h->d_tiles.as<TileDev>(), h->n_tiles, h->d_frames.as<double>(), h->d_m0.as<double>(),
+                         h->d_m1.as<double>(), h->d_c.as<double>(), (size_t)h->c_elems, h->d_partial.as<double>());
+      HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(launch_lm_any(h, make_params(h), true));  // PH_START: publishes u(x0)
+  }
+  HIP_TRY(hipStreamSynchronize(s));
+  return MVO_HIP_OK;
+}
+
+int partial_pass(mvo_hip_context* h) {
+  if (!h->uploaded || !h->pass_mode || !h->d_pairsum.p) return MVO_HIP_ERR_STATE;
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  const uint32_t fold_blocks = (h->n_tiles + FOLD_WAVES - 1) / FOLD_WAVES;
+  if (fold_blocks) {
+    if (h->opt.use_loss_function)
+      hipLaunchKernelGGL((k_pass<true>), dim3(fold_blocks), dim3(FOLD_THREADS), 0, s, h->d_tiles.as<TileDev>(),
+                         h->n_tiles, h->d_c.as<double>(), (size_t)h->c_elems, h->d_pair_u.as<double>(),
+                         h->d_status.as<int32_t>(), h->d_partial.as<double>());
+    else
+      hipLaunchKernelGGL((k_pass<false>), dim3(fold_blocks), dim3(FOLD_THREADS), 0, s, h->d_tiles.as<TileDev>(),
+                         h->n_tiles, h->d_c.as<double>(), (size_t)h->c_elems, h->d_pair_u.as<double>(),
+                         h->d_status.as<int32_t>(), h->d_partial.as<double>());
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(launch_reduce_slots(h));
+  HIP_TRY(hipStreamSynchronize(s));
+  return MVO_HIP_OK;
+}
+
+int partial_advance(mvo_hip_context* h, int32_t* done) {
+  if (!h->uploaded || !h->d_pairsum.p) return MVO_HIP_ERR_STATE;
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  HIP_TRY(launch_lm_any(h, make_params(h), true));
+  HIP_TRY(hipMemcpyAsync(h->h_done, h->d_done.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  const bool all = (uint32_t)h->h_done[0] >= h->W;
+  if (all) {
+    HIP_TRY(hipMemcpyAsync(h->h_results, h->d_results.p, sizeof(LmResult) * h->W, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  }
+  if (done) *done = all ? 1 : 0;
+  return MVO_HIP_OK;
 }
 
 int do_solve(mvo_hip_context* h) {
@@ -494,7 +582,7 @@ void mvo_hip_destroy(mvo_hip_handle h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   DevBuf* bufs[] = {&h->d_frames, &h->d_initx, &h->d_wins, &h->d_pairs, &h->d_tiles, &h->d_m0, &h->d_m1,
                     &h->d_c, &h->d_partial, &h->d_pair_u, &h->d_states, &h->d_results, &h->d_status,
-                    &h->d_done, &h->d_trace, &h->d_res, &h->d_jac};
+                    &h->d_done, &h->d_trace, &h->d_res, &h->d_jac, &h->d_pairsum, &h->d_pairs_unit};
   for (DevBuf* b : bufs) b->release();
   if (h->h_results) (void)hipHostFree(h->h_results);
   if (h->h_done) (void)hipHostFree(h->h_done);
@@ -596,6 +684,27 @@ int mvo_hip_pair_moments(mvo_hip_handle h, double* moments) {
       for (int v = 0; v < 6; ++v) S[v] += part[(size_t)sl * 8 + v];
     std::memcpy(moments + 6 * p, S, sizeof S);
   }
+  return MVO_HIP_OK;
+}
+
+int mvo_hip_partial_begin(mvo_hip_handle h) { return h ? partial_begin(h) : MVO_HIP_ERR_INVALID_ARGUMENT; }
+
+int mvo_hip_partial_pass(mvo_hip_handle h) { return h ? partial_pass(h) : MVO_HIP_ERR_INVALID_ARGUMENT; }
+
+int mvo_hip_partial_advance(mvo_hip_handle h, int32_t* done) {
+  return h ? partial_advance(h, done) : MVO_HIP_ERR_INVALID_ARGUMENT;
+}
+
+int mvo_hip_partial_sums(mvo_hip_handle h, void* device_buffer, uint64_t n_doubles, int direction) {
+  if (!h || !device_buffer) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  if (!h->uploaded || !h->d_pairsum.p) return MVO_HIP_ERR_STATE;
+  if (n_doubles != 8ull * h->W * h->P) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(h->device));
+  if (direction == 0)
+    HIP_TRY(hipMemcpyAsync(device_buffer, h->d_pairsum.p, sizeof(double) * n_doubles, hipMemcpyDeviceToDevice, h->stream));
+  else
+    HIP_TRY(hipMemcpyAsync(h->d_pairsum.p, device_buffer, sizeof(double) * n_doubles, hipMemcpyDeviceToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
   return MVO_HIP_OK;
 }
 

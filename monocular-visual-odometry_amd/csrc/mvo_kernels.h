@@ -206,6 +206,22 @@ __global__ __launch_bounds__(FOLD_THREADS) void k_pass(const TileDev* __restrict
 }
 
 // ---------------------------------------------------------------------------------------
+// k_reduce_slots: per-pair sums of the slot partials (observation-partitioned mode: these 8
+// numbers per pair are what the ranks all-reduce before the identical LM step).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_reduce_slots(const PairDev* __restrict__ pairs, uint32_t n_pairs,
+                                                      const double* __restrict__ partial,
+                                                      double* __restrict__ pair_sums) {
+  const uint32_t item = blockIdx.x * 256 + threadIdx.x;
+  if (item >= n_pairs * 8) return;
+  const uint32_t p = item >> 3, v = item & 7;
+  const PairDev pd = pairs[p];
+  double acc = 0.0;
+  for (uint32_t sl = pd.slot_begin; sl < pd.slot_end; ++sl) acc += partial[(size_t)sl * 8 + v];
+  pair_sums[item] = acc;
+}
+
+// ---------------------------------------------------------------------------------------
 // k_eval (debug / parity): raw r and local Jacobian rows at the initial point.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(FOLD_THREADS) void k_eval(SolveParams prm, const TileDev* __restrict__ tiles,

@@ -1,0 +1,145 @@
+// adapter_check.cpp -- exercises host/IterativeRefinementHip.hpp with stand-ins for the reference's
+// Frame / Feature data model (sliding_window/Frame.hpp, Feature.hpp), so that the adapter and its
+// gathering order can be tested without OpenCV/ROS.
+//
+//   adapter_check gather <tracks.bin> <csr.bin>     CPU only: dumps the CSR buffers the adapter builds
+//   adapter_check refine <tracks.bin> <out.bin>     GPU: runs refine() through libmvo_hip
+//
+// tracks.bin (little endian): int32 N, M, maxNumIterations, useLoss, fixLength; double ftol, gtol,
+//   ptol, lowest, highest; per frame: double R[9], vec[3], scale; int32 nfeat; per feature:
+//   double ray[3] (x,y,1 as projectPixelTo3dRay returns), int32 preFeature, int32 preFeatureCounter.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "IterativeRefinementHip.hpp"
+
+namespace {
+
+struct Vec3 {
+  double v[3];
+  double &operator[](int i) { return v[i]; }
+  const double &operator[](int i) const { return v[i]; }
+};
+struct Mat33 {
+  double m[9];
+  double operator()(int r, int c) const { return m[3 * r + c]; }
+};
+struct RefinementFrame {  // IterativeRefinement.hpp:171-175
+  Mat33 R;
+  Vec3 vec;
+  double scale;
+};
+struct Feature {  // sliding_window/Feature.hpp
+  Vec3 ray;
+  int preFeature;
+  unsigned int preFeatureCounter;
+};
+struct Parameters {
+  bool fixLength;
+};
+
+// The subset of sliding_window/Frame.hpp that refine() touches, with the same semantics.
+class Frame {
+ public:
+  std::vector<Feature> features;
+  const Frame *preFrame;
+  Parameters params;
+  Frame() : preFrame(0) { params.fixLength = false; }
+  const Parameters &getParameters() const { return params; }
+  const Frame &getPreviousFrame(unsigned int past) const {
+    const Frame *f = this;
+    for (unsigned int i = 0; i < past; i++) f = f->preFrame;
+    return *f;
+  }
+  // Frame.hpp:258-302: features of THIS frame whose track reaches `past` frames back
+  void getCorrespondingFeatures(unsigned int past, std::vector<Vec3> &oldFeatures,
+                                std::vector<Vec3> &newFeatures) const {
+    for (std::size_t i = 0; i < features.size(); i++) {
+      if (features[i].preFeatureCounter >= past) {
+        newFeatures.push_back(features[i].ray);
+        const Feature *old = &features[i];
+        const Frame *frame = this;
+        for (unsigned int k = 0; k < past; k++) {
+          frame = frame->preFrame;
+          old = &frame->features[static_cast<std::size_t>(old->preFeature)];
+        }
+        oldFeatures.push_back(old->ray);
+      }
+    }
+  }
+};
+
+bool rd(FILE *f, void *p, std::size_t n) { return std::fread(p, 1, n, f) == n; }
+
+}  // namespace
+
+int main(int argc, char **argv) {
+  if (argc != 4) {
+    std::fprintf(stderr, "usage: adapter_check gather|refine <tracks.bin> <out.bin>\n");
+    return 2;
+  }
+  const std::string mode = argv[1];
+  FILE *f = std::fopen(argv[2], "rb");
+  if (!f) return 3;
+  int32_t hdr[5];
+  double tol[5];
+  if (!rd(f, hdr, sizeof hdr) || !rd(f, tol, sizeof tol)) return 4;
+  const unsigned int N = static_cast<unsigned int>(hdr[0]), M = static_cast<unsigned int>(hdr[1]);
+  std::vector<Frame> frames(N);
+  std::vector<RefinementFrame> data(N);
+  for (unsigned int i = 0; i < N; i++) {
+    int32_t nfeat;
+    if (!rd(f, data[i].R.m, 72) || !rd(f, data[i].vec.v, 24) || !rd(f, &data[i].scale, 8) || !rd(f, &nfeat, 4))
+      return 4;
+    frames[i].features.resize(static_cast<std::size_t>(nfeat));
+    frames[i].params.fixLength = hdr[4] != 0;
+    frames[i].preFrame = (i + 1 < N) ? &frames[i + 1] : 0;
+    for (int32_t k = 0; k < nfeat; k++) {
+      Feature &ft = frames[i].features[static_cast<std::size_t>(k)];
+      int32_t pre, cnt;
+      if (!rd(f, ft.ray.v, 24) || !rd(f, &pre, 4) || !rd(f, &cnt, 4)) return 4;
+      ft.preFeature = pre;
+      ft.preFeatureCounter = static_cast<unsigned int>(cnt);
+    }
+  }
+  std::fclose(f);
+
+  FILE *o = std::fopen(argv[3], "wb");
+  if (!o) return 5;
+  if (mode == "gather") {
+    mvo_hip_adapter::GatheredObservations g;
+    mvo_hip_adapter::gather<Vec3>(frames[0], M, N, g);
+    const uint64_t np = g.pair_offsets.size() - 1, nb = g.m0.size() / 3;
+    std::fwrite(&np, 8, 1, o);
+    std::fwrite(&nb, 8, 1, o);
+    std::fwrite(g.pair_offsets.data(), 8, g.pair_offsets.size(), o);
+    std::fwrite(g.m0.data(), 8, g.m0.size(), o);
+    std::fwrite(g.m1.data(), 8, g.m1.size(), o);
+  } else {
+    mvo_hip_handle h = 0;
+    int rc = mvo_hip_create(0, 1, N, 0, &h);
+    if (rc != MVO_HIP_OK) {
+      std::fprintf(stderr, "mvo_hip_create: %s\n", mvo_hip_status_string(rc));
+      return 10 + rc;
+    }
+    mvo_hip_summary s;
+    std::memset(&s, 0, sizeof s);
+    rc = mvo_hip_adapter::refine<Vec3>(h, data, M, N, 4, hdr[2], tol[0], tol[1], tol[2], hdr[3] != 0, tol[3],
+                                       tol[4], frames[0], &s);
+    mvo_hip_destroy(h);
+    if (rc != MVO_HIP_OK) {
+      std::fprintf(stderr, "refine: %s\n", mvo_hip_status_string(rc));
+      return 10 + rc;
+    }
+    for (unsigned int i = 0; i < N; i++) {
+      std::fwrite(data[i].vec.v, 8, 3, o);
+      std::fwrite(&data[i].scale, 8, 1, o);
+    }
+    std::fwrite(&s, sizeof s, 1, o);
+  }
+  std::fclose(o);
+  return 0;
+}

@@ -29,7 +29,8 @@ EXPORTED_SYMBOLS = [
     "mvo_hip_create", "mvo_hip_destroy", "mvo_hip_refine", "mvo_hip_refine_batch", "mvo_hip_upload",
     "mvo_hip_solve", "mvo_hip_download", "mvo_hip_eval", "mvo_hip_pair_moments", "mvo_hip_set_trace",
     "mvo_hip_get_trace", "mvo_hip_get_timing", "mvo_hip_reverse_scale", "mvo_hip_scale",
-    "mvo_hip_num_pairs", "mvo_hip_status_string", "mvo_hip_version",
+    "mvo_hip_num_pairs", "mvo_hip_status_string", "mvo_hip_version", "mvo_hip_partial_begin",
+    "mvo_hip_partial_pass", "mvo_hip_partial_advance", "mvo_hip_partial_sums",
 ]
 
 
@@ -132,6 +133,10 @@ def load():
                                    C.POINTER(Observations), C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
         L.mvo_hip_pair_moments.argtypes = [C.c_void_p, C.c_void_p]
         L.mvo_hip_set_trace.argtypes = [C.c_void_p, C.c_int32]
+        L.mvo_hip_partial_begin.argtypes = [C.c_void_p]
+        L.mvo_hip_partial_pass.argtypes = [C.c_void_p]
+        L.mvo_hip_partial_advance.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+        L.mvo_hip_partial_sums.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]
         L.mvo_hip_get_trace.argtypes = [C.c_void_p, C.POINTER(Iteration), C.c_int32, C.POINTER(C.c_int32)]
         L.mvo_hip_get_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
         L.mvo_hip_reverse_scale.argtypes = [C.c_double] * 3
@@ -238,6 +243,7 @@ class Solver:
     def upload(self, windows, options=None):
         opt = options or make_options()
         self._W, self._M, self._N = len(windows), windows[0].M, windows[0].N
+        self._pass_mode = bool(opt.use_loss_function) or opt.assembly_mode == ASSEMBLY_PASSES
         self._frames0 = np.ascontiguousarray(np.concatenate([w.frames for w in windows], axis=0),
                                              dtype=np.float64)
         pk = _Packed(windows)
@@ -258,6 +264,37 @@ class Solver:
         if rc != OK:
             raise MvoHipError(rc, "mvo_hip_download")
         return frames.reshape(self._W, self._N, 13), list(summ)
+
+    # -- observation-partitioned mode (one window over several GPUs) -------------------------
+    def solve_partitioned(self, allreduce, sums):
+        """Solve the uploaded SHARD together with the other ranks.  `sums` is a device tensor of
+        8 * n_windows * n_pairs float64 (anything with .data_ptr() and .numel()); `allreduce(sums)`
+        must sum it in place over all ranks and return after the result is usable by other streams
+        (torch.distributed.all_reduce + torch.cuda.synchronize()).  Every rank ends with the same
+        refined frames; fetch them with download()."""
+        lib, n = self._lib, int(sums.numel())
+
+        def check(rc, what):
+            if rc != OK:
+                raise MvoHipError(rc, what)
+
+        def exchange():
+            check(lib.mvo_hip_partial_sums(self._h, sums.data_ptr(), n, 0), "mvo_hip_partial_sums(out)")
+            allreduce(sums)
+            check(lib.mvo_hip_partial_sums(self._h, sums.data_ptr(), n, 1), "mvo_hip_partial_sums(in)")
+
+        check(lib.mvo_hip_partial_begin(self._h), "mvo_hip_partial_begin")
+        done = C.c_int32(0)
+        if not self._pass_mode:
+            exchange()
+            check(lib.mvo_hip_partial_advance(self._h, C.byref(done)), "mvo_hip_partial_advance")
+        else:
+            while not done.value:
+                check(lib.mvo_hip_partial_pass(self._h), "mvo_hip_partial_pass")
+                exchange()
+                check(lib.mvo_hip_partial_advance(self._h, C.byref(done)), "mvo_hip_partial_advance")
+        if not done.value:
+            raise MvoHipError(ERR_DEVICE, "partitioned solve did not terminate")
 
     # -- debug / parity -------------------------------------------------------------------
     def evaluate(self, window, options=None):

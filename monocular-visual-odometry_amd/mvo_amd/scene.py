@@ -81,6 +81,7 @@ def make_window(
     init_angle_deg: float = 3.0,
     init_scale_jitter: float = 0.2,
     min_abs_vx: float = 0.2,
+    keep_tracks: bool = False,
 ) -> Window:
     """Build one window.
 
@@ -180,12 +181,48 @@ def make_window(
         s = true_scale[k] * rng.uniform(1.0 - init_scale_jitter, 1.0 + init_scale_jitter)
         frames[k, 12] = float(np.clip(s, LOWEST_LENGTH + 0.01, HIGHEST_LENGTH - 0.01))
 
+    meta = dict(seed=seed, n_landmarks=n_landmarks, span=span, noise_sigma=noise_sigma,
+                outlier_fraction=outlier_fraction)
+    if keep_tracks:
+        assert outlier_fraction == 0, "outliers are injected per residual block, not per track"
+        meta["tracks"] = dict(lo=lo_a, hi=hi_a, rays=rays)
     return Window(
         N=N, M=M, frames=frames, pair_offsets=offs, m0=m0, m1=m1, true_vec=true_vec,
-        true_scale=true_scale, bearing_observations=bearing_obs,
-        meta=dict(seed=seed, n_landmarks=n_landmarks, span=span, noise_sigma=noise_sigma,
-                  outlier_fraction=outlier_fraction),
+        true_scale=true_scale, bearing_observations=bearing_obs, meta=meta,
     )
+
+
+def write_track_file(w: Window, path: str, max_num_iterations=10, function_tolerance=0.0,
+                     gradient_tolerance=0.0, parameter_tolerance=0.0, use_loss_function=False,
+                     fix_length=False, lowest_length=LOWEST_LENGTH, highest_length=HIGHEST_LENGTH):
+    """Serialise a window (built with keep_tracks=True) as the reference's Frame/Feature track
+    structure (sliding_window/Frame.hpp, Feature.hpp) for host/adapter_check: per frame the
+    features in landmark order, each with its ray (x, y, 1) as projectPixelTo3dRay returns it
+    (FeatureOperations.cpp:31-33), the index of its predecessor feature in the next older frame
+    (_preFeature, -1 if none) and the number of older frames it reaches (_preFeatureCounter)."""
+    import struct
+
+    tr = w.meta["tracks"]
+    lo, hi, rays = tr["lo"], tr["hi"], tr["rays"]
+    N = w.N
+    ids = [np.nonzero((lo <= i) & (hi >= i))[0] for i in range(N)]
+    index = []
+    for i in range(N):
+        m = -np.ones(len(lo), dtype=np.int64)
+        m[ids[i]] = np.arange(len(ids[i]))
+        index.append(m)
+    with open(path, "wb") as f:
+        f.write(struct.pack("<5i", N, w.M, max_num_iterations, int(use_loss_function), int(fix_length)))
+        f.write(struct.pack("<5d", function_tolerance, gradient_tolerance, parameter_tolerance,
+                            lowest_length, highest_length))
+        for i in range(N):
+            f.write(np.ascontiguousarray(w.frames[i], dtype="<f8").tobytes())
+            f.write(struct.pack("<i", len(ids[i])))
+            for l in ids[i]:
+                r = rays[i, l] / rays[i, l, 2]
+                pre = int(index[i + 1][l]) if i + 1 < N and hi[l] >= i + 1 else -1
+                cnt = int(min(hi[l], N - 1) - i)
+                f.write(struct.pack("<3dii", r[0], r[1], r[2], pre, cnt))
 
 
 # ---------------------------------------------------------------------------------------

@@ -1,0 +1,41 @@
+"""Multi-GPU partition plans for the refinement path.
+
+* independent windows (BASELINE config 3): a static block partition of window ids, one process
+  per GPU, no data-path collective;
+* one large window (config 4): every pair's residual blocks are range-partitioned; the per-pair
+  sums are additive, so one all-reduce of 8 doubles per pair precedes each (identical) LM step.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import scene
+
+
+def shard_range(n: int, rank: int, world: int):
+    """[lo, hi) of a balanced contiguous partition of range(n)."""
+    return (n * rank) // world, (n * (rank + 1)) // world
+
+
+def shard_windows(n_windows: int, rank: int, world: int):
+    lo, hi = shard_range(n_windows, rank, world)
+    return range(lo, hi)
+
+
+def shard_observations(w: "scene.Window", rank: int, world: int) -> "scene.Window":
+    """This rank's share of every frame pair's residual blocks (same frames, same pair order)."""
+    offs = [0]
+    a0, a1 = [], []
+    for p in range(w.n_pairs):
+        lo, hi = int(w.pair_offsets[p]), int(w.pair_offsets[p + 1])
+        s0, s1 = shard_range(hi - lo, rank, world)
+        a0.append(w.m0[lo + s0:lo + s1])
+        a1.append(w.m1[lo + s0:lo + s1])
+        offs.append(offs[-1] + (s1 - s0))
+    return scene.Window(
+        N=w.N, M=w.M, frames=w.frames, pair_offsets=np.array(offs, dtype=np.uint64),
+        m0=np.ascontiguousarray(np.concatenate(a0)) if a0 else w.m0[:0],
+        m1=np.ascontiguousarray(np.concatenate(a1)) if a1 else w.m1[:0],
+        true_vec=w.true_vec, true_scale=w.true_scale, bearing_observations=w.bearing_observations,
+        meta=dict(w.meta, shard=(rank, world)),
+    )

@@ -1,0 +1,107 @@
+"""Observation-partitioned solve (one large window over several GPUs) on ONE
+GPU: two handles play two ranks (threads + a barrier stand in for the all-reduce), and a
+world-size-1 RCCL process group exercises the real torch.distributed call path."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from _util import FIXED10, refined
+from mvo_amd import capi, scene, sharding
+
+pytestmark = pytest.mark.gpu
+
+
+def _two_rank_solve(w, opt):
+    world = 2
+    solvers = [capi.Solver(0) for _ in range(world)]
+    sums = [torch.zeros(8 * w.n_pairs, dtype=torch.float64, device="cuda") for _ in range(world)]
+    barrier = threading.Barrier(world)
+    errors = []
+
+    def allreduce_for(rank):
+        def allreduce(t):
+            torch.cuda.synchronize()
+            barrier.wait()
+            total = sums[0] + sums[1]
+            torch.cuda.synchronize()
+            barrier.wait()
+            t.copy_(total)
+            torch.cuda.synchronize()
+            barrier.wait()
+        return allreduce
+
+    def run(rank):
+        try:
+            solvers[rank].upload([sharding.shard_observations(w, rank, world)], opt)
+            solvers[rank].solve_partitioned(allreduce_for(rank), sums[rank])
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+            barrier.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(120)
+    assert not errors, errors
+    out = [s.download() for s in solvers]
+    for s in solvers:
+        s.close()
+    return out
+
+
+@pytest.mark.parametrize("use_loss", [False, True])
+def test_two_shards_equal_single_solve(solver, oracle, use_loss):
+    w = scene.make_window(30, 5, 800, seed=41, span=("sliding", 18))
+    kw = dict(use_loss_function=use_loss, **FIXED10)
+    out = _two_rank_solve(w, capi.make_options(**kw))
+    (f0, s0), (f1, s1) = out
+    assert np.array_equal(f0, f1) and s0[0].final_cost == s1[0].final_cost   # ranks agree bitwise
+    fs, ss = solver.refine(w, capi.make_options(**kw))
+    assert np.abs(refined(f0[0], 5) - refined(fs, 5)).max() < 1e-9           # summation order only
+    fo, so, _ = oracle.refine(w, oracle.make_options(**kw))
+    assert np.abs(refined(f0[0], 5) - refined(fo, 5)).max() < 1e-6
+    assert s0[0].iterations == so.iterations == 10
+
+
+def test_default_tolerances_terminate_on_all_ranks(oracle):
+    w = scene.make_window(9, 3, 300, seed=42)
+    out = _two_rank_solve(w, capi.make_options(use_loss_function=True))
+    fo, so, _ = oracle.refine(w, oracle.make_options(use_loss_function=True))
+    for f, s in out:
+        assert s[0].termination == so.termination == 0
+        assert abs(s[0].iterations - so.iterations) <= 1
+        assert np.abs(refined(f[0], 3)[:, :3] - refined(fo, 3)[:, :3]).max() < 1e-4
+
+
+def test_rccl_world1_call_path(solver):
+    """torch.distributed backend "nccl" is RCCL on ROCm; one rank is all a one-GPU box offers."""
+    import os
+    import socket
+    import torch.distributed as dist
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        w = scene.config1()
+        for use_loss in (False, True):
+            opt = capi.make_options(use_loss_function=use_loss, **FIXED10)
+            sums = torch.zeros(8 * w.n_pairs, dtype=torch.float64, device="cuda")
+
+            def allreduce(t):
+                dist.all_reduce(t)
+                torch.cuda.synchronize()
+
+            solver.upload([w], opt)
+            solver.solve_partitioned(allreduce, sums)
+            fp, sp = solver.download()
+            fs, ss = solver.refine(w, opt)
+            assert np.abs(refined(fp[0], 5) - refined(fs, 5)).max() < 1e-9
+            assert float(sums.abs().sum()) > 0
+    finally:
+        dist.destroy_process_group()
