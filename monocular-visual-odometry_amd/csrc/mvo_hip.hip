@@ -10,6 +10,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -180,6 +181,10 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
         n_tiles += (obs[w].pair_offsets[p + 1] - obs[w].pair_offsets[p] + tile - 1) / tile;
     if (n_tiles >= 16384) break;
   }
+  if (const char* e = std::getenv("MVO_HIP_TILE")) {  // tuning knob for experiments
+    const int t = std::atoi(e);
+    if (t >= 64 && t <= 65536 && (t % 64) == 0) tile = (uint32_t)t;
+  }
   h->tile_size = tile;
 
   std::vector<WinDev> wins(W);
@@ -248,6 +253,13 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
   if (h->pass_mode) HIP_TRY(h->d_c.reserve(sizeof(double) * 3 * h->c_elems));
   HIP_TRY(h->d_partial.reserve(sizeof(double) * 8 * ((size_t)slot + 1)));
   HIP_TRY(h->d_pair_u.reserve(sizeof(double) * 4 * pairs.size()));
+  HIP_TRY(h->d_pairsum.reserve(sizeof(double) * 8 * pairs.size()));
+  HIP_TRY(h->d_pairs_unit.reserve(sizeof(PairDev) * pairs.size()));
+  std::vector<PairDev> unit(pairs);  // the same pairs, each reading its own row of d_pairsum
+  for (size_t q = 0; q < unit.size(); ++q) {
+    unit[q].slot_begin = (uint32_t)q;
+    unit[q].slot_end = (uint32_t)q + 1;
+  }
   HIP_TRY(h->d_states.reserve(sizeof(LmState) * W));
   HIP_TRY(h->d_results.reserve(sizeof(LmResult) * W));
   HIP_TRY(h->d_status.reserve(sizeof(int32_t) * W));
@@ -266,6 +278,7 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
   HIP_TRY(hipMemcpyAsync(h->d_initx.p, initx.data(), sizeof(double) * initx.size(), hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(h->d_wins.p, wins.data(), sizeof(WinDev) * W, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(h->d_pairs.p, pairs.data(), sizeof(PairDev) * pairs.size(), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(h->d_pairs_unit.p, unit.data(), sizeof(PairDev) * unit.size(), hipMemcpyHostToDevice, s));
   if (!tiles.empty())
     HIP_TRY(hipMemcpyAsync(h->d_tiles.p, tiles.data(), sizeof(TileDev) * tiles.size(), hipMemcpyHostToDevice, s));
   uint64_t pos = 0;
@@ -296,7 +309,8 @@ hipError_t launch_lm(mvo_hip_context* h, const SolveParams& prm, bool from_pair_
     if (e != hipSuccess) return e;
     configured = dyn;
   }
-  hipLaunchKernelGGL(k_lm<NT>, dim3(h->W), dim3(NT), dyn, h->stream, prm, h->d_wins.as<WinDev>(),
+  hipLaunchKernelGGL(k_lm<NT>, dim3(h->W), dim3(NT), dyn, h->stream, prm, from_pair_sums ? 1 : 0,
+                     h->d_wins.as<WinDev>(),
                      h->d_frames.as<double>(), h->d_initx.as<double>(),
                      from_pair_sums ? h->d_pairs_unit.as<PairDev>() : h->d_pairs.as<PairDev>(),
                      from_pair_sums ? h->d_pairsum.as<double>() : h->d_partial.as<double>(),
@@ -324,14 +338,6 @@ int partial_begin(mvo_hip_context* h) {
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t s = h->stream;
   const uint32_t n = h->W * h->P;
-  HIP_TRY(h->d_pairsum.reserve(sizeof(double) * 8 * (size_t)n));
-  HIP_TRY(h->d_pairs_unit.reserve(sizeof(PairDev) * (size_t)n));
-  std::vector<PairDev> unit(h->h_pairs);
-  for (uint32_t p = 0; p < n; ++p) {
-    unit[p].slot_begin = p;
-    unit[p].slot_end = p + 1;
-  }
-  HIP_TRY(hipMemcpyAsync(h->d_pairs_unit.p, unit.data(), sizeof(PairDev) * n, hipMemcpyHostToDevice, s));
   if (h->trace_cap > 0) HIP_TRY(h->d_trace.reserve(sizeof(TraceRec) * (size_t)h->trace_cap));
   HIP_TRY(hipMemsetAsync(h->d_states.p, 0, sizeof(LmState) * h->W, s));
   HIP_TRY(hipMemsetAsync(h->d_status.p, 0, sizeof(int32_t) * h->W, s));
@@ -434,7 +440,10 @@ int do_solve(mvo_hip_context* h) {
       HIP_TRY(timed_end());
       ++asm_launches;
     }
-    HIP_TRY(launch_lm_any(h, prm));
+    // S_p never changes without a loss: sum the slots once, then the whole LM loop runs in one
+    // launch on 8 doubles per pair
+    HIP_TRY(launch_reduce_slots(h));
+    HIP_TRY(launch_lm_any(h, prm, true));
     ++lm_launches;
   } else {
     if (fold_blocks) {
@@ -759,6 +768,17 @@ const char* mvo_hip_status_string(int status) {
     default: return "unknown status";
   }
 }
+
+#ifdef MVO_LM_STAMPS
+// diagnostic build: phase cycle counters of k_lm (window 0); [0] = iterations counted
+int mvo_hip_debug_stamps(unsigned long long* out8, int reset) {
+  if (reset) {
+    unsigned long long z[16] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(mvo_lm_stamps), z, sizeof z) == hipSuccess ? 0 : 4;
+  }
+  return hipMemcpyFromSymbol(out8, HIP_SYMBOL(mvo_lm_stamps), 128) == hipSuccess ? 0 : 4;
+}
+#endif
 
 const char* mvo_hip_version(void) { return "libmvo_hip 0.1 (gfx950)"; }
 

@@ -17,6 +17,33 @@
 
 #include "mvo_device.h"
 
+// Diagnostic build only (-DMVO_LM_STAMPS): thread 0 of window 0 accumulates the shader-clock
+// cycles spent in each phase of an LM iteration into a buffer of its own (mvo_lm_stamps).
+#ifdef MVO_LM_STAMPS
+__device__ unsigned long long mvo_lm_stamps[16];
+#define MVO_STAMP(i)                                                        \
+  do {                                                                      \
+    if (w == 0 && tid == 0) {                                               \
+      const unsigned long long now_ = __builtin_amdgcn_s_memtime();         \
+      if ((i) > 0) mvo_lm_stamps[(i)] += now_ - stamp_prev_;                \
+      else mvo_lm_stamps[0] += 1;                                           \
+      stamp_prev_ = now_;                                                   \
+    }                                                                       \
+  } while (0)
+// finer stamps inside lm_advance (slots 8..15); `stamp_on` = window 0
+#define MVO_ASTAMP(i)                                                       \
+  do {                                                                      \
+    if (stamp_on && lane == 0) {                                            \
+      const unsigned long long now_ = __builtin_amdgcn_s_memtime();         \
+      mvo_lm_stamps[(i)] += now_ - astamp_prev_;                            \
+      astamp_prev_ = now_;                                                  \
+    }                                                                       \
+  } while (0)
+#else
+#define MVO_STAMP(i) do { } while (0)
+#define MVO_ASTAMP(i) do { } while (0)
+#endif
+
 // ---- wave-level helpers -----------------------------------------------------------------
 __device__ __forceinline__ double bcast_lane(double v, int src_lane /* compile-time uniform */) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
@@ -24,10 +51,51 @@ __device__ __forceinline__ double bcast_lane(double v, int src_lane /* compile-t
   return __hiloint2double(hi, lo);
 }
 
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-  return v;
+// Broadcast of lane SRC (0..15) of each 16-lane row to all lanes of that row (row_newbcast): two
+// v_mov_dpp, result stays in VGPRs -- used for the elimination's data flow (all matrix rows live
+// in row 0).  Values that steer control flow use bcast_lane (v_readlane: truly wave-uniform).
+template <int SRC>
+__device__ __forceinline__ double row_bcast(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + SRC, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + SRC, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+// DPP permutations inside each 16-lane row (no LDS traffic): xor 1, xor 2, half-row mirror, row
+// mirror.  After the four steps every lane of a row holds the row's total.  All state of k_lm's
+// dense algebra lives in row 0 (lanes 0..14 = matrix rows, lanes 0..4 = refined frames).
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row0_sum(double v) {
+  v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_f64<0x141>(v);  // row_half_mirror
+  v += dpp_f64<0x140>(v);  // row_mirror
+  return bcast_lane(v, 0);
+}
+__device__ __forceinline__ double row0_max(double v) {
+  v = fmax(v, dpp_f64<0xB1>(v));
+  v = fmax(v, dpp_f64<0x4E>(v));
+  v = fmax(v, dpp_f64<0x141>(v));
+  v = fmax(v, dpp_f64<0x140>(v));
+  return bcast_lane(v, 0);
+}
+
+// s(t) and s'(t) of IR.cpp:298-309 with one exp (same expressions as d_scale / d_dscale)
+__device__ __forceinline__ void d_scale_both(double t, double max_len, double min_len, double& s, double& sp) {
+  const double e = exp(-1.0 * t);
+  if (isinf(e)) {
+    s = min_len;
+    sp = 0.0;
+  } else {
+    const double g = 1.0 + e;
+    s = min_len + ((max_len - min_len) / g);
+    sp = (-(max_len - min_len) / (g * g)) * (-e);
+  }
 }
 
 // compact column index of (frame k, component j); fix_length drops the t column
@@ -38,19 +106,25 @@ __device__ __forceinline__ int fcol(int i, int fix) { return fix ? 3 * (i >> 1) 
 // per-pair index of (a, b) in the reference's loop order
 __device__ __forceinline__ int pair_index(int N, int a, int b) { return a * (N - 1) - (a * (a - 1)) / 2 + (b - a); }
 
-struct LmShared {
+template <int PARTS>
+struct LmSharedT {
+  LmState st;                                   // solver state (HBM copy only at launch begin/end)
   double zvec[MVO_MAXM][3], zt[MVO_MAXM], zs[MVO_MAXM], zsp[MVO_MAXM];
   double G[MVO_MAXM][9];                        // G[k][3*row + col]: columns (s_k jl0, s_k jl1, s'_k v_k)
   double cls[MVO_MAXM * (MVO_MAXM + 1)][10];    // class (a, j = min(b, M)): T(6) q(3) cost(1)
+  double clsp[PARTS > 1 ? MVO_MAXM * (MVO_MAXM + 1) * 10 : 1][PARTS];  // strided parts of the class sums
+  double W[MVO_MAXM * MVO_MAXM][6], y[MVO_MAXM][3];  // per block (k,l): sum of T; per frame: sum of q
   double Hz[MVO_MAXC * MVO_MAXC], gz[MVO_MAXC]; // full 3M system at z
   double cost_z;
   int32_t go, phase;
+  int32_t hsel, pad_;  // which of {st.H, Hz} holds the ACCEPTED system (the other receives the next evaluation)
 };
 
-// Register-resident solver state of wavefront 0.
+// Working copy of the solver state inside lm_advance (wavefront 0): filled from the LDS LmState on
+// entry, flushed on exit, so nothing is live in registers across the evaluation phases.
 struct LmRegs {
-  // lane l < n: row l of J^T J (active columns), gradient, jacobi scale, LM diagonal
-  double hrow[MVO_MAXC], g, js, dg, hdiag;
+  // lane l < n: gradient, jacobi scale, LM diagonal, H_ll of active column l (row l of H is in LDS)
+  double g, js, dg, hdiag;
   // lane k < M: accepted / candidate / best point of refined frame k
   double xv[3], xt, cv[3], ct, bv[3], bt;
   // wave-uniform scalars
@@ -60,61 +134,58 @@ struct LmRegs {
       ntrace;
 };
 
-__device__ __forceinline__ void regs_load(LmRegs& r, const LmState* __restrict__ g, int lane) {
-  const int l = lane < MVO_MAXC ? lane : 0, k = lane < MVO_MAXM ? lane : 0;
-#pragma unroll
-  for (int j = 0; j < MVO_MAXC; ++j) r.hrow[j] = g->H[l * MVO_MAXC + j];
-  r.g = g->g[l];
-  r.js = g->jscale[l];
-  r.dg = g->diag[l];
-  r.hdiag = g->H[l * MVO_MAXC + l];
+__device__ __forceinline__ void regs_load(LmRegs& r, const LmState& g, const double* __restrict__ Hacc, int fix,
+                                          int n, int lane) {
+  const int l = lane < n ? lane : 0, k = lane < MVO_MAXM ? lane : 0;
+  r.g = g.g[l];
+  r.js = g.jscale[l];
+  r.dg = g.diag[l];
+  r.hdiag = Hacc[fcol(l, fix) * (MVO_MAXC + 1)];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
-    r.xv[j] = g->x_vec[k][j];
-    r.cv[j] = g->c_vec[k][j];
-    r.bv[j] = g->b_vec[k][j];
+    r.xv[j] = g.x_vec[k][j];
+    r.cv[j] = g.c_vec[k][j];
+    r.bv[j] = g.b_vec[k][j];
   }
-  r.xt = g->x_t[k];
-  r.ct = g->c_t[k];
-  r.bt = g->b_t[k];
-  r.x_cost = g->x_cost; r.x_norm = g->x_norm; r.min_cost = g->min_cost; r.mcc = g->model_cost_change;
-  r.radius = g->radius; r.decf = g->decrease_factor; r.gmn = g->grad_max_norm;
-  r.initial_cost = g->initial_cost; r.final_cost = g->final_cost;
-  r.se_min = g->se_min; r.se_cur = g->se_cur; r.se_ref = g->se_ref; r.se_cand = g->se_cand;
-  r.se_acc_ref = g->se_acc_ref; r.se_acc_cand = g->se_acc_cand;
-  r.se_nonmono = g->se_nonmono; r.reuse_diag = g->reuse_diagonal; r.iteration = g->iteration;
-  r.num_invalid = g->num_invalid; r.nsucc = g->nsucc; r.nunsucc = g->nunsucc; r.status = g->status;
-  r.termination = g->termination; r.reason = g->reason; r.phase = g->phase; r.ntrace = g->ntrace;
+  r.xt = g.x_t[k];
+  r.ct = g.c_t[k];
+  r.bt = g.b_t[k];
+  r.x_cost = g.x_cost; r.x_norm = g.x_norm; r.min_cost = g.min_cost; r.mcc = g.model_cost_change;
+  r.radius = g.radius; r.decf = g.decrease_factor; r.gmn = g.grad_max_norm;
+  r.initial_cost = g.initial_cost; r.final_cost = g.final_cost;
+  r.se_min = g.se_min; r.se_cur = g.se_cur; r.se_ref = g.se_ref; r.se_cand = g.se_cand;
+  r.se_acc_ref = g.se_acc_ref; r.se_acc_cand = g.se_acc_cand;
+  r.se_nonmono = g.se_nonmono; r.reuse_diag = g.reuse_diagonal; r.iteration = g.iteration;
+  r.num_invalid = g.num_invalid; r.nsucc = g.nsucc; r.nunsucc = g.nunsucc; r.status = g.status;
+  r.termination = g.termination; r.reason = g.reason; r.phase = g.phase; r.ntrace = g.ntrace;
 }
 
-__device__ __forceinline__ void regs_store(const LmRegs& r, LmState* __restrict__ g, int lane) {
+__device__ __forceinline__ void regs_store(const LmRegs& r, LmState& g, int lane) {
   if (lane < MVO_MAXC) {
-#pragma unroll
-    for (int j = 0; j < MVO_MAXC; ++j) g->H[lane * MVO_MAXC + j] = r.hrow[j];
-    g->g[lane] = r.g;
-    g->jscale[lane] = r.js;
-    g->diag[lane] = r.dg;
+    g.g[lane] = r.g;
+    g.jscale[lane] = r.js;
+    g.diag[lane] = r.dg;
   }
   if (lane < MVO_MAXM) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      g->x_vec[lane][j] = r.xv[j];
-      g->c_vec[lane][j] = r.cv[j];
-      g->b_vec[lane][j] = r.bv[j];
+      g.x_vec[lane][j] = r.xv[j];
+      g.c_vec[lane][j] = r.cv[j];
+      g.b_vec[lane][j] = r.bv[j];
     }
-    g->x_t[lane] = r.xt;
-    g->c_t[lane] = r.ct;
-    g->b_t[lane] = r.bt;
+    g.x_t[lane] = r.xt;
+    g.c_t[lane] = r.ct;
+    g.b_t[lane] = r.bt;
   }
   if (lane == 0) {
-    g->x_cost = r.x_cost; g->x_norm = r.x_norm; g->min_cost = r.min_cost; g->model_cost_change = r.mcc;
-    g->radius = r.radius; g->decrease_factor = r.decf; g->grad_max_norm = r.gmn;
-    g->initial_cost = r.initial_cost; g->final_cost = r.final_cost;
-    g->se_min = r.se_min; g->se_cur = r.se_cur; g->se_ref = r.se_ref; g->se_cand = r.se_cand;
-    g->se_acc_ref = r.se_acc_ref; g->se_acc_cand = r.se_acc_cand;
-    g->se_nonmono = r.se_nonmono; g->reuse_diagonal = r.reuse_diag; g->iteration = r.iteration;
-    g->num_invalid = r.num_invalid; g->nsucc = r.nsucc; g->nunsucc = r.nunsucc; g->status = r.status;
-    g->termination = r.termination; g->reason = r.reason; g->phase = r.phase; g->ntrace = r.ntrace;
+    g.x_cost = r.x_cost; g.x_norm = r.x_norm; g.min_cost = r.min_cost; g.model_cost_change = r.mcc;
+    g.radius = r.radius; g.decrease_factor = r.decf; g.grad_max_norm = r.gmn;
+    g.initial_cost = r.initial_cost; g.final_cost = r.final_cost;
+    g.se_min = r.se_min; g.se_cur = r.se_cur; g.se_ref = r.se_ref; g.se_cand = r.se_cand;
+    g.se_acc_ref = r.se_acc_ref; g.se_acc_cand = r.se_acc_cand;
+    g.se_nonmono = r.se_nonmono; g.reuse_diagonal = r.reuse_diag; g.iteration = r.iteration;
+    g.num_invalid = r.num_invalid; g.nsucc = r.nsucc; g.nunsucc = r.nunsucc; g.status = r.status;
+    g.termination = r.termination; g.reason = r.reason; g.phase = r.phase; g.ntrace = r.ntrace;
   }
 }
 
@@ -134,7 +205,7 @@ __device__ __forceinline__ double frames_diff_norm(int lane, int M, int fix, con
       acc = inf_norm ? fmax(acc, d) : acc + d * d;
     }
   }
-  return inf_norm ? wave_max(acc) : sqrt(wave_sum(acc));
+  return inf_norm ? row0_max(acc) : sqrt(row0_sum(acc));
 }
 
 // x (+) sign*delta for frame `lane`: delta lives one component per lane (compact columns)
@@ -154,13 +225,84 @@ __device__ __forceinline__ void lm_terminate(LmRegs& r, int termination, int rea
   r.reason = reason;
 }
 
+// Lanes k < M publish the point to evaluate and everything the evaluation needs per frame:
+// s_k, s'_k and G_k = [s_k J_loc(v_k) | s'_k v_k], J_loc(v) = [[-2vy, 2vz], [2vx, 0], [0, -2vx]].
+template <class SH>
+__device__ __forceinline__ void lm_publish_point(SH& sh, const SolveParams& prm, int M, int lane,
+                                                 const double v[3], double t) {
+  if (lane < M) {
+    const int k = lane;
+    double s, sp;
+    d_scale_both(t, prm.max_len, prm.min_len, s, sp);
+    sh.zvec[k][0] = v[0];
+    sh.zvec[k][1] = v[1];
+    sh.zvec[k][2] = v[2];
+    sh.zt[k] = t;
+    sh.zs[k] = s;
+    sh.zsp[k] = sp;
+    sh.G[k][0] = s * (-2.0 * v[1]); sh.G[k][1] = s * (2.0 * v[2]);  sh.G[k][2] = sp * v[0];
+    sh.G[k][3] = s * (2.0 * v[0]);  sh.G[k][4] = 0.0;               sh.G[k][5] = sp * v[1];
+    sh.G[k][6] = 0.0;               sh.G[k][7] = s * (-2.0 * v[0]); sh.G[k][8] = sp * v[2];
+  }
+}
+
+// a[j] = js_l H_lj js_j for matrix row l = lane (zero rows for lanes >= n)
+template <int J>
+__device__ __forceinline__ void gj_setup(double (&a)[MVO_MAXC], const double* __restrict__ hrow, double js,
+                                         int lane, int n) {
+  if constexpr (J < MVO_MAXC) {
+    const double jsj = row_bcast<J>(js);
+    a[J] = (lane < n) ? js * hrow[J] * jsj : 0.0;
+    gj_setup<J + 1>(a, hrow, js, lane, n);
+  }
+}
+
+// diagonal: active rows get the LM damping D^2 = diag / radius, padding rows become identity
+__device__ __forceinline__ void a_diag_fix(double (&a)[MVO_MAXC], int lane, bool active, double dd) {
+#pragma unroll
+  for (int j = 0; j < MVO_MAXC; ++j)
+    if (j == lane) a[j] = active ? a[j] + dd : 1.0;
+}
+
+template <int J, int K>
+__device__ __forceinline__ void gj_row_update(double (&a)[MVO_MAXC], double f) {
+  if constexpr (K < MVO_MAXC) {
+    a[K] -= f * row_bcast<J>(a[K]);
+    gj_row_update<J, K + 1>(a, f);
+  }
+}
+
+// Gauss-Jordan elimination without pivoting (the matrix is SPD): after column J every other row
+// has a zero in that column.  Pivots <= 0 (or non-finite) flag the solve as failed.
+template <int J>
+__device__ __forceinline__ void gj_eliminate(double (&a)[MVO_MAXC], double& rhs, double& mydiag, bool& ok,
+                                             int lane) {
+  if constexpr (J < MVO_MAXC) {
+    const double piv = bcast_lane(a[J], J);
+    if (!(piv > 0.0) || isinf(piv)) ok = false;
+    const double f = (lane == J) ? 0.0 : a[J] * fast_rcp(piv);
+    if (lane == J) mydiag = piv;
+    gj_row_update<J, J + 1>(a, f);
+    rhs -= f * row_bcast<J>(rhs);
+    gj_eliminate<J + 1>(a, rhs, mydiag, ok, lane);
+  }
+}
+
 // Wave-0 control logic: Ceres 1.14 TrustRegionMinimizer::Minimize restated around the evaluation
 // that was just completed at z (= x0 in PH_EVAL_X0, the candidate in PH_EVAL_CAND); the system
 // assembled at z is in sh.Hz / sh.gz / sh.cost_z.  Every lane executes it; scalars are uniform.
 // Returns 1 when a new candidate awaits evaluation (published in sh.zvec/zt), 0 when done.
-__device__ int lm_advance(LmRegs& r, LmShared& sh, const SolveParams& prm, int M, int n, int lane,
-                          TraceRec* __restrict__ trace) {
+template <class SH>
+__device__ int lm_advance_body(LmRegs& r, SH& sh, const SolveParams& prm, int M, int n, int lane,
+                               TraceRec* __restrict__ trace, int& hsel) {
+  LmState& st = sh.st;
   const int fix = prm.fix_length;
+  // accepted system: hsel ? sh.Hz : st.H
+  const double* __restrict__ Hnew = hsel ? st.H : sh.Hz;  // the system just assembled at z
+#ifdef MVO_LM_STAMPS
+  const bool stamp_on = trace != nullptr || true;
+  unsigned long long astamp_prev_ = __builtin_amdgcn_s_memtime();
+#endif
   TraceRec it;
   it.cost = it.cost_change = it.gradient_max_norm = it.step_norm = it.relative_decrease = 0.0;
   it.trust_region_radius = 0.0;
@@ -249,10 +391,9 @@ __device__ int lm_advance(LmRegs& r, LmShared& sh, const SolveParams& prm, int M
     }
     const int l = lane < n ? lane : 0;
     const int fl = fcol(l, fix);
-#pragma unroll
-    for (int j = 0; j < MVO_MAXC; ++j) r.hrow[j] = (lane < n && j < n) ? sh.Hz[fl * MVO_MAXC + fcol(j, fix)] : 0.0;
+    hsel ^= 1;  // the buffers swap roles: no copy of the 15 x 15 system
     r.g = lane < n ? sh.gz[fl] : 0.0;
-    r.hdiag = lane < n ? sh.Hz[fl * MVO_MAXC + fl] : 0.0;
+    r.hdiag = lane < n ? Hnew[fl * MVO_MAXC + fl] : 0.0;
     if (first) {
       r.js = 1.0 / (1.0 + sqrt(r.hdiag));  // jacobi_scaling, fixed at iteration 0
       r.initial_cost = r.final_cost = r.x_cost;
@@ -270,6 +411,7 @@ __device__ int lm_advance(LmRegs& r, LmShared& sh, const SolveParams& prm, int M
     it.gradient_max_norm = r.gmn;
   }
 
+  MVO_ASTAMP(8);
   for (;;) {
     // ---- FinalizeIterationAndCheckIfMinimizerCanContinue ----
     if (it.step_is_successful) {
@@ -299,6 +441,7 @@ __device__ int lm_advance(LmRegs& r, LmShared& sh, const SolveParams& prm, int M
       return 0;
     }
 
+    MVO_ASTAMP(9);
     // ---- next iteration: ComputeTrustRegionStep ----
     ++r.iteration;
     it.cost = it.cost_change = it.gradient_max_norm = it.step_norm = it.relative_decrease = 0.0;
@@ -309,40 +452,34 @@ __device__ int lm_advance(LmRegs& r, LmShared& sh, const SolveParams& prm, int M
     // (Js^T Js + D^2) y = Js^T r with Js = J diag(jscale), D^2 = diag / radius; step = -y.
     // Ceres solves the equivalent least-squares problem by dense QR; here the reduced system is
     // eliminated in registers, one row per lane (Gauss-Jordan, no pivoting: the matrix is SPD).
-    double as[MVO_MAXC], a[MVO_MAXC];
+    double a[MVO_MAXC];
+    {
+      const double* __restrict__ Hacc = hsel ? sh.Hz : st.H;
+      const int fl = fcol(lane < n ? lane : 0, fix);
+      double hrow[MVO_MAXC];
 #pragma unroll
-    for (int j = 0; j < MVO_MAXC; ++j) {
-      const double jsj = bcast_lane(r.js, j);
-      as[j] = (lane < n) ? r.js * r.hrow[j] * jsj : 0.0;  // lanes >= n carry no row
-      a[j] = as[j];
-      if (j == lane) a[j] = (lane < n) ? as[j] + r.dg / r.radius : 1.0;  // pad rows: identity
+      for (int j = 0; j < MVO_MAXC; ++j) hrow[j] = Hacc[fl * MVO_MAXC + (fix ? 3 * (j >> 1) + (j & 1) : j)];  // loads first
+      gj_setup<0>(a, hrow, r.js, lane, n);
     }
+    const double dd = r.dg / r.radius;
+    if (lane < MVO_MAXC) a_diag_fix(a, lane, (lane < n), dd);
     const double rhs0 = (lane < n) ? r.js * r.g : 0.0;
+    MVO_ASTAMP(10);
     double rhs = rhs0, mydiag = 1.0;
     bool ok = true;
-#pragma unroll
-    for (int j = 0; j < MVO_MAXC; ++j) {
-      const double piv = bcast_lane(a[j], j);
-      if (!(piv > 0.0) || isinf(piv)) ok = false;
-      const double f = (lane == j) ? 0.0 : a[j] / piv;
-      if (lane == j) mydiag = piv;
-#pragma unroll
-      for (int k = j + 1; k < MVO_MAXC; ++k) a[k] -= f * bcast_lane(a[k], j);
-      rhs -= f * bcast_lane(rhs, j);
-    }
-    double step = -(rhs / mydiag);
+    gj_eliminate<0>(a, rhs, mydiag, ok, lane);
+    MVO_ASTAMP(11);
+    double step = -(rhs * fast_rcp(mydiag));
     if (lane >= n) step = 0.0;
     if (__any(!isfinite(step))) ok = false;
     double mcc = 0.0;
     if (ok) {
-      // model_cost_change = -(Js step)^T (r + Js step/2) = -step^T Js^T r - step^T Js^T Js step / 2
-      double row = 0.0;
-#pragma unroll
-      for (int j = 0; j < MVO_MAXC; ++j) row += as[j] * bcast_lane(step, j);
-      const double lin = wave_sum(step * rhs0);
-      const double quad = wave_sum(step * row);
-      mcc = -(lin + 0.5 * quad);
+      // model_cost_change = -(Js step)^T (r + Js step / 2) = -step^T b - step^T As step / 2 with
+      // b = Js^T r, As = Js^T Js.  The step solves (As + D^2) step = -b, so As step = -b - D^2 step
+      // and the change is (-step^T b + step^T D^2 step) / 2 -- no second pass over the matrix.
+      mcc = 0.5 * row0_sum(step * (dd * step - rhs0));
     }
+    MVO_ASTAMP(12);
     r.mcc = mcc;
     const bool valid = ok && mcc > 0.0;
     if (!valid) {
@@ -360,26 +497,110 @@ __device__ int lm_advance(LmRegs& r, LmShared& sh, const SolveParams& prm, int M
     r.num_invalid = 0;
     // ---- ComputeCandidatePoint: delta = step o jscale; candidate = Plus(x, delta) ----
     frames_plus(lane, M, fix, r.xv, r.xt, step * r.js, 1.0, r.cv, r.ct);
-    if (lane < M) {
-      sh.zvec[lane][0] = r.cv[0];
-      sh.zvec[lane][1] = r.cv[1];
-      sh.zvec[lane][2] = r.cv[2];
-      sh.zt[lane] = r.ct;
-    }
+    MVO_ASTAMP(13);
+    lm_publish_point(sh, prm, M, lane, r.cv, r.ct);
+    MVO_ASTAMP(14);
     r.phase = PH_EVAL_CAND;
     return 1;
   }
 }
 
+// (a, b) of pair p in the reference's loop order (inverse of pair_index)
+__device__ __forceinline__ void pair_ab(int N, int M, int p, int& a, int& b) {
+  a = 0;
+#pragma unroll
+  for (int k = 1; k < MVO_MAXM; ++k)
+    if (k < M && p >= pair_index(N, k, k)) a = k;
+  b = a + (p - pair_index(N, a, a));
+}
+
+struct PairIn {
+  double S[7];
+  double off[3];
+  int a, b;
+};
+
+// per-pair inputs: moments (sum of the pair's slots) and the fixed-frame offset n_b v_b (b >= M)
+__device__ __forceinline__ void pair_load(PairIn& in, int p, int N, int M, bool unit_slots,
+                                          const PairDev* __restrict__ wp, const double* __restrict__ partial,
+                                          uint32_t pair_off, const double* __restrict__ fr) {
+  if (unit_slots) {
+    pair_ab(N, M, p, in.a, in.b);
+    const double* __restrict__ ps = partial + (size_t)(pair_off + p) * 8;
+#pragma unroll
+    for (int v = 0; v < 7; ++v) in.S[v] = ps[v];
+  } else {
+    const PairDev pd = wp[p];
+    in.a = (int)pd.a;
+    in.b = (int)pd.b;
+#pragma unroll
+    for (int v = 0; v < 7; ++v) in.S[v] = 0.0;
+    for (uint32_t sl = pd.slot_begin; sl < pd.slot_end; ++sl) {
+      const double* __restrict__ ps = partial + (size_t)sl * 8;
+#pragma unroll
+      for (int v = 0; v < 7; ++v) in.S[v] += ps[v];
+    }
+  }
+  in.off[0] = in.off[1] = in.off[2] = 0.0;
+  if (in.b >= M) {  // IR.cpp:137-144: only frame b itself
+    const double* __restrict__ f = fr + MVO_FRAME_DOUBLES * in.b;
+    const double nb = f[12];
+    in.off[0] = nb * f[9];
+    in.off[1] = nb * f[10];
+    in.off[2] = nb * f[11];
+  }
+}
+
+// projected moments of one pair at the published point: T = P S P, q = P S u, cost
+template <class SH>
+__device__ __forceinline__ void pair_eval(const PairIn& in, const SH& sh, int M, int pass_mode,
+                                          double* __restrict__ o) {
+  const int kmax = in.b < M - 1 ? in.b : M - 1;
+  double bx = 0.0, by = 0.0, bz = 0.0;
+  for (int k = in.a; k <= kmax; ++k) {  // IR.cpp:466-577: s_a v_a + ... left to right
+    const double tx = sh.zs[k] * sh.zvec[k][0], ty = sh.zs[k] * sh.zvec[k][1], tz = sh.zs[k] * sh.zvec[k][2];
+    if (k == in.a) { bx = tx; by = ty; bz = tz; } else { bx += tx; by += ty; bz += tz; }
+  }
+  bx += in.off[0];
+  by += in.off[1];
+  bz += in.off[2];
+  const double nb = sqrt(bx * bx + by * by + bz * bz);
+  const double inb = 1.0 / nb, inb2 = inb * inb;
+  const double u0 = bx * inb, u1 = by * inb, u2 = bz * inb;
+  const double* S = in.S;
+  const double Su0 = S[0] * u0 + S[1] * u1 + S[2] * u2;
+  const double Su1 = S[1] * u0 + S[3] * u1 + S[4] * u2;
+  const double Su2 = S[2] * u0 + S[4] * u1 + S[5] * u2;
+  const double uSu = u0 * Su0 + u1 * Su1 + u2 * Su2;
+  o[0] = (S[0] - 2.0 * u0 * Su0 + u0 * u0 * uSu) * inb2;
+  o[1] = (S[1] - u0 * Su1 - Su0 * u1 + u0 * u1 * uSu) * inb2;
+  o[2] = (S[2] - u0 * Su2 - Su0 * u2 + u0 * u2 * uSu) * inb2;
+  o[3] = (S[3] - 2.0 * u1 * Su1 + u1 * u1 * uSu) * inb2;
+  o[4] = (S[4] - u1 * Su2 - Su1 * u2 + u1 * u2 * uSu) * inb2;
+  o[5] = (S[5] - 2.0 * u2 * Su2 + u2 * u2 * uSu) * inb2;
+  o[6] = (Su0 - u0 * uSu) * inb;
+  o[7] = (Su1 - u1 * uSu) * inb;
+  o[8] = (Su2 - u2 * uSu) * inb;
+  o[9] = pass_mode ? 0.5 * S[6] : 0.5 * uSu;  // 1/2 sum rho from the pass, or the moment form
+}
+
+// symmetric 3x3 stored as (xx,xy,xz,yy,yz,zz)
+__device__ __forceinline__ int sym6(int r, int c) {
+  const int lo = r < c ? r : c, hi = r < c ? c : r;
+  return lo == 0 ? hi : (lo == 1 ? 2 + hi : 5);
+}
+
 template <int NT>
-__global__ __launch_bounds__(NT) void k_lm(SolveParams prm, const WinDev* __restrict__ wins,
+__global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, const WinDev* __restrict__ wins,
                                            const double* __restrict__ frames, const double* __restrict__ init_x,
                                            const PairDev* __restrict__ pairs, const double* __restrict__ partial,
                                            LmState* __restrict__ states, LmResult* __restrict__ results,
                                            double* __restrict__ pair_u, int32_t* __restrict__ win_status,
                                            TraceRec* __restrict__ trace, int32_t* __restrict__ done_count) {
-  extern __shared__ double pairbuf[];  // P x 10: T(6) q(3) cost(1)
-  __shared__ LmShared sh;
+  constexpr int ROUNDS = NT >= 256 ? 4 : 1;  // pairs prefetched per thread (P <= 64 when NT == 64)
+  constexpr int PARTS = NT >= 256 ? 8 : 1;   // strided parts of a long class sum
+  extern __shared__ double pairbuf[];        // P x 10: T(6) q(3) cost(1)
+  __shared__ LmSharedT<PARTS> sh;
   const int w = blockIdx.x, tid = threadIdx.x;
   const int lane = tid & 63;
   const bool wave0 = tid < 64;
@@ -392,175 +613,209 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, const WinDev* __rest
   const double* __restrict__ fr = frames + (size_t)MVO_FRAME_DOUBLES * win.frame_off;
   const PairDev* __restrict__ wp = pairs + win.pair_off;
 
-  LmRegs r;
+  // solver state HBM -> LDS (all threads), then the point to evaluate is published by wave 0
+  for (int i = tid; i < (int)(sizeof(LmState) / 8); i += NT)
+    reinterpret_cast<double*>(&sh.st)[i] = reinterpret_cast<const double*>(gst)[i];
+  __syncthreads();
   if (wave0) {
-    regs_load(r, gst, lane);
-    if (r.phase == PH_START) {
+    LmState& st = sh.st;
+    const int k = lane < M ? lane : 0;
+    if (st.phase == PH_START && lane < M) {
       // IR.cpp:95-109: vec_k from the frame, t_k = reverseScale(scale_k) (host libm, uploaded)
-      const int k = lane < M ? lane : 0;
-      r.xv[0] = init_x[((size_t)w * MVO_MAXM + k) * 4 + 0];
-      r.xv[1] = init_x[((size_t)w * MVO_MAXM + k) * 4 + 1];
-      r.xv[2] = init_x[((size_t)w * MVO_MAXM + k) * 4 + 2];
-      r.xt = init_x[((size_t)w * MVO_MAXM + k) * 4 + 3];
+      st.x_vec[k][0] = init_x[((size_t)w * MVO_MAXM + k) * 4 + 0];
+      st.x_vec[k][1] = init_x[((size_t)w * MVO_MAXM + k) * 4 + 1];
+      st.x_vec[k][2] = init_x[((size_t)w * MVO_MAXM + k) * 4 + 2];
+      st.x_t[k] = init_x[((size_t)w * MVO_MAXM + k) * 4 + 3];
     }
-    const bool at_x = (r.phase != PH_EVAL_CAND);
-    if (lane < M) {
-      sh.zvec[lane][0] = at_x ? r.xv[0] : r.cv[0];
-      sh.zvec[lane][1] = at_x ? r.xv[1] : r.cv[1];
-      sh.zvec[lane][2] = at_x ? r.xv[2] : r.cv[2];
-      sh.zt[lane] = at_x ? r.xt : r.ct;
+    if (st.phase != PH_EVAL_CAND) lm_publish_point(sh, prm, M, lane, st.x_vec[k], st.x_t[k]);
+    else lm_publish_point(sh, prm, M, lane, st.c_vec[k], st.c_t[k]);
+    if (lane == 0) {
+      sh.phase = st.phase;
+      sh.hsel = 0;  // between launches the accepted system lives in st.H
     }
-    if (lane == 0) sh.phase = r.phase;
   }
   __syncthreads();
 
+#ifdef MVO_LM_STAMPS
+  unsigned long long stamp_prev_ = 0;
+#endif
   bool need_pass = false;
   if (sh.phase == PH_START) {
-    if (wave0) r.phase = PH_EVAL_X0;
+    if (tid == 0) sh.st.phase = PH_EVAL_X0;
     need_pass = prm.pass_mode != 0;
+    __syncthreads();
   }
 
   while (!need_pass) {
+    MVO_STAMP(0);
     // ---------------- evaluation at z: assemble J^T J, J^T r, cost ----------------
-    if (tid < M) {
-      const int k = tid;
-      const double s = d_scale(sh.zt[k], prm.max_len, prm.min_len);
-      const double sp = d_dscale(sh.zt[k], prm.max_len, prm.min_len);
-      sh.zs[k] = s;
-      sh.zsp[k] = sp;
-      const double vx = sh.zvec[k][0], vy = sh.zvec[k][1], vz = sh.zvec[k][2];
-      // J_loc(v) = [[-2vy, 2vz], [2vx, 0], [0, -2vx]]  (d Plus / d delta at 0)
-      sh.G[k][0] = s * (-2.0 * vy); sh.G[k][1] = s * (2.0 * vz);  sh.G[k][2] = sp * vx;
-      sh.G[k][3] = s * (2.0 * vx);  sh.G[k][4] = 0.0;             sh.G[k][5] = sp * vy;
-      sh.G[k][6] = 0.0;             sh.G[k][7] = s * (-2.0 * vx); sh.G[k][8] = sp * vz;
-    }
-    __syncthreads();
-    for (int p = tid; p < P; p += NT) {
-      const PairDev pd = wp[p];
-      double S[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      for (uint32_t sl = pd.slot_begin; sl < pd.slot_end; ++sl) {
-        const double* __restrict__ ps = partial + (size_t)sl * 8;
+    // (1) per frame pair: projected moments.  Loads of all rounds are issued before any use.
+    {
+      PairIn in[ROUNDS];
 #pragma unroll
-        for (int v = 0; v < 8; ++v) S[v] += ps[v];
+      for (int rr = 0; rr < ROUNDS; ++rr) {
+        const int p = tid + rr * NT;
+        if (p < P) pair_load(in[rr], p, N, M, unit_slots != 0, wp, partial, win.pair_off, fr);
       }
-      double u[3], nb;
-      pair_unit_baseline(fr, M, (int)pd.a, (int)pd.b, sh.zvec, sh.zs, u, nb);
-      const double Su0 = S[0] * u[0] + S[1] * u[1] + S[2] * u[2];
-      const double Su1 = S[1] * u[0] + S[3] * u[1] + S[4] * u[2];
-      const double Su2 = S[2] * u[0] + S[4] * u[1] + S[5] * u[2];
-      const double uSu = u[0] * Su0 + u[1] * Su1 + u[2] * Su2;
-      const double inb = 1.0 / nb, inb2 = inb * inb;
-      double* __restrict__ o = pairbuf + (size_t)p * 10;
-      // T = P S P, P = (I - u u^T)/nb
-      o[0] = (S[0] - 2.0 * u[0] * Su0 + u[0] * u[0] * uSu) * inb2;
-      o[1] = (S[1] - u[0] * Su1 - Su0 * u[1] + u[0] * u[1] * uSu) * inb2;
-      o[2] = (S[2] - u[0] * Su2 - Su0 * u[2] + u[0] * u[2] * uSu) * inb2;
-      o[3] = (S[3] - 2.0 * u[1] * Su1 + u[1] * u[1] * uSu) * inb2;
-      o[4] = (S[4] - u[1] * Su2 - Su1 * u[2] + u[1] * u[2] * uSu) * inb2;
-      o[5] = (S[5] - 2.0 * u[2] * Su2 + u[2] * u[2] * uSu) * inb2;
-      // q = P S u
-      o[6] = (Su0 - u[0] * uSu) * inb;
-      o[7] = (Su1 - u[1] * uSu) * inb;
-      o[8] = (Su2 - u[2] * uSu) * inb;
-      // cost: moment form 1/2 u^T S u, or 1/2 sum rho from the pass
-      o[9] = prm.pass_mode ? 0.5 * S[6] : 0.5 * uSu;
+#pragma unroll
+      for (int rr = 0; rr < ROUNDS; ++rr) {
+        const int p = tid + rr * NT;
+        if (p < P) pair_eval(in[rr], sh, M, prm.pass_mode, pairbuf + (size_t)p * 10);
+      }
+      for (int p = tid + ROUNDS * NT; p < P; p += NT) {
+        PairIn x;
+        pair_load(x, p, N, M, unit_slots != 0, wp, partial, win.pair_off, fr);
+        pair_eval(x, sh, M, prm.pass_mode, pairbuf + (size_t)p * 10);
+      }
     }
     __syncthreads();
-    // Class sums in pair order.  Class (a, j), j = min(b, M): j < M is the single pair b = j,
-    // j = M collects the pairs b = M .. N-2 (those with a fixed-frame offset).  The free frames
-    // of a class are a .. min(j, M-1).
-    const int MC = M + 1;
-    for (int item = tid; item < M * MC * 10; item += NT) {
-      const int a = item / (MC * 10), j = (item / 10) % MC, v = item % 10;
-      double acc = 0.0;
+    MVO_STAMP(1);
+    // (2) class sums in pair order.  Class (a, j), j = min(b, M): j < M is the single pair b = j,
+    // j = M collects the pairs b = M .. N-2 (those with a fixed-frame offset), summed in PARTS
+    // strided parts.  The free frames of a class are a .. min(j, M-1).
+    constexpr int MCX = MVO_MAXM + 1;  // fixed table stride: index arithmetic with constant divisors
+    for (int item = tid; item < MVO_MAXM * MCX * PARTS; item += NT) {
+      const int part = item % PARTS, c = item / PARTS, a = c / MCX, j = c % MCX;
+      if (a >= M || j > M) continue;
+      double acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
       if (j >= a) {
         const int b0 = j, b1 = (j == M) ? N - 2 : j;
         if (b0 <= N - 2) {
-          const int p0 = pair_index(N, a, b0);
-          for (int b = b0; b <= b1; ++b) acc += pairbuf[(size_t)(p0 + (b - b0)) * 10 + v];
+          const double2* __restrict__ src = reinterpret_cast<const double2*>(pairbuf + (size_t)pair_index(N, a, b0) * 10);
+          for (int b = b0 + part; b <= b1; b += PARTS) {
+            const double2* __restrict__ q = src + (b - b0) * 5;
+#pragma unroll
+            for (int v = 0; v < 5; ++v) {
+              const double2 t = q[v];
+              acc[2 * v] += t.x;
+              acc[2 * v + 1] += t.y;
+            }
+          }
         }
       }
-      sh.cls[a * MC + j][v] = acc;
+#pragma unroll
+      for (int v = 0; v < 10; ++v) {
+        if (PARTS == 1) sh.cls[c][v] = acc[v];
+        else sh.clsp[c * 10 + v][part] = acc[v];
+      }
     }
     __syncthreads();
-    for (int item = tid; item < M * M + M + 1; item += NT) {
-      if (item < M * M) {
-        const int k = item / M, l = item % M;
-        if (l >= k) {
-          // W = sum of T over the pairs whose free frames contain k and l: a <= k, min(j,M-1) >= l.
-          // The pair (k,k) is kept apart: its baseline is s_k v_k alone, so r does not depend on
-          // t_k at all (IR.cpp:466-471 normalises the scale away) and its scale row/column is
-          // exactly zero instead of rounding noise of the size of S.
-          double W[6] = {0, 0, 0, 0, 0, 0};
-          for (int a = 0; a <= k; ++a)
-            for (int j = l; j <= M; ++j) {
-              if (k == l && a == k && j == k) continue;
-              for (int v = 0; v < 6; ++v) W[v] += sh.cls[a * MC + j][v];
+    if (PARTS > 1) {
+      for (int cv = tid; cv < MVO_MAXM * MCX * 10; cv += NT) {
+        double acc = 0.0;
+#pragma unroll
+        for (int part = 0; part < PARTS; ++part) acc += sh.clsp[cv][part];
+        sh.cls[cv / 10][cv % 10] = acc;
+      }
+      __syncthreads();
+    }
+    MVO_STAMP(2);
+    // (3) W_kl = sum of T over the pairs whose free frames contain k and l (a <= k, j >= l),
+    // y_k = sum of q over those containing k.  The pair (k,k) is kept apart: its baseline is
+    // s_k v_k alone, so r does not depend on t_k at all (IR.cpp:466-471 normalises the scale
+    // away) and its scale row/column is exactly zero instead of rounding noise of the size of S.
+    for (int item = tid; item < MVO_MAXM * MVO_MAXM * 6 + MVO_MAXM * 3 + 1; item += NT) {
+      if (item < MVO_MAXM * MVO_MAXM * 6) {
+        const int kl = item / 6, v = item % 6, k = kl / MVO_MAXM, l = kl % MVO_MAXM;
+        if (l >= k && l < M) {
+          double acc = 0.0;
+#pragma unroll
+          for (int a = 0; a < MVO_MAXM; ++a)
+#pragma unroll
+            for (int j = 0; j < MCX; ++j) {
+              const bool in = a <= k && j >= l && j <= M && !(k == l && a == k && j == k);
+              acc = fma(sh.cls[a * MCX + j][v], in ? 1.0 : 0.0, acc);  // 30 reads issue back to back
             }
-          double blk[9];
-          {
-            const double Wm[9] = {W[0], W[1], W[2], W[1], W[3], W[4], W[2], W[4], W[5]};
-            double WG[9];
-            for (int rr = 0; rr < 3; ++rr)
-              for (int c = 0; c < 3; ++c)
-                WG[3 * rr + c] = Wm[3 * rr] * sh.G[l][c] + Wm[3 * rr + 1] * sh.G[l][3 + c] + Wm[3 * rr + 2] * sh.G[l][6 + c];
-            for (int i = 0; i < 3; ++i)
-              for (int jj = 0; jj < 3; ++jj)
-                blk[3 * i + jj] = sh.G[k][i] * WG[jj] + sh.G[k][3 + i] * WG[3 + jj] + sh.G[k][6 + i] * WG[6 + jj];
-          }
-          if (k == l) {
-            const double* Ts = sh.cls[k * MC + k];
-            const double Wm[9] = {Ts[0], Ts[1], Ts[2], Ts[1], Ts[3], Ts[4], Ts[2], Ts[4], Ts[5]};
-            double WG[9];
-            for (int rr = 0; rr < 3; ++rr)
-              for (int c = 0; c < 3; ++c)
-                WG[3 * rr + c] = Wm[3 * rr] * sh.G[k][c] + Wm[3 * rr + 1] * sh.G[k][3 + c] + Wm[3 * rr + 2] * sh.G[k][6 + c];
-            for (int i = 0; i < 2; ++i)
-              for (int jj = 0; jj < 2; ++jj)
-                blk[3 * i + jj] += sh.G[k][i] * WG[jj] + sh.G[k][3 + i] * WG[3 + jj] + sh.G[k][6 + i] * WG[6 + jj];
-          }
-          for (int i = 0; i < 3; ++i)
-            for (int jj = 0; jj < 3; ++jj) {
-              sh.Hz[(3 * k + i) * MVO_MAXC + 3 * l + jj] = blk[3 * i + jj];
-              sh.Hz[(3 * l + jj) * MVO_MAXC + 3 * k + i] = blk[3 * i + jj];
-            }
+          sh.W[kl][v] = acc;
         }
-      } else if (item < M * M + M) {
-        const int k = item - M * M;
-        double y[3] = {0, 0, 0};
-        for (int a = 0; a <= k; ++a)
-          for (int j = k; j <= M; ++j) {
-            if (a == k && j == k) continue;
-            for (int v = 0; v < 3; ++v) y[v] += sh.cls[a * MC + j][6 + v];
-          }
-        const double* qs = &sh.cls[k * MC + k][6];
-        for (int i = 0; i < 3; ++i) {
-          double gi = sh.G[k][i] * y[0] + sh.G[k][3 + i] * y[1] + sh.G[k][6 + i] * y[2];
-          if (i < 2) gi += sh.G[k][i] * qs[0] + sh.G[k][3 + i] * qs[1] + sh.G[k][6 + i] * qs[2];
-          sh.gz[3 * k + i] = gi;
+      } else if (item < MVO_MAXM * MVO_MAXM * 6 + MVO_MAXM * 3) {
+        const int k = (item - MVO_MAXM * MVO_MAXM * 6) / 3, v = (item - MVO_MAXM * MVO_MAXM * 6) % 3;
+        if (k < M) {
+          double acc = 0.0;
+#pragma unroll
+          for (int a = 0; a < MVO_MAXM; ++a)
+#pragma unroll
+            for (int j = 0; j < MCX; ++j) {
+              const bool in = a <= k && j >= k && j <= M && !(a == k && j == k);
+              acc = fma(sh.cls[a * MCX + j][6 + v], in ? 1.0 : 0.0, acc);
+            }
+          sh.y[k][v] = acc;
         }
       } else {
         double c = 0.0;
-        for (int a = 0; a < M; ++a)
-          for (int j = a; j <= M; ++j) c += sh.cls[a * MC + j][9];
+#pragma unroll
+        for (int a = 0; a < MVO_MAXM; ++a)
+#pragma unroll
+          for (int j = 0; j < MCX; ++j) {
+            const bool in = a < M && j >= a && j <= M;
+            c = fma(sh.cls[a * MCX + j][9], in ? 1.0 : 0.0, c);
+          }
         sh.cost_z = c;
       }
     }
     __syncthreads();
-    // ---------------- wavefront 0: accept/reject, damping, next candidate ----------------
-    if (wave0) {
-      const int go = lm_advance(r, sh, prm, M, n, lane, (w == 0) ? trace : nullptr);
-      if (lane == 0) sh.go = go;
+    MVO_STAMP(3);
+    // (4) 3x3 blocks G_k^T W_kl G_l (one entry per thread) and gradient entries G_k^T y_k
+    for (int item = tid; item < MVO_MAXM * MVO_MAXM * 9 + MVO_MAXM * 3; item += NT) {
+      if (item < MVO_MAXM * MVO_MAXM * 9) {
+        const int kl = item / 9, i = (item % 9) / 3, jj = item % 3, k = kl / MVO_MAXM, l = kl % MVO_MAXM;
+        if (l >= k && l < M) {
+          double val = 0.0;
+#pragma unroll
+          for (int rr = 0; rr < 3; ++rr) {
+            double wg = 0.0;  // (W G_l)[rr][jj]
+#pragma unroll
+            for (int m = 0; m < 3; ++m) wg += sh.W[kl][sym6(rr, m)] * sh.G[l][3 * m + jj];
+            val += sh.G[k][3 * rr + i] * wg;
+          }
+          if (k == l && i < 2 && jj < 2) {
+            const double* Ts = sh.cls[k * MCX + k];
+#pragma unroll
+            for (int rr = 0; rr < 3; ++rr) {
+              double wg = 0.0;
+#pragma unroll
+              for (int m = 0; m < 3; ++m) wg += Ts[sym6(rr, m)] * sh.G[k][3 * m + jj];
+              val += sh.G[k][3 * rr + i] * wg;
+            }
+          }
+          double* __restrict__ Hw = sh.hsel ? sh.st.H : sh.Hz;
+          Hw[(3 * k + i) * MVO_MAXC + 3 * l + jj] = val;
+          Hw[(3 * l + jj) * MVO_MAXC + 3 * k + i] = val;
+        }
+      } else {
+        const int k = (item - MVO_MAXM * MVO_MAXM * 9) / 3, i = (item - MVO_MAXM * MVO_MAXM * 9) % 3;
+        if (k < M) {
+          double gi = sh.G[k][i] * sh.y[k][0] + sh.G[k][3 + i] * sh.y[k][1] + sh.G[k][6 + i] * sh.y[k][2];
+          if (i < 2) {
+            const double* qs = &sh.cls[k * MCX + k][6];
+            gi += sh.G[k][i] * qs[0] + sh.G[k][3 + i] * qs[1] + sh.G[k][6 + i] * qs[2];
+          }
+          sh.gz[3 * k + i] = gi;
+        }
+      }
     }
     __syncthreads();
+    MVO_STAMP(4);
+    // ---------------- wavefront 0: accept/reject, damping, next candidate ----------------
+    if (wave0) {
+      LmRegs r;
+      regs_load(r, sh.st, sh.hsel ? sh.Hz : sh.st.H, fix, n, lane);
+      int hsel = sh.hsel;
+      const int go = lm_advance_body(r, sh, prm, M, n, lane, (w == 0) ? trace : nullptr, hsel);
+      regs_store(r, sh.st, lane);
+      if (lane == 0) {
+        sh.go = go;
+        sh.hsel = hsel;
+      }
+    }
+    __syncthreads();
+    MVO_STAMP(5);
     if (!sh.go) break;
     if (prm.pass_mode) need_pass = true;
   }
 
   if (need_pass) {
     // publish the unit baselines of the point to evaluate; k_pass runs next on the stream
-    if (tid < M) sh.zs[tid] = d_scale(sh.zt[tid], prm.max_len, prm.min_len);
-    __syncthreads();
     for (int p = tid; p < P; p += NT) {
       const PairDev pd = wp[p];
       double u[3], nb;
@@ -572,28 +827,33 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, const WinDev* __rest
       o[3] = nb;
     }
   }
-  if (wave0) {
-    regs_store(r, gst, lane);
-    if (r.status != 0) {
-      LmResult* __restrict__ res = results + w;
-      if (lane < MVO_MAXM) {
-        res->vec[lane][0] = r.bv[0];
-        res->vec[lane][1] = r.bv[1];
-        res->vec[lane][2] = r.bv[2];
-        res->t[lane] = r.bt;
-      }
-      if (lane == 0) {
-        res->initial_cost = r.initial_cost;
-        res->final_cost = r.final_cost;
-        res->termination = r.termination;
-        res->reason = r.reason;
-        res->iterations = r.ntrace - 1;
-        res->nsucc = r.nsucc;
-        res->nunsucc = r.nunsucc;
-        res->pad = 0;
-        win_status[w] = 1;
-        atomicAdd(done_count, 1);
-      }
+  __syncthreads();
+  if (sh.hsel) {  // bring the accepted system home before the state leaves LDS
+    for (int i = tid; i < MVO_MAXC * MVO_MAXC; i += NT) sh.st.H[i] = sh.Hz[i];
+    __syncthreads();
+  }
+  for (int i = tid; i < (int)(sizeof(LmState) / 8); i += NT)
+    reinterpret_cast<double*>(gst)[i] = reinterpret_cast<const double*>(&sh.st)[i];
+  if (wave0 && sh.st.status != 0) {
+    const LmState& st = sh.st;
+    LmResult* __restrict__ res = results + w;
+    if (lane < MVO_MAXM) {
+      res->vec[lane][0] = st.b_vec[lane][0];
+      res->vec[lane][1] = st.b_vec[lane][1];
+      res->vec[lane][2] = st.b_vec[lane][2];
+      res->t[lane] = st.b_t[lane];
+    }
+    if (lane == 0) {
+      res->initial_cost = st.initial_cost;
+      res->final_cost = st.final_cost;
+      res->termination = st.termination;
+      res->reason = st.reason;
+      res->iterations = st.ntrace - 1;
+      res->nsucc = st.nsucc;
+      res->nunsucc = st.nunsucc;
+      res->pad = 0;
+      win_status[w] = 1;
+      atomicAdd(done_count, 1);
     }
   }
 }

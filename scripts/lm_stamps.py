@@ -1,0 +1,22 @@
+"""Diagnostic: where an LM iteration spends its cycles (needs libmvo_hip_stamps.so, built with
+`make -C monocular-visual-odometry_amd libmvo_hip_stamps.so`).  Shares, not absolute times."""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "monocular-visual-odometry_amd"))
+from mvo_amd import capi, scene
+capi.LIB_PATH = os.path.join(ROOT, "monocular-visual-odometry_amd", "libmvo_hip_stamps.so")
+lib = capi.load()
+lib.mvo_hip_debug_stamps.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+names = ["iterations", "per-pair", "class sums", "W/y", "blocks", "lm_advance", "-", "-", "adv:decide", "adv:finalize", "adv:setup", "adv:eliminate", "adv:mcc", "adv:plus", "adv:publish", "-"]
+fixed = dict(max_num_iterations=10, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
+for label, ws in (("config2", [scene.config2()]), ("config4", [scene.config4()]), ("config1 x 64", [scene.config3_window(i) for i in range(64)])):
+    with capi.Solver(0) as s:
+        s.upload(ws, capi.make_options(**fixed))
+        s.solve()
+        buf = (C.c_ulonglong * 16)()
+        lib.mvo_hip_debug_stamps(buf, 1)
+        s.solve()
+        lib.mvo_hip_debug_stamps(buf, 0)
+        n = max(1, buf[0])
+        print(label, "evaluations", buf[0], " cycles/eval:", {names[i]: buf[i] // n for i in range(1, 6)}, "total", sum(buf[1:6]) // n)
+        print("    inside lm_advance:", {names[i]: buf[i] // n for i in range(8, 15)})
