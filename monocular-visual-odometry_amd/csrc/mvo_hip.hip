@@ -66,7 +66,7 @@ struct mvo_hip_context {
   hipStream_t stream = nullptr;
   hipError_t last_hip_error = hipSuccess;
   // device buffers
-  DevBuf d_frames, d_initx, d_wins, d_pairs, d_tiles, d_m0, d_m1, d_c, d_partial, d_pair_u, d_states,
+  DevBuf d_frames, d_initx, d_wins, d_pairs, d_tiles, d_wave_tiles, d_m0, d_m1, d_c, d_partial, d_pair_u, d_states,
       d_results, d_status, d_done, d_trace, d_res, d_jac, d_pairsum, d_pairs_unit;
   // pinned host mirror of small results
   LmResult* h_results = nullptr;
@@ -78,7 +78,8 @@ struct mvo_hip_context {
   uint64_t n_obs = 0;      // residual blocks (all windows)
   uint64_t c_elems = 0;    // padded plane length
   uint32_t n_tiles = 0, n_slots = 0;
-  uint32_t tile_size = 0;
+  uint32_t n_waves = 0;          // wavefronts of an observation pass (one chunk each)
+  uint32_t max_block_tiles = 0;  // LDS rows a workgroup needs for its tiles' sums
   mvo_hip_options opt{};
   bool pass_mode = false;
   std::vector<mvo_hip_frame> h_frames;  // copy of the uploaded frames (write-back base)
@@ -172,26 +173,29 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
   uint64_t n_obs = 0;
   for (uint32_t w = 0; w < W; ++w) n_obs += obs[w].pair_offsets[P];
   h->n_obs = n_obs;
-  // tile size: enough wave-tiles to fill 256 CUs x 32 waves a few times over
-  uint32_t tile = 1024;
-  for (; tile > 128; tile >>= 1) {
-    uint64_t n_tiles = 0;
-    for (uint32_t w = 0; w < W; ++w)
-      for (uint32_t p = 0; p < P; ++p)
-        n_tiles += (obs[w].pair_offsets[p + 1] - obs[w].pair_offsets[p] + tile - 1) / tile;
-    if (n_tiles >= 16384) break;
-  }
-  if (const char* e = std::getenv("MVO_HIP_TILE")) {  // tuning knob for experiments
+  // One chunk of consecutive residual blocks per wavefront, all wavefronts resident at once:
+  // waves_per_cu * 256 CUs of them, but at least kMinChunk blocks each so that small problems
+  // do not pay one reduction per handful of blocks.
+  uint32_t waves_per_cu = 16;
+  if (const char* e = std::getenv("MVO_HIP_WAVES_PER_CU")) {  // tuning knob for experiments
     const int t = std::atoi(e);
-    if (t >= 64 && t <= 65536 && (t % 64) == 0) tile = (uint32_t)t;
+    if (t >= 1 && t <= 64) waves_per_cu = (uint32_t)t;
   }
-  h->tile_size = tile;
+  const uint64_t kMinChunk = 256, kMaxWaveTiles = 255;
+  uint64_t want_waves = (n_obs + kMinChunk - 1) / kMinChunk;
+  if (want_waves > 256ull * waves_per_cu) want_waves = 256ull * waves_per_cu;
+  if (want_waves == 0) want_waves = 1;
+  const uint64_t chunk = (n_obs + want_waves - 1) / want_waves > 0 ? (n_obs + want_waves - 1) / want_waves : 1;
 
   std::vector<WinDev> wins(W);
   std::vector<PairDev>& pairs = h->h_pairs;
   pairs.assign((size_t)W * P, PairDev{});
   std::vector<TileDev> tiles;
-  tiles.reserve((size_t)(n_obs / tile) + (size_t)W * P + 8);
+  tiles.reserve((size_t)want_waves + (size_t)W * P + 8);
+  std::vector<uint32_t> wave_tiles;  // first tile of every wavefront, plus the end
+  wave_tiles.reserve((size_t)want_waves + 8);
+  wave_tiles.push_back(0);
+  uint64_t wave_fill = 0;  // residual blocks already given to the current wavefront
   std::vector<double> initx((size_t)W * MVO_MAXM * 4, 0.0);
   uint64_t src = 0, cpos = 0;
   uint32_t slot = 0;
@@ -218,26 +222,43 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
         const uint64_t cnt = obs[w].pair_offsets[p + 1] - obs[w].pair_offsets[p];
         pd.slot_begin = slot;
         uint32_t cur_slot = 0;
-        for (uint64_t done = 0; done < cnt; done += tile) {
+        for (uint64_t done = 0; done < cnt;) {
+          // close the current wavefront when its chunk is full (or its tile list is)
+          if (wave_fill >= chunk || tiles.size() - wave_tiles.back() >= kMaxWaveTiles) {
+            wave_tiles.push_back((uint32_t)tiles.size());
+            wave_fill = 0;
+          }
+          const uint64_t take = (cnt - done) < (chunk - wave_fill) ? (cnt - done) : (chunk - wave_fill);
           TileDev t{};
           t.pair = w * P + p;
           t.win = w;
           t.src_start = (uint32_t)(src + done);
           t.c_start = (uint32_t)(cpos + done);
-          t.count = (uint32_t)((cnt - done) < tile ? (cnt - done) : tile);
+          t.count = (uint32_t)take;
           t.f0 = w * N + a;      // IR.cpp:172  R0 = frames[frame0].R
           t.f1 = w * N + b + 1;  // IR.cpp:171  R1 = frames[frame1 + 1].R
-          // a slot never spans workgroups: new slot at a workgroup boundary or a new pair
-          if (done == 0 || (tiles.size() % FOLD_WAVES) == 0) cur_slot = slot++;
+          // a slot never spans workgroups: new slot for a new pair or at a workgroup boundary
+          const bool block_start = tiles.size() == wave_tiles.back() && ((wave_tiles.size() - 1) % FOLD_WAVES) == 0;
+          if (done == 0 || block_start) cur_slot = slot++;
           t.slot = cur_slot;
           tiles.push_back(t);
+          done += take;
+          wave_fill += take;
         }
         pd.slot_end = slot;
         src += cnt;
         cpos += (cnt + 31) & ~31ull;  // pair segments of c start on 256-byte boundaries
       }
   }
+  if (tiles.size() > wave_tiles.back()) wave_tiles.push_back((uint32_t)tiles.size());
   h->n_tiles = (uint32_t)tiles.size();
+  h->n_waves = (uint32_t)wave_tiles.size() - 1;
+  h->max_block_tiles = 1;
+  for (uint32_t g = 0; g < h->n_waves; g += FOLD_WAVES) {
+    const uint32_t e = g + FOLD_WAVES < h->n_waves ? g + FOLD_WAVES : h->n_waves;
+    const uint32_t nt = wave_tiles[e] - wave_tiles[g];
+    if (nt > h->max_block_tiles) h->max_block_tiles = nt;
+  }
   h->n_slots = slot;
   h->c_elems = cpos + 32;
 
@@ -248,6 +269,7 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
   HIP_TRY(h->d_wins.reserve(sizeof(WinDev) * W));
   HIP_TRY(h->d_pairs.reserve(sizeof(PairDev) * pairs.size()));
   HIP_TRY(h->d_tiles.reserve(sizeof(TileDev) * (tiles.size() + 1)));
+  HIP_TRY(h->d_wave_tiles.reserve(sizeof(uint32_t) * (wave_tiles.size() + 1)));
   HIP_TRY(h->d_m0.reserve(sizeof(double) * 3 * (n_obs + 1)));
   HIP_TRY(h->d_m1.reserve(sizeof(double) * 3 * (n_obs + 1)));
   if (h->pass_mode) HIP_TRY(h->d_c.reserve(sizeof(double) * 3 * h->c_elems));
@@ -281,6 +303,8 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
   HIP_TRY(hipMemcpyAsync(h->d_pairs_unit.p, unit.data(), sizeof(PairDev) * unit.size(), hipMemcpyHostToDevice, s));
   if (!tiles.empty())
     HIP_TRY(hipMemcpyAsync(h->d_tiles.p, tiles.data(), sizeof(TileDev) * tiles.size(), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(h->d_wave_tiles.p, wave_tiles.data(), sizeof(uint32_t) * wave_tiles.size(),
+                         hipMemcpyHostToDevice, s));
   uint64_t pos = 0;
   for (uint32_t w = 0; w < W; ++w) {
     const uint64_t cnt = obs[w].pair_offsets[P];
@@ -297,6 +321,43 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
   h->timing.upload_seconds =
       std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
   return MVO_HIP_OK;
+}
+
+uint32_t pass_blocks(const mvo_hip_context* h) { return (h->n_waves + FOLD_WAVES - 1) / FOLD_WAVES; }
+size_t pass_lds(const mvo_hip_context* h) { return sizeof(double) * 8 * (size_t)h->max_block_tiles; }
+
+// observation pass #0: c = (R0 m0) x (R1 m1); stores c (pass mode) or sums the moments (no loss)
+hipError_t launch_fold(mvo_hip_context* h, bool write_c) {
+  const uint32_t blocks = pass_blocks(h);
+  if (!blocks) return hipSuccess;
+  if (write_c)
+    hipLaunchKernelGGL((k_fold<true, false>), dim3(blocks), dim3(FOLD_THREADS), 0, h->stream,
+                       h->d_tiles.as<TileDev>(), h->d_wave_tiles.as<uint32_t>(), h->n_waves,
+                       h->d_frames.as<double>(), h->d_m0.as<double>(), h->d_m1.as<double>(), h->d_c.as<double>(),
+                       (size_t)h->c_elems, h->d_partial.as<double>());
+  else
+    hipLaunchKernelGGL((k_fold<false, true>), dim3(blocks), dim3(FOLD_THREADS), pass_lds(h), h->stream,
+                       h->d_tiles.as<TileDev>(), h->d_wave_tiles.as<uint32_t>(), h->n_waves,
+                       h->d_frames.as<double>(), h->d_m0.as<double>(), h->d_m1.as<double>(), (double*)nullptr,
+                       (size_t)0, h->d_partial.as<double>());
+  return hipGetLastError();
+}
+
+// one evaluation pass over the folded c at the unit baselines in d_pair_u
+hipError_t launch_pass(mvo_hip_context* h) {
+  const uint32_t blocks = pass_blocks(h);
+  if (!blocks) return hipSuccess;
+  if (h->opt.use_loss_function)
+    hipLaunchKernelGGL((k_pass<true>), dim3(blocks), dim3(FOLD_THREADS), pass_lds(h), h->stream,
+                       h->d_tiles.as<TileDev>(), h->d_wave_tiles.as<uint32_t>(), h->n_waves, h->d_c.as<double>(),
+                       (size_t)h->c_elems, h->d_pair_u.as<double>(), h->d_status.as<int32_t>(),
+                       h->d_partial.as<double>());
+  else
+    hipLaunchKernelGGL((k_pass<false>), dim3(blocks), dim3(FOLD_THREADS), pass_lds(h), h->stream,
+                       h->d_tiles.as<TileDev>(), h->d_wave_tiles.as<uint32_t>(), h->n_waves, h->d_c.as<double>(),
+                       (size_t)h->c_elems, h->d_pair_u.as<double>(), h->d_status.as<int32_t>(),
+                       h->d_partial.as<double>());
+  return hipGetLastError();
 }
 
 template <int NT>
@@ -343,22 +404,11 @@ int partial_begin(mvo_hip_context* h) {
   HIP_TRY(hipMemsetAsync(h->d_status.p, 0, sizeof(int32_t) * h->W, s));
   HIP_TRY(hipMemsetAsync(h->d_done.p, 0, sizeof(int32_t) * 4, s));
   HIP_TRY(hipMemsetAsync(h->d_pairsum.p, 0, sizeof(double) * 8 * (size_t)n, s));
-  const uint32_t fold_blocks = (h->n_tiles + FOLD_WAVES - 1) / FOLD_WAVES;
   if (!h->pass_mode) {
-    if (fold_blocks) {
-      hipLaunchKernelGGL((k_fold<false, true>), dim3(fold_blocks), dim3(FOLD_THREADS), 0, s,
-                         h->d_tiles.as<TileDev>(), h->n_tiles, h->d_frames.as<double>(), h->d_m0.as<double>(),
-                         h->d_m1.as<double>(), (double*)nullptr, (size_t)0, h->d_partial.as<double>());
-      HIP_TRY(hipGetLastError());
-    }
+    HIP_TRY(launch_fold(h, false));
     HIP_TRY(launch_reduce_slots(h));
   } else {
-    if (fold_blocks) {
-      hipLaunchKernelGGL((k_fold<true, false>), dim3(fold_blocks), dim3(FOLD_THREADS), 0, s,
-                         h->d_tiles.as<TileDev>(), h->n_tiles, h->d_frames.as<double>(), h->d_m0.as<double>(),
-                         h->d_m1.as<double>(), h->d_c.as<double>(), (size_t)h->c_elems, h->d_partial.as<double>());
-      HIP_TRY(hipGetLastError());
-    }
+    HIP_TRY(launch_fold(h, true));
     HIP_TRY(launch_lm_any(h, make_params(h), true));  // PH_START: publishes u(x0)
   }
   HIP_TRY(hipStreamSynchronize(s));
@@ -369,18 +419,7 @@ int partial_pass(mvo_hip_context* h) {
   if (!h->uploaded || !h->pass_mode || !h->d_pairsum.p) return MVO_HIP_ERR_STATE;
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t s = h->stream;
-  const uint32_t fold_blocks = (h->n_tiles + FOLD_WAVES - 1) / FOLD_WAVES;
-  if (fold_blocks) {
-    if (h->opt.use_loss_function)
-      hipLaunchKernelGGL((k_pass<true>), dim3(fold_blocks), dim3(FOLD_THREADS), 0, s, h->d_tiles.as<TileDev>(),
-                         h->n_tiles, h->d_c.as<double>(), (size_t)h->c_elems, h->d_pair_u.as<double>(),
-                         h->d_status.as<int32_t>(), h->d_partial.as<double>());
-    else
-      hipLaunchKernelGGL((k_pass<false>), dim3(fold_blocks), dim3(FOLD_THREADS), 0, s, h->d_tiles.as<TileDev>(),
-                         h->n_tiles, h->d_c.as<double>(), (size_t)h->c_elems, h->d_pair_u.as<double>(),
-                         h->d_status.as<int32_t>(), h->d_partial.as<double>());
-    HIP_TRY(hipGetLastError());
-  }
+  HIP_TRY(launch_pass(h));
   HIP_TRY(launch_reduce_slots(h));
   HIP_TRY(hipStreamSynchronize(s));
   return MVO_HIP_OK;
@@ -416,7 +455,7 @@ int do_solve(mvo_hip_context* h) {
   HIP_TRY(hipMemsetAsync(h->d_status.p, 0, sizeof(int32_t) * h->W, s));
   HIP_TRY(hipMemsetAsync(h->d_done.p, 0, sizeof(int32_t) * 4, s));
 
-  const uint32_t fold_blocks = (h->n_tiles + FOLD_WAVES - 1) / FOLD_WAVES;
+  const uint32_t fold_blocks = pass_blocks(h);
   int n_timed = 0;
   auto timed_begin = [&]() -> hipError_t {
     return n_timed < kMaxTimedLaunches ? hipEventRecord(h->ev[2 + 2 * n_timed], s) : hipSuccess;
@@ -433,10 +472,7 @@ int do_solve(mvo_hip_context* h) {
     // one fold+moment pass, then the whole LM loop in a single launch
     if (fold_blocks) {
       HIP_TRY(timed_begin());
-      hipLaunchKernelGGL((k_fold<false, true>), dim3(fold_blocks), dim3(FOLD_THREADS), 0, s,
-                         h->d_tiles.as<TileDev>(), h->n_tiles, h->d_frames.as<double>(), h->d_m0.as<double>(),
-                         h->d_m1.as<double>(), (double*)nullptr, (size_t)0, h->d_partial.as<double>());
-      HIP_TRY(hipGetLastError());
+      HIP_TRY(launch_fold(h, false));
       HIP_TRY(timed_end());
       ++asm_launches;
     }
@@ -448,10 +484,7 @@ int do_solve(mvo_hip_context* h) {
   } else {
     if (fold_blocks) {
       HIP_TRY(timed_begin());
-      hipLaunchKernelGGL((k_fold<true, false>), dim3(fold_blocks), dim3(FOLD_THREADS), 0, s,
-                         h->d_tiles.as<TileDev>(), h->n_tiles, h->d_frames.as<double>(), h->d_m0.as<double>(),
-                         h->d_m1.as<double>(), h->d_c.as<double>(), (size_t)h->c_elems, h->d_partial.as<double>());
-      HIP_TRY(hipGetLastError());
+      HIP_TRY(launch_fold(h, true));
       HIP_TRY(timed_end());
       ++asm_launches;
     }
@@ -467,15 +500,7 @@ int do_solve(mvo_hip_context* h) {
       for (int i = 0; i < n; ++i) {
         if (fold_blocks) {
           HIP_TRY(timed_begin());
-          if (prm.use_loss)
-            hipLaunchKernelGGL((k_pass<true>), dim3(fold_blocks), dim3(FOLD_THREADS), 0, s,
-                               h->d_tiles.as<TileDev>(), h->n_tiles, h->d_c.as<double>(), (size_t)h->c_elems,
-                               h->d_pair_u.as<double>(), h->d_status.as<int32_t>(), h->d_partial.as<double>());
-          else
-            hipLaunchKernelGGL((k_pass<false>), dim3(fold_blocks), dim3(FOLD_THREADS), 0, s,
-                               h->d_tiles.as<TileDev>(), h->n_tiles, h->d_c.as<double>(), (size_t)h->c_elems,
-                               h->d_pair_u.as<double>(), h->d_status.as<int32_t>(), h->d_partial.as<double>());
-          HIP_TRY(hipGetLastError());
+          HIP_TRY(launch_pass(h));
           HIP_TRY(timed_end());
           ++asm_launches;
         }
@@ -589,7 +614,7 @@ void mvo_hip_destroy(mvo_hip_handle h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  DevBuf* bufs[] = {&h->d_frames, &h->d_initx, &h->d_wins, &h->d_pairs, &h->d_tiles, &h->d_m0, &h->d_m1,
+  DevBuf* bufs[] = {&h->d_frames, &h->d_initx, &h->d_wins, &h->d_pairs, &h->d_tiles, &h->d_wave_tiles, &h->d_m0, &h->d_m1,
                     &h->d_c, &h->d_partial, &h->d_pair_u, &h->d_states, &h->d_results, &h->d_status,
                     &h->d_done, &h->d_trace, &h->d_res, &h->d_jac, &h->d_pairsum, &h->d_pairs_unit};
   for (DevBuf* b : bufs) b->release();
@@ -675,13 +700,7 @@ int mvo_hip_pair_moments(mvo_hip_handle h, double* moments) {
   if (!h || !moments) return MVO_HIP_ERR_INVALID_ARGUMENT;
   if (!h->uploaded) return MVO_HIP_ERR_STATE;
   HIP_TRY(hipSetDevice(h->device));
-  const uint32_t blocks = (h->n_tiles + FOLD_WAVES - 1) / FOLD_WAVES;
-  if (blocks) {
-    hipLaunchKernelGGL((k_fold<false, true>), dim3(blocks), dim3(FOLD_THREADS), 0, h->stream,
-                       h->d_tiles.as<TileDev>(), h->n_tiles, h->d_frames.as<double>(), h->d_m0.as<double>(),
-                       h->d_m1.as<double>(), (double*)nullptr, (size_t)0, h->d_partial.as<double>());
-    HIP_TRY(hipGetLastError());
-  }
+  HIP_TRY(launch_fold(h, false));
   std::vector<double> part((size_t)h->n_slots * 8 + 8);
   if (h->n_slots)
     HIP_TRY(hipMemcpyAsync(part.data(), h->d_partial.p, sizeof(double) * 8 * h->n_slots, hipMemcpyDeviceToHost,

@@ -19,107 +19,140 @@
 #define FOLD_WAVES 4
 
 // ---------------------------------------------------------------------------------------
-// workgroup epilogue shared by k_fold / k_pass: red[w][8] holds each wave's tile sums; the
-// waves of a workgroup whose tiles share a slot are summed in wave order and stored once.
+// 8 values x 64 lanes -> 8 totals with 7 + 3 exchange steps instead of 8 x 6: every halving step
+// trades half of the values with the partner lane (xor 32, 16 through the LDS crossbar; xor 8 and
+// the in-group steps through DPP).  On return lane L holds the total of value
+// ((L>>5)&1)*4 + ((L>>4)&1)*2 + ((L>>3)&1), identical in the 8 lanes of its group.
+// Fixed pairing order => bitwise reproducible.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void block_store_partials(const TileDev* __restrict__ tiles, uint32_t n_tiles,
-                                                     double (*red)[8], double* __restrict__ partial) {
-  __syncthreads();
-  const int v = threadIdx.x;
-  if (v < 8) {
-    double acc = 0.0;
-    const uint32_t t0 = blockIdx.x * FOLD_WAVES;
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_reduce8(const double (&v)[8], int lane) {
+  const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8;
+  double w4[4], w2[2], w1;
 #pragma unroll
-    for (int w = 0; w < FOLD_WAVES; ++w) {
-      const uint32_t t = t0 + w;
-      if (t >= n_tiles) break;
-      acc += red[w][v];
-      const uint32_t slot = tiles[t].slot;
-      const bool last = (w == FOLD_WAVES - 1) || (t + 1 >= n_tiles) || (tiles[t + 1].slot != slot);
-      if (last) {
-        partial[(size_t)slot * 8 + v] = acc;
-        acc = 0.0;
-      }
+  for (int j = 0; j < 4; ++j) {
+    const double keep = b5 ? v[j + 4] : v[j], send = b5 ? v[j] : v[j + 4];
+    w4[j] = keep + __shfl_xor(send, 32, 64);
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const double keep = b4 ? w4[j + 2] : w4[j], send = b4 ? w4[j] : w4[j + 2];
+    w2[j] = keep + __shfl_xor(send, 16, 64);
+  }
+  {
+    const double keep = b3 ? w2[1] : w2[0], send = b3 ? w2[0] : w2[1];
+    w1 = keep + dpp_mov_f64<0x128>(send);  // row_ror:8 == lane xor 8
+  }
+  w1 += dpp_mov_f64<0xB1>(w1);   // quad_perm [1,0,3,2]
+  w1 += dpp_mov_f64<0x4E>(w1);   // quad_perm [2,3,0,1]
+  w1 += dpp_mov_f64<0x141>(w1);  // row_half_mirror: joins the two quads of the 8-lane group
+  return w1;
+}
+
+// lane L (L % 8 == 0) owns value index (L >> 3) in the bit order above
+__device__ __forceinline__ int reduce8_value_of_lane(int lane) {
+  return ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
+}
+
+// ---------------------------------------------------------------------------------------
+// Work decomposition of the observation passes.  The host cuts the flat residual-block range
+// into one CHUNK per wavefront (equal sizes, all wavefronts resident at once, so there is no
+// tail round); a chunk is a list of TILES, each the intersection of the chunk with one frame
+// pair.  wave_tiles[g] .. wave_tiles[g+1] are the tiles of wavefront g.  Per tile the wave
+// reduces its sums once; the tiles of a workgroup that continue the same pair are merged through
+// LDS into one SLOT (a slot never spans workgroups) -- no global atomics anywhere.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void block_store_partials(const TileDev* __restrict__ tiles, uint32_t bt0, uint32_t bt1,
+                                                     const double* __restrict__ red,
+                                                     double* __restrict__ partial) {
+  __syncthreads();
+  const uint32_t nt = bt1 - bt0;
+  for (uint32_t item = threadIdx.x; item < nt * 8; item += FOLD_THREADS) {
+    const uint32_t lt = item >> 3, v = item & 7;
+    const uint32_t slot = tiles[bt0 + lt].slot;
+    if (lt == 0 || tiles[bt0 + lt - 1].slot != slot) {  // first tile of its run (runs are <= 4 long)
+      double acc = red[lt * 8 + v];
+      for (uint32_t q = lt + 1; q < nt && tiles[bt0 + q].slot == slot; ++q) acc += red[q * 8 + v];
+      partial[(size_t)slot * 8 + v] = acc;
     }
   }
 }
 
 // ---------------------------------------------------------------------------------------
 // k_fold: reads m0, m1 (48 B / residual block, caller's interleaved layout), optionally writes
-// c (24 B / block) and/or accumulates S.  One wavefront per tile.
+// c (24 B / block) and/or accumulates S = sum c c^T.
 // ---------------------------------------------------------------------------------------
 template <bool WRITE_C, bool MOMENTS>
-__global__ __launch_bounds__(FOLD_THREADS) void k_fold(const TileDev* __restrict__ tiles, uint32_t n_tiles,
+__global__ __launch_bounds__(FOLD_THREADS) void k_fold(const TileDev* __restrict__ tiles,
+                                                       const uint32_t* __restrict__ wave_tiles, uint32_t n_waves,
                                                        const double* __restrict__ frames,
                                                        const double* __restrict__ m0,
                                                        const double* __restrict__ m1,
                                                        double* __restrict__ cbuf, size_t cstride,
                                                        double* __restrict__ partial) {
-  __shared__ double red[FOLD_WAVES][8];
+  extern __shared__ double red[];  // [tiles of this workgroup][8]
   const int lane = threadIdx.x & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const uint32_t t = blockIdx.x * FOLD_WAVES + wv;
-  double S0 = 0, S1 = 0, S2 = 0, S3 = 0, S4 = 0, S5 = 0;
-  if (t < n_tiles) {
-    const TileDev tl = tiles[t];
-    const double* __restrict__ R0 = frames + (size_t)MVO_FRAME_DOUBLES * tl.f0;
-    const double* __restrict__ R1 = frames + (size_t)MVO_FRAME_DOUBLES * tl.f1;
-    const double a0 = R0[0], a1 = R0[1], a2 = R0[2], a3 = R0[3], a4 = R0[4], a5 = R0[5], a6 = R0[6],
-                 a7 = R0[7], a8 = R0[8];
-    const double b0 = R1[0], b1 = R1[1], b2 = R1[2], b3 = R1[3], b4 = R1[4], b5 = R1[5], b6 = R1[6],
-                 b7 = R1[7], b8 = R1[8];
-    const double* __restrict__ p0 = m0 + 3 * (size_t)tl.src_start;
-    const double* __restrict__ p1 = m1 + 3 * (size_t)tl.src_start;
-    double* __restrict__ cx = cbuf + tl.c_start;
-    double* __restrict__ cy = cx + cstride;
-    double* __restrict__ cz = cy + cstride;
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t bw0 = blockIdx.x * FOLD_WAVES;
+  const uint32_t bw1 = bw0 + FOLD_WAVES < n_waves ? bw0 + FOLD_WAVES : n_waves;
+  const uint32_t bt0 = wave_tiles[bw0], bt1 = wave_tiles[bw1];
+  const uint32_t gw = bw0 + wv;
+  if (gw < n_waves) {
+    const uint32_t t0 = wave_tiles[gw], t1 = wave_tiles[gw + 1];
+    for (uint32_t t = t0; t < t1; ++t) {
+      const TileDev tl = tiles[t];
+      const double* __restrict__ R0 = frames + (size_t)MVO_FRAME_DOUBLES * tl.f0;
+      const double* __restrict__ R1 = frames + (size_t)MVO_FRAME_DOUBLES * tl.f1;
+      const double a0 = R0[0], a1 = R0[1], a2 = R0[2], a3 = R0[3], a4 = R0[4], a5 = R0[5], a6 = R0[6],
+                   a7 = R0[7], a8 = R0[8];
+      const double b0 = R1[0], b1 = R1[1], b2 = R1[2], b3 = R1[3], b4 = R1[4], b5 = R1[5], b6 = R1[6],
+                   b7 = R1[7], b8 = R1[8];
+      const double* __restrict__ p0 = m0 + 3 * (size_t)tl.src_start;
+      const double* __restrict__ p1 = m1 + 3 * (size_t)tl.src_start;
+      double* __restrict__ cx = cbuf + tl.c_start;
+      double* __restrict__ cy = cx + cstride;
+      double* __restrict__ cz = cy + cstride;
+      double S[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll 4
-    for (uint32_t i = lane; i < tl.count; i += 64) {
-      const double x0 = p0[3 * i], y0 = p0[3 * i + 1], z0 = p0[3 * i + 2];
-      const double x1 = p1[3 * i], y1 = p1[3 * i + 1], z1 = p1[3 * i + 2];
-      const double px = a0 * x0 + a1 * y0 + a2 * z0;  // R0 * m0
-      const double py = a3 * x0 + a4 * y0 + a5 * z0;
-      const double pz = a6 * x0 + a7 * y0 + a8 * z0;
-      const double qx = b0 * x1 + b1 * y1 + b2 * z1;  // R1 * m1
-      const double qy = b3 * x1 + b4 * y1 + b5 * z1;
-      const double qz = b6 * x1 + b7 * y1 + b8 * z1;
-      const double vx = py * qz - pz * qy;  // c = p x q
-      const double vy = pz * qx - px * qz;
-      const double vz = px * qy - py * qx;
-      if (WRITE_C) {
-        cx[i] = vx;
-        cy[i] = vy;
-        cz[i] = vz;
+      for (uint32_t i = lane; i < tl.count; i += 64) {
+        const double x0 = p0[3 * i], y0 = p0[3 * i + 1], z0 = p0[3 * i + 2];
+        const double x1 = p1[3 * i], y1 = p1[3 * i + 1], z1 = p1[3 * i + 2];
+        const double px = a0 * x0 + a1 * y0 + a2 * z0;  // R0 * m0
+        const double py = a3 * x0 + a4 * y0 + a5 * z0;
+        const double pz = a6 * x0 + a7 * y0 + a8 * z0;
+        const double qx = b0 * x1 + b1 * y1 + b2 * z1;  // R1 * m1
+        const double qy = b3 * x1 + b4 * y1 + b5 * z1;
+        const double qz = b6 * x1 + b7 * y1 + b8 * z1;
+        const double vx = py * qz - pz * qy;  // c = p x q
+        const double vy = pz * qx - px * qz;
+        const double vz = px * qy - py * qx;
+        if (WRITE_C) {
+          cx[i] = vx;
+          cy[i] = vy;
+          cz[i] = vz;
+        }
+        if (MOMENTS) {
+          S[0] += vx * vx;
+          S[1] += vx * vy;
+          S[2] += vx * vz;
+          S[3] += vy * vy;
+          S[4] += vy * vz;
+          S[5] += vz * vz;
+        }
       }
       if (MOMENTS) {
-        S0 += vx * vx;
-        S1 += vx * vy;
-        S2 += vx * vz;
-        S3 += vy * vy;
-        S4 += vy * vz;
-        S5 += vz * vz;
+        const double tot = wave_reduce8(S, lane);
+        if ((lane & 7) == 0) red[(t - bt0) * 8 + reduce8_value_of_lane(lane)] = tot;
       }
     }
   }
-  if (MOMENTS) {
-    S0 = wave_sum(S0);
-    S1 = wave_sum(S1);
-    S2 = wave_sum(S2);
-    S3 = wave_sum(S3);
-    S4 = wave_sum(S4);
-    S5 = wave_sum(S5);
-    if (lane == 0) {
-      red[wv][0] = S0;
-      red[wv][1] = S1;
-      red[wv][2] = S2;
-      red[wv][3] = S3;
-      red[wv][4] = S4;
-      red[wv][5] = S5;
-      red[wv][6] = 0.0;
-      red[wv][7] = 0.0;
-    }
-    block_store_partials(tiles, n_tiles, red, partial);
-  }
+  if (MOMENTS) block_store_partials(tiles, bt0, bt1, red, partial);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -127,82 +160,89 @@ __global__ __launch_bounds__(FOLD_THREADS) void k_fold(const TileDev* __restrict
 // reads c (24 B / block) as 16-byte loads from three SoA planes.
 // partial[slot] = { S (6, weighted), sum rho(r^2) or sum r^2, sum w r^2 }
 // ---------------------------------------------------------------------------------------
+// One residual block of the evaluation pass.  ROBUST = ceres::CauchyLoss(0.5): b = 0.25, c = 4,
+// rho(s) = b log(1 + c s), rho'(s) = 1 / (1 + c s); rho'' < 0 always, so Ceres' Corrector scales
+// residual and Jacobian row by sqrt(rho') -- i.e. the moments are weighted by w = rho'.
+// sum_i log(1 + c s_i) is carried as log(prod_i (1 + c s_i)): one multiply per block instead of
+// one fp64 log (the factors lie in [1, 5]; the caller renormalises the product's exponent), and
+// 1/(1 + c s) is a v_rcp_f64 seed plus two Newton steps (<= 1 ulp for arguments in [1, 5]).
 template <bool ROBUST>
 __device__ __forceinline__ void pass_accum(double cx, double cy, double cz, double u0, double u1, double u2,
-                                           double& S0, double& S1, double& S2, double& S3, double& S4,
-                                           double& S5, double& rho, double& wr2) {
+                                           double (&S)[8], double& prod) {
   const double r = u0 * cx + u1 * cy + u2 * cz;
   const double s = r * r;
   double w = 1.0;
   if (ROBUST) {
-    // ceres::CauchyLoss(0.5): b = 0.25, c = 4; rho = b log(1 + s c); rho' = 1 / (1 + s c)
-    const double sum = 1.0 + s * 4.0;
-    const double inv = 1.0 / sum;
-    rho += 0.25 * log(sum);
-    w = fmax(DBL_MIN, inv);
+    const double sum = fma(s, 4.0, 1.0);
+    w = fmax(DBL_MIN, fast_rcp(sum));
+    prod *= sum;
   } else {
-    rho += s;
+    S[6] += s;
   }
-  wr2 += w * s;
+  S[7] = fma(w, s, S[7]);
   const double wx = w * cx, wy = w * cy, wz = w * cz;
-  S0 += wx * cx;
-  S1 += wx * cy;
-  S2 += wx * cz;
-  S3 += wy * cy;
-  S4 += wy * cz;
-  S5 += wz * cz;
+  S[0] = fma(wx, cx, S[0]);
+  S[1] = fma(wx, cy, S[1]);
+  S[2] = fma(wx, cz, S[2]);
+  S[3] = fma(wy, cy, S[3]);
+  S[4] = fma(wy, cz, S[4]);
+  S[5] = fma(wz, cz, S[5]);
 }
 
 template <bool ROBUST>
-__global__ __launch_bounds__(FOLD_THREADS) void k_pass(const TileDev* __restrict__ tiles, uint32_t n_tiles,
+__global__ __launch_bounds__(FOLD_THREADS) void k_pass(const TileDev* __restrict__ tiles,
+                                                       const uint32_t* __restrict__ wave_tiles, uint32_t n_waves,
                                                        const double* __restrict__ cbuf, size_t cstride,
                                                        const double* __restrict__ pair_u,
                                                        const int32_t* __restrict__ win_status,
                                                        double* __restrict__ partial) {
-  __shared__ double red[FOLD_WAVES][8];
+  extern __shared__ double red[];
   const int lane = threadIdx.x & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const uint32_t t = blockIdx.x * FOLD_WAVES + wv;
-  double S0 = 0, S1 = 0, S2 = 0, S3 = 0, S4 = 0, S5 = 0, rho = 0, wr2 = 0;
-  if (t < n_tiles) {
-    const TileDev tl = tiles[t];
-    if (win_status[tl.win] == 0) {
-      const double u0 = pair_u[4 * (size_t)tl.pair], u1 = pair_u[4 * (size_t)tl.pair + 1],
-                   u2 = pair_u[4 * (size_t)tl.pair + 2];
-      const double* __restrict__ cx = cbuf + tl.c_start;
-      const double* __restrict__ cy = cx + cstride;
-      const double* __restrict__ cz = cy + cstride;
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t bw0 = blockIdx.x * FOLD_WAVES;
+  const uint32_t bw1 = bw0 + FOLD_WAVES < n_waves ? bw0 + FOLD_WAVES : n_waves;
+  const uint32_t bt0 = wave_tiles[bw0], bt1 = wave_tiles[bw1];
+  const uint32_t gw = bw0 + wv;
+  if (gw < n_waves) {
+    const uint32_t t0 = wave_tiles[gw], t1 = wave_tiles[gw + 1];
+    for (uint32_t t = t0; t < t1; ++t) {
+      const TileDev tl = tiles[t];
+      double S[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (win_status[tl.win] == 0) {
+        const double u0 = pair_u[4 * (size_t)tl.pair], u1 = pair_u[4 * (size_t)tl.pair + 1],
+                     u2 = pair_u[4 * (size_t)tl.pair + 2];
+        // 16-byte loads need an even start: step back one element when the tile starts odd
+        const uint32_t head = tl.c_start & 1u;
+        const double* __restrict__ cx = cbuf + (tl.c_start - head);
+        const double* __restrict__ cy = cx + cstride;
+        const double* __restrict__ cz = cy + cstride;
+        const uint32_t len = tl.count + head;
+        double prod = 1.0;     // running product of (1 + 4 r^2) of this lane
+        int32_t prod_exp = 0;  // exponent split off so far
+        for (uint32_t i0 = 2 * lane; i0 < len; i0 += 128 * 64) {
+          const uint32_t i1 = (len - i0) > 128 * 64 ? i0 + 128 * 64 : len;
 #pragma unroll 2
-      for (uint32_t i = 2 * lane; i < tl.count; i += 128) {
-        const double2 x = *reinterpret_cast<const double2*>(cx + i);
-        const double2 y = *reinterpret_cast<const double2*>(cy + i);
-        const double2 z = *reinterpret_cast<const double2*>(cz + i);
-        pass_accum<ROBUST>(x.x, y.x, z.x, u0, u1, u2, S0, S1, S2, S3, S4, S5, rho, wr2);
-        const bool v1 = (i + 1) < tl.count;  // the pad element of an odd tile is not data
-        pass_accum<ROBUST>(v1 ? x.y : 0.0, v1 ? y.y : 0.0, v1 ? z.y : 0.0, u0, u1, u2, S0, S1, S2, S3,
-                           S4, S5, rho, wr2);
+          for (uint32_t i = i0; i < i1; i += 128) {
+            const double2 x = *reinterpret_cast<const double2*>(cx + i);
+            const double2 y = *reinterpret_cast<const double2*>(cy + i);
+            const double2 z = *reinterpret_cast<const double2*>(cz + i);
+            const bool v0 = i >= head, v1 = (i + 1) < len;  // neighbours' elements and pads are not data
+            pass_accum<ROBUST>(v0 ? x.x : 0.0, v0 ? y.x : 0.0, v0 ? z.x : 0.0, u0, u1, u2, S, prod);
+            pass_accum<ROBUST>(v1 ? x.y : 0.0, v1 ? y.y : 0.0, v1 ? z.y : 0.0, u0, u1, u2, S, prod);
+          }
+          if (ROBUST) {  // <= 128 factors <= 5 since the last split: far from overflow
+            int e;
+            prod = frexp(prod, &e);
+            prod_exp += e;
+          }
+        }
+        if (ROBUST) S[6] = 0.25 * (log(prod) + (double)prod_exp * 0.693147180559945309417232121458);
       }
+      const double tot = wave_reduce8(S, lane);
+      if ((lane & 7) == 0) red[(t - bt0) * 8 + reduce8_value_of_lane(lane)] = tot;
     }
   }
-  S0 = wave_sum(S0);
-  S1 = wave_sum(S1);
-  S2 = wave_sum(S2);
-  S3 = wave_sum(S3);
-  S4 = wave_sum(S4);
-  S5 = wave_sum(S5);
-  rho = wave_sum(rho);
-  wr2 = wave_sum(wr2);
-  if (lane == 0) {
-    red[wv][0] = S0;
-    red[wv][1] = S1;
-    red[wv][2] = S2;
-    red[wv][3] = S3;
-    red[wv][4] = S4;
-    red[wv][5] = S5;
-    red[wv][6] = rho;
-    red[wv][7] = wr2;
-  }
-  block_store_partials(tiles, n_tiles, red, partial);
+  block_store_partials(tiles, bt0, bt1, red, partial);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -244,6 +244,7 @@ class Solver:
         opt = options or make_options()
         self._W, self._M, self._N = len(windows), windows[0].M, windows[0].N
         self._pass_mode = bool(opt.use_loss_function) or opt.assembly_mode == ASSEMBLY_PASSES
+        self._frames_out = None
         self._frames0 = np.ascontiguousarray(np.concatenate([w.frames for w in windows], axis=0),
                                              dtype=np.float64)
         pk = _Packed(windows)
@@ -257,13 +258,17 @@ class Solver:
         if rc != OK:
             raise MvoHipError(rc, "mvo_hip_solve")
 
-    def download(self):
-        frames = self._frames0.copy()
-        summ = (Summary * self._W)()
-        rc = self._lib.mvo_hip_download(self._h, frames.ctypes.data, summ)
+    def download(self, copy=True):
+        """-> (frames[W,N,13], [Summary]).  copy=False returns views of buffers that the next
+        download overwrites (what a tight replay loop wants)."""
+        if getattr(self, "_frames_out", None) is None or self._frames_out.shape != self._frames0.shape:
+            self._frames_out = self._frames0.copy()
+            self._summ_out = (Summary * self._W)()
+        rc = self._lib.mvo_hip_download(self._h, self._frames_out.ctypes.data, self._summ_out)
         if rc != OK:
             raise MvoHipError(rc, "mvo_hip_download")
-        return frames.reshape(self._W, self._N, 13), list(summ)
+        frames = self._frames_out.copy() if copy else self._frames_out
+        return frames.reshape(self._W, self._N, 13), (list(self._summ_out) if copy else self._summ_out)
 
     # -- observation-partitioned mode (one window over several GPUs) -------------------------
     def solve_partitioned(self, allreduce, sums):
