@@ -11,6 +11,17 @@ for p in (os.path.join(ROOT, "monocular-visual-odometry_amd"), os.path.join(ROOT
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The shared libraries are build products (git-ignored).  On a fresh checkout compile them
+    # once (hipcc cross-compiles gfx950 without a GPU); this builds the product and the checker,
+    # it does not substitute one for the other.
+    import subprocess
+
+    need = [os.path.join(ROOT, "monocular-visual-odometry_amd", "libmvo_hip.so"),
+            os.path.join(ROOT, "monocular-visual-odometry_amd", "host", "adapter_check"),
+            os.path.join(ROOT, "oracle", "libmvo_oracle.so")]
+    if not all(os.path.exists(p) for p in need):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "monocular-visual-odometry_amd"), "all"])
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "all"])
 
 
 @pytest.fixture(scope="session")
