@@ -78,7 +78,9 @@ typedef struct mvo_hip_options {
 } mvo_hip_options;
 
 #define MVO_HIP_ASSEMBLY_AUTO 0
-#define MVO_HIP_ASSEMBLY_PASSES 1
+#define MVO_HIP_ASSEMBLY_PASSES 1 /* bit 0 */
+#define MVO_HIP_ASSEMBLY_TILED 2  /* bit 1: always use the chip-wide tiled observation passes; by default
+                                     small or many windows are evaluated by their own LM workgroup */
 
 /* What IterativeRefinement.cpp:111-183 gathers from nowFrame: replaces the
  * std::list<std::vector<Eigen::Vector3d>> "features" (IterativeRefinement.cpp:111,147-165). */

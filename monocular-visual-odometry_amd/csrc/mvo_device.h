@@ -22,6 +22,7 @@ struct WinDev {
 struct PairDev {
   uint32_t slot_begin, slot_end;  // partial-sum slots owned by this pair
   uint32_t a, b;                  // frame indices within the window (IR.cpp:116,134)
+  uint32_t src_start, count;      // the pair's residual blocks in the caller-ordered ray arrays
 };
 
 // One wave-tile: a run of residual blocks of ONE frame pair, processed by one wavefront.
@@ -43,7 +44,7 @@ struct SolveParams {
   int32_t fix_length;
   int32_t pass_mode;   // 1: every evaluation is an observation pass (k_pass)
   int32_t trace_cap;
-  int32_t pad;
+  int32_t inline_eval;  // 1: k_lm evaluates the observations itself (small / many windows)
 };
 
 struct TraceRec {  // == mvo_hip_iteration

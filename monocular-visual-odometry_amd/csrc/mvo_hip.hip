@@ -82,6 +82,7 @@ struct mvo_hip_context {
   uint32_t max_block_tiles = 0;  // LDS rows a workgroup needs for its tiles' sums
   mvo_hip_options opt{};
   bool pass_mode = false;
+  bool inline_eval = false;  // k_lm runs the observation passes itself (small or many windows)
   std::vector<mvo_hip_frame> h_frames;  // copy of the uploaded frames (write-back base)
   std::vector<PairDev> h_pairs;
   // trace
@@ -145,6 +146,7 @@ SolveParams make_params(const mvo_hip_context* h) {
   prm.fix_length = h->opt.fix_length ? 1 : 0;
   prm.pass_mode = h->pass_mode ? 1 : 0;
   prm.trace_cap = h->trace_cap;
+  prm.inline_eval = h->inline_eval ? 1 : 0;
   return prm;
 }
 
@@ -168,11 +170,21 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
   h->N = N;
   h->P = P;
   h->opt = *opt;
-  h->pass_mode = opt->use_loss_function || opt->assembly_mode == MVO_HIP_ASSEMBLY_PASSES;
+  h->pass_mode = opt->use_loss_function || (opt->assembly_mode & MVO_HIP_ASSEMBLY_PASSES);
 
   uint64_t n_obs = 0;
   for (uint32_t w = 0; w < W; ++w) n_obs += obs[w].pair_offsets[P];
   h->n_obs = n_obs;
+  // Who runs the observation passes?  With many windows (their workgroups alone fill the chip) or
+  // small windows (one workgroup is faster than the launches it saves) each window's k_lm
+  // workgroup evaluates its own observations and the whole solve is ONE launch; large single
+  // windows use the chip-wide tiled passes.  MVO_HIP_ASSEMBLY_TILED forces the latter.
+  {
+    uint64_t max_win_obs = 0;
+    for (uint32_t w = 0; w < W; ++w)
+      if (obs[w].pair_offsets[P] > max_win_obs) max_win_obs = obs[w].pair_offsets[P];
+    h->inline_eval = (W >= 1024 || max_win_obs <= 8192) && !(opt->assembly_mode & MVO_HIP_ASSEMBLY_TILED);
+  }
   // One chunk of consecutive residual blocks per wavefront, all wavefronts resident at once:
   // waves_per_cu * 256 CUs of them, but at least kMinChunk blocks each so that small problems
   // do not pay one reduction per handful of blocks.
@@ -219,6 +231,8 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
         PairDev& pd = pairs[(size_t)w * P + p];
         pd.a = a;
         pd.b = b;
+        pd.src_start = (uint32_t)src;
+        pd.count = (uint32_t)(obs[w].pair_offsets[p + 1] - obs[w].pair_offsets[p]);
         const uint64_t cnt = obs[w].pair_offsets[p + 1] - obs[w].pair_offsets[p];
         pd.slot_begin = slot;
         uint32_t cur_slot = 0;
@@ -375,6 +389,7 @@ hipError_t launch_lm(mvo_hip_context* h, const SolveParams& prm, bool from_pair_
                      h->d_frames.as<double>(), h->d_initx.as<double>(),
                      from_pair_sums ? h->d_pairs_unit.as<PairDev>() : h->d_pairs.as<PairDev>(),
                      from_pair_sums ? h->d_pairsum.as<double>() : h->d_partial.as<double>(),
+                     h->d_m0.as<double>(), h->d_m1.as<double>(), h->d_pairsum.as<double>(),
                      h->d_states.as<LmState>(), h->d_results.as<LmResult>(),
                      h->d_pair_u.as<double>(), h->d_status.as<int32_t>(), h->d_trace.as<TraceRec>(),
                      h->d_done.as<int32_t>());
@@ -409,7 +424,9 @@ int partial_begin(mvo_hip_context* h) {
     HIP_TRY(launch_reduce_slots(h));
   } else {
     HIP_TRY(launch_fold(h, true));
-    HIP_TRY(launch_lm_any(h, make_params(h), true));  // PH_START: publishes u(x0)
+    SolveParams prm = make_params(h);
+    prm.inline_eval = 0;  // the passes are separate launches here: their sums get all-reduced
+    HIP_TRY(launch_lm_any(h, prm, true));  // PH_START: publishes u(x0)
   }
   HIP_TRY(hipStreamSynchronize(s));
   return MVO_HIP_OK;
@@ -429,7 +446,9 @@ int partial_advance(mvo_hip_context* h, int32_t* done) {
   if (!h->uploaded || !h->d_pairsum.p) return MVO_HIP_ERR_STATE;
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t s = h->stream;
-  HIP_TRY(launch_lm_any(h, make_params(h), true));
+  SolveParams prm = make_params(h);
+  prm.inline_eval = 0;
+  HIP_TRY(launch_lm_any(h, prm, true));
   HIP_TRY(hipMemcpyAsync(h->h_done, h->d_done.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   const bool all = (uint32_t)h->h_done[0] >= h->W;
@@ -468,7 +487,11 @@ int do_solve(mvo_hip_context* h) {
 
   HIP_TRY(hipEventRecord(h->ev[0], s));
   int lm_launches = 0, asm_launches = 0;
-  if (!h->pass_mode) {
+  if (h->inline_eval) {
+    // the whole solve -- observation passes included -- is one launch, one workgroup per window
+    HIP_TRY(launch_lm_any(h, prm, true));
+    ++lm_launches;
+  } else if (!h->pass_mode) {
     // one fold+moment pass, then the whole LM loop in a single launch
     if (fold_blocks) {
       HIP_TRY(timed_begin());
@@ -538,7 +561,15 @@ int do_solve(mvo_hip_context* h) {
   tm.assembly_launches = asm_launches;
   tm.lm_launches = lm_launches;
   tm.residual_blocks = h->n_obs;
-  if (!h->pass_mode) {
+  if (h->inline_eval) {
+    // the passes run inside k_lm: attribute the launch to them (an upper bound on their time)
+    tm.assembly_seconds = tm.device_seconds;
+    tm.assembly_launches = 1;
+    uint64_t evals = 0;
+    for (uint32_t w = 0; w < h->W; ++w) evals += (uint64_t)(h->h_results[w].iterations + 1);
+    tm.assembly_bytes = h->pass_mode ? (uint64_t)(48.0 * (double)h->n_obs * (double)evals / (double)h->W)
+                                     : 48ull * h->n_obs;
+  } else if (!h->pass_mode) {
     tm.assembly_seconds = tm.assembly_first_seconds;
     tm.assembly_bytes = 48ull * h->n_obs;  // k_fold<moments>: read m0, m1
   } else {

@@ -16,6 +16,7 @@
 #pragma once
 
 #include "mvo_device.h"
+#include "mvo_kernels.h"
 
 // Diagnostic build only (-DMVO_LM_STAMPS): thread 0 of window 0 accumulates the shader-clock
 // cycles spent in each phase of an LM iteration into a buffer of its own (mvo_lm_stamps).
@@ -522,11 +523,11 @@ struct PairIn {
 
 // per-pair inputs: moments (sum of the pair's slots) and the fixed-frame offset n_b v_b (b >= M)
 __device__ __forceinline__ void pair_load(PairIn& in, int p, int N, int M, bool unit_slots,
-                                          const PairDev* __restrict__ wp, const double* __restrict__ partial,
+                                          const PairDev* __restrict__ wp, const double* partial,
                                           uint32_t pair_off, const double* __restrict__ fr) {
   if (unit_slots) {
     pair_ab(N, M, p, in.a, in.b);
-    const double* __restrict__ ps = partial + (size_t)(pair_off + p) * 8;
+    const double* ps = partial + (size_t)(pair_off + p) * 8;
 #pragma unroll
     for (int v = 0; v < 7; ++v) in.S[v] = ps[v];
   } else {
@@ -536,7 +537,7 @@ __device__ __forceinline__ void pair_load(PairIn& in, int p, int N, int M, bool 
 #pragma unroll
     for (int v = 0; v < 7; ++v) in.S[v] = 0.0;
     for (uint32_t sl = pd.slot_begin; sl < pd.slot_end; ++sl) {
-      const double* __restrict__ ps = partial + (size_t)sl * 8;
+      const double* ps = partial + (size_t)sl * 8;
 #pragma unroll
       for (int v = 0; v < 7; ++v) in.S[v] += ps[v];
     }
@@ -590,11 +591,75 @@ __device__ __forceinline__ int sym6(int r, int c) {
   return lo == 0 ? hi : (lo == 1 ? 2 + hi : 5);
 }
 
+// Inline evaluation (small windows / many windows): the window's own workgroup runs the observation
+// pass -- one wavefront per frame pair, straight from the caller's rays -- and leaves the 8 sums
+// of every pair in pair_sums, exactly what k_fold/k_pass + k_reduce_slots would have produced.
+// MODE 0: second moments only (no loss; done once per solve)
+// MODE 1: pass at the published point, w = 1      (assembly_mode = PASSES)
+// MODE 2: pass at the published point, Cauchy(0.5)
+template <int MODE, int NT, class SH>
+__device__ __forceinline__ void inline_pass(const SH& sh, const PairDev* __restrict__ wp, int P, int M,
+                                            const double* __restrict__ fr, const double* __restrict__ m0,
+                                            const double* __restrict__ m1, double* pair_sums) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int p = wave; p < P; p += NT / 64) {
+    const PairDev pd = wp[p];
+    const double* __restrict__ R0 = fr + MVO_FRAME_DOUBLES * pd.a;        // IR.cpp:172
+    const double* __restrict__ R1 = fr + MVO_FRAME_DOUBLES * (pd.b + 1);  // IR.cpp:171
+    const double a0 = R0[0], a1 = R0[1], a2 = R0[2], a3 = R0[3], a4 = R0[4], a5 = R0[5], a6 = R0[6], a7 = R0[7],
+                 a8 = R0[8];
+    const double b0 = R1[0], b1 = R1[1], b2 = R1[2], b3 = R1[3], b4 = R1[4], b5 = R1[5], b6 = R1[6], b7 = R1[7],
+                 b8 = R1[8];
+    double u[3] = {0.0, 0.0, 0.0}, nb;
+    if (MODE != 0) pair_unit_baseline(fr, M, (int)pd.a, (int)pd.b, sh.zvec, sh.zs, u, nb);
+    const double* __restrict__ p0 = m0 + 3 * (size_t)pd.src_start;
+    const double* __restrict__ p1 = m1 + 3 * (size_t)pd.src_start;
+    double S[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double prod = 1.0;
+    int32_t prod_exp = 0;
+    for (uint32_t i0 = lane; i0 < pd.count; i0 += 64 * 128) {
+      const uint32_t i1 = (pd.count - i0) > 64 * 128 ? i0 + 64 * 128 : pd.count;
+#pragma unroll 2
+      for (uint32_t i = i0; i < i1; i += 64) {
+        const double x0 = p0[3 * i], y0 = p0[3 * i + 1], z0 = p0[3 * i + 2];
+        const double x1 = p1[3 * i], y1 = p1[3 * i + 1], z1 = p1[3 * i + 2];
+        const double px = a0 * x0 + a1 * y0 + a2 * z0, py = a3 * x0 + a4 * y0 + a5 * z0,
+                     pz = a6 * x0 + a7 * y0 + a8 * z0;
+        const double qx = b0 * x1 + b1 * y1 + b2 * z1, qy = b3 * x1 + b4 * y1 + b5 * z1,
+                     qz = b6 * x1 + b7 * y1 + b8 * z1;
+        const double vx = py * qz - pz * qy, vy = pz * qx - px * qz, vz = px * qy - py * qx;
+        if (MODE == 0) {
+          S[0] += vx * vx;
+          S[1] += vx * vy;
+          S[2] += vx * vz;
+          S[3] += vy * vy;
+          S[4] += vy * vz;
+          S[5] += vz * vz;
+        } else {
+          pass_accum<MODE == 2>(vx, vy, vz, u[0], u[1], u[2], S, prod);
+        }
+      }
+      if (MODE == 2) {
+        int e;
+        prod = frexp(prod, &e);
+        prod_exp += e;
+      }
+    }
+    if (MODE == 2) S[6] = 0.25 * (log(prod) + (double)prod_exp * 0.693147180559945309417232121458);
+    const double tot = wave_reduce8(S, lane);
+    if ((lane & 7) == 0) pair_sums[(size_t)p * 8 + reduce8_value_of_lane(lane)] = tot;
+  }
+}
+
 template <int NT>
 __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, const WinDev* __restrict__ wins,
                                            const double* __restrict__ frames, const double* __restrict__ init_x,
-                                           const PairDev* __restrict__ pairs, const double* __restrict__ partial,
-                                           LmState* __restrict__ states, LmResult* __restrict__ results,
+                                           const PairDev* __restrict__ pairs, const double* partial,
+                                           const double* __restrict__ m0, const double* __restrict__ m1,
+                                           double* pair_sums,  // may alias `partial` (inline evaluation)
+                                           LmState* __restrict__ states,
+                                           LmResult* __restrict__ results,
                                            double* __restrict__ pair_u, int32_t* __restrict__ win_status,
                                            TraceRec* __restrict__ trace, int32_t* __restrict__ done_count) {
   constexpr int ROUNDS = NT >= 256 ? 4 : 1;  // pairs prefetched per thread (P <= 64 when NT == 64)
@@ -642,13 +707,23 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
   bool need_pass = false;
   if (sh.phase == PH_START) {
     if (tid == 0) sh.st.phase = PH_EVAL_X0;
-    need_pass = prm.pass_mode != 0;
+    need_pass = prm.pass_mode != 0 && !prm.inline_eval;
+    __syncthreads();
+  }
+  double* my_sums = pair_sums + (size_t)win.pair_off * 8;
+  if (prm.inline_eval && !prm.pass_mode) {  // no loss: the moments are folded once, here
+    inline_pass<0, NT>(sh, wp, P, M, fr, m0, m1, my_sums);
     __syncthreads();
   }
 
   while (!need_pass) {
     MVO_STAMP(0);
     // ---------------- evaluation at z: assemble J^T J, J^T r, cost ----------------
+    if (prm.inline_eval && prm.pass_mode) {  // one observation pass per evaluation, in this workgroup
+      if (prm.use_loss) inline_pass<2, NT>(sh, wp, P, M, fr, m0, m1, my_sums);
+      else inline_pass<1, NT>(sh, wp, P, M, fr, m0, m1, my_sums);
+      __syncthreads();
+    }
     // (1) per frame pair: projected moments.  Loads of all rounds are issued before any use.
     {
       PairIn in[ROUNDS];
@@ -811,7 +886,7 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
     __syncthreads();
     MVO_STAMP(5);
     if (!sh.go) break;
-    if (prm.pass_mode) need_pass = true;
+    if (prm.pass_mode && !prm.inline_eval) need_pass = true;
   }
 
   if (need_pass) {

@@ -24,6 +24,7 @@ ERR_STATE = 6
 
 ASSEMBLY_AUTO = 0
 ASSEMBLY_PASSES = 1
+ASSEMBLY_TILED = 2
 
 EXPORTED_SYMBOLS = [
     "mvo_hip_create", "mvo_hip_destroy", "mvo_hip_refine", "mvo_hip_refine_batch", "mvo_hip_upload",
@@ -243,7 +244,7 @@ class Solver:
     def upload(self, windows, options=None):
         opt = options or make_options()
         self._W, self._M, self._N = len(windows), windows[0].M, windows[0].N
-        self._pass_mode = bool(opt.use_loss_function) or opt.assembly_mode == ASSEMBLY_PASSES
+        self._pass_mode = bool(opt.use_loss_function) or bool(opt.assembly_mode & ASSEMBLY_PASSES)
         self._frames_out = None
         self._frames0 = np.ascontiguousarray(np.concatenate([w.frames for w in windows], axis=0),
                                              dtype=np.float64)

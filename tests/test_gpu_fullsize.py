@@ -114,7 +114,9 @@ def test_config3_batch_equals_its_parts(solver, oracle):
     a smaller batch (tiles never mix windows; only the tile size, hence the summation order, may
     differ), and samples match the oracle."""
     ws = [scene.config3_window(i) for i in range(512)]
+    ft, st = solver.refine_batch(ws, capi.make_options(assembly_mode=capi.ASSEMBLY_TILED, **FIXED10))
     fb, sb = solver.refine_batch(ws, capi.make_options(**FIXED10))
+    assert np.abs(fb - ft).max() < 1e-6   # chip-wide tiled passes vs per-window inline evaluation
     fa, sa = solver.refine_batch(ws[:256], capi.make_options(**FIXED10))
     fc, sc = solver.refine_batch(ws[256:], capi.make_options(**FIXED10))
     # different summation order + 10 LM iterations on weakly observable lengths: same bar as vs the oracle

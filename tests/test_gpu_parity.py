@@ -56,7 +56,10 @@ def test_eval_and_moments_match_oracle(solver, oracle, name):
 
 
 # ------------------------------------------------------------------ refine(): fixed iteration count
-@pytest.mark.parametrize("mode", [capi.ASSEMBLY_AUTO, capi.ASSEMBLY_PASSES])
+MODES = [capi.ASSEMBLY_AUTO, capi.ASSEMBLY_PASSES, capi.ASSEMBLY_TILED, capi.ASSEMBLY_TILED | capi.ASSEMBLY_PASSES]
+
+
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("name", list(shapes()))
 def test_refine_fixed_iterations_matches_oracle(solver, oracle, name, mode):
     w = shapes()[name]()
@@ -74,7 +77,7 @@ def test_refine_fixed_iterations_matches_oracle(solver, oracle, name, mode):
 def test_iteration_trace_matches_oracle(solver, oracle, name):
     """Same accept/reject sequence, same costs and radii, iteration by iteration."""
     w = shapes()[name]()
-    for mode in (capi.ASSEMBLY_AUTO, capi.ASSEMBLY_PASSES):
+    for mode in MODES:
         solver.set_trace(64)
         fg, sg = solver.refine(w, capi.make_options(assembly_mode=mode, **FIXED10))
         tg = solver.trace(64)
@@ -89,11 +92,12 @@ def test_iteration_trace_matches_oracle(solver, oracle, name):
         assert sg.num_successful_steps == so.num_successful_steps
 
 
+@pytest.mark.parametrize("tiled", [0, capi.ASSEMBLY_TILED])
 @pytest.mark.parametrize("use_loss,fix", [(True, False), (False, True), (True, True)])
-def test_refine_loss_and_fixed_length(solver, oracle, use_loss, fix):
+def test_refine_loss_and_fixed_length(solver, oracle, use_loss, fix, tiled):
     for w in (scene.config1(), scene.make_window(7, 5, 300, seed=5, outlier_fraction=0.2)):
         kw = dict(use_loss_function=use_loss, fix_length=fix, **FIXED10)
-        fg, sg = solver.refine(w, capi.make_options(**kw))
+        fg, sg = solver.refine(w, capi.make_options(assembly_mode=tiled, **kw))
         fo, so, _ = oracle.refine(w, oracle.make_options(**kw))
         assert np.abs(refined(fg, w.M) - refined(fo, w.M)).max() < TOL_FINAL
         assert abs(sg.final_cost - so.final_cost) <= 1e-8 * so.initial_cost
@@ -104,7 +108,7 @@ def test_refine_loss_and_fixed_length(solver, oracle, use_loss, fix):
 @pytest.mark.parametrize("case", GOLDEN_CASES)
 def test_converged_minimiser_matches_scipy_golden(solver, case):
     w, z = load_golden(case)
-    for mode in (capi.ASSEMBLY_AUTO, capi.ASSEMBLY_PASSES):
+    for mode in MODES:
         opt = capi.make_options(use_loss_function=bool(z["use_loss"]), fix_length=bool(z["fix_length"]),
                                 assembly_mode=mode, **TIGHT)
         f, s = solver.refine(w, opt)
@@ -125,9 +129,10 @@ def test_default_options_terminate_like_the_oracle(solver, oracle):
 
 
 # ------------------------------------------------------------------ batches
-def test_batch_matches_single_and_oracle(solver, oracle):
+@pytest.mark.parametrize("tiled", [0, capi.ASSEMBLY_TILED])
+def test_batch_matches_single_and_oracle(solver, oracle, tiled):
     ws = [scene.config3_window(i) for i in range(48)]
-    fb, sb = solver.refine_batch(ws, capi.make_options(**FIXED10))
+    fb, sb = solver.refine_batch(ws, capi.make_options(assembly_mode=tiled, **FIXED10))
     for i in (0, 1, 17, 47):
         fo, so, _ = oracle.refine(ws[i], oracle.make_options(**FIXED10))
         assert np.abs(refined(fb[i], 5) - refined(fo, 5)).max() < TOL_FINAL
@@ -136,11 +141,12 @@ def test_batch_matches_single_and_oracle(solver, oracle):
         assert sb[i].iterations == so.iterations == 10
 
 
-def test_batch_robust_with_early_finishers(solver, oracle):
+@pytest.mark.parametrize("tiled", [0, capi.ASSEMBLY_TILED])
+def test_batch_robust_with_early_finishers(solver, oracle, tiled):
     """Windows that converge early must not disturb the others (device-side status flags)."""
     ws = [scene.make_window(6, 3, 40 + 10 * i, seed=300 + i) for i in range(12)]
     kw = dict(use_loss_function=True, max_num_iterations=30)
-    fb, sb = solver.refine_batch(ws, capi.make_options(**kw))
+    fb, sb = solver.refine_batch(ws, capi.make_options(assembly_mode=tiled, **kw))
     its = set()
     for i, w in enumerate(ws):
         fo, so, _ = oracle.refine(w, oracle.make_options(**kw))
@@ -185,7 +191,7 @@ def test_single_observation_and_odd_sizes(solver, oracle):
         r, J, _ = solver.evaluate(w)
         ro, Jo, _ = oracle.evaluate(w)
         assert rel_inf(r, ro) < TOL_RJ and rel_inf(J, Jo) < TOL_RJ
-        for mode in (capi.ASSEMBLY_AUTO, capi.ASSEMBLY_PASSES):
+        for mode in MODES:
             kw = dict(max_num_iterations=3, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
             fg, sg = solver.refine(w, capi.make_options(assembly_mode=mode, **kw))
             fo, so, _ = oracle.refine(w, oracle.make_options(**kw))
@@ -244,7 +250,7 @@ def test_download_before_upload_is_an_error():
 def test_split_phase_is_repeatable(solver):
     """solve() restarts from the uploaded initial values: two solves are bitwise identical."""
     w = scene.config1()
-    solver.upload([w], capi.make_options(use_loss_function=True, **FIXED10))
+    solver.upload([w], capi.make_options(use_loss_function=True, assembly_mode=capi.ASSEMBLY_TILED, **FIXED10))
     solver.solve()
     f1, s1 = solver.download()
     solver.solve()
