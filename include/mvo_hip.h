@@ -209,6 +209,12 @@ int mvo_hip_pair_moments(mvo_hip_handle h, double *moments);
 int mvo_hip_set_trace(mvo_hip_handle h, int32_t capacity);
 int mvo_hip_get_trace(mvo_hip_handle h, mvo_hip_iteration *rows, int32_t capacity, int32_t *n_rows);
 
+/* Device-side timing (HIP events around the launches) costs a few microseconds per solve and is
+ * off by default; with it off mvo_hip_get_timing reports only the host-clock fields
+ * (upload_seconds, solve_seconds), the launch counts and residual_blocks.  No reference
+ * counterpart: the reference times refine() with ROS_INFO stamps around the call
+ * (IterativeRefinement.cpp:231-234). */
+int mvo_hip_set_profiling(mvo_hip_handle h, int enabled);
 int mvo_hip_get_timing(mvo_hip_handle h, mvo_hip_timing *out);
 
 /* scalar helpers exported for bindings and tests (host code, libm):

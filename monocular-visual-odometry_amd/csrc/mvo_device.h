@@ -45,6 +45,7 @@ struct SolveParams {
   int32_t pass_mode;   // 1: every evaluation is an observation pass (k_pass)
   int32_t trace_cap;
   int32_t inline_eval;  // 1: k_lm evaluates the observations itself (small / many windows)
+  int32_t fresh;        // 1: first launch of a solve -- the stored state is stale, start from zeros
 };
 
 struct TraceRec {  // == mvo_hip_iteration

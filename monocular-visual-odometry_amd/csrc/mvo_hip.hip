@@ -58,6 +58,10 @@ struct DevBuf {
 };
 
 constexpr int kMaxTimedLaunches = 128;
+// uploads with at most this many residual blocks stage their rays in the pinned arena too
+constexpr uint64_t kArenaRayLimit = 1u << 16;
+// windows with at most this many residual blocks are evaluated inside k_lm
+constexpr uint64_t kInlineWindowLimit = 8192;
 
 }  // namespace
 
@@ -66,12 +70,40 @@ struct mvo_hip_context {
   hipStream_t stream = nullptr;
   hipError_t last_hip_error = hipSuccess;
   // device buffers
-  DevBuf d_frames, d_initx, d_wins, d_pairs, d_tiles, d_wave_tiles, d_m0, d_m1, d_c, d_partial, d_pair_u, d_states,
-      d_results, d_status, d_done, d_trace, d_res, d_jac, d_pairsum, d_pairs_unit;
-  // pinned host mirror of small results
-  LmResult* h_results = nullptr;
-  size_t h_results_cap = 0;
+  DevBuf d_arena, d_m0, d_m1, d_c, d_partial, d_pair_u, d_states, d_ctl, d_trace, d_res, d_jac, d_pairsum;
+  // The tables of one upload (and the rays of a small one) are staged in ONE pinned block and
+  // reach the device in ONE copy into d_arena; these point into it (rays: or into d_m0 / d_m1).
+  struct {
+    double* frames = nullptr;
+    double* initx = nullptr;
+    WinDev* wins = nullptr;
+    PairDev* pairs = nullptr;
+    PairDev* pairs_unit = nullptr;
+    TileDev* tiles = nullptr;
+    uint32_t* wave_tiles = nullptr;
+    double* m0 = nullptr;
+    double* m1 = nullptr;
+  } t;
+  char* h_arena = nullptr;
+  size_t h_arena_cap = 0;
+  bool copy_pending = false;  // an async copy out of h_arena may still be in flight
+  // d_ctl = [window status: W int32, padded][done counter: 4 int32][results: W LmResult];
+  // the last two are mirrored in pinned host memory by one copy
+  int32_t* d_status = nullptr;
+  int32_t* d_done = nullptr;
+  LmResult* d_results = nullptr;
+  char* h_ctl = nullptr;  // pinned: [done: 4 int32][results]
+  size_t h_ctl_cap = 0;
   int32_t* h_done = nullptr;
+  LmResult* h_results = nullptr;
+  // host-side staging vectors, kept between calls so that a steady-state upload allocates nothing
+  std::vector<WinDev> v_wins;
+  std::vector<PairDev> v_unit;
+  std::vector<TileDev> v_tiles;
+  std::vector<uint32_t> v_wave_tiles;
+  std::vector<double> v_initx;
+  bool lm_started = false;  // false until the first k_lm launch of the current solve
+  bool profiling = false;  // record HIP events around the launches (mvo_hip_set_profiling)
   // problem description of the last upload
   bool uploaded = false;
   uint32_t W = 0, M = 0, N = 0, P = 0;
@@ -175,15 +207,15 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
   uint64_t n_obs = 0;
   for (uint32_t w = 0; w < W; ++w) n_obs += obs[w].pair_offsets[P];
   h->n_obs = n_obs;
-  // Who runs the observation passes?  With many windows (their workgroups alone fill the chip) or
-  // small windows (one workgroup is faster than the launches it saves) each window's k_lm
-  // workgroup evaluates its own observations and the whole solve is ONE launch; large single
-  // windows use the chip-wide tiled passes.  MVO_HIP_ASSEMBLY_TILED forces the latter.
+  // Who runs the observation passes?  For small windows one workgroup is faster than the launches
+  // it saves: each window's k_lm workgroup evaluates its own observations and the whole solve is
+  // ONE launch.  Larger windows use the chip-wide tiled passes (measured: 4096 windows of 10.5 k
+  // residual blocks run 5 % faster tiled).  MVO_HIP_ASSEMBLY_TILED forces the latter.
   {
     uint64_t max_win_obs = 0;
     for (uint32_t w = 0; w < W; ++w)
       if (obs[w].pair_offsets[P] > max_win_obs) max_win_obs = obs[w].pair_offsets[P];
-    h->inline_eval = (W >= 1024 || max_win_obs <= 8192) && !(opt->assembly_mode & MVO_HIP_ASSEMBLY_TILED);
+    h->inline_eval = max_win_obs <= kInlineWindowLimit && !(opt->assembly_mode & MVO_HIP_ASSEMBLY_TILED);
   }
   // One chunk of consecutive residual blocks per wavefront, all wavefronts resident at once:
   // waves_per_cu * 256 CUs of them, but at least kMinChunk blocks each so that small problems
@@ -199,16 +231,20 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
   if (want_waves == 0) want_waves = 1;
   const uint64_t chunk = (n_obs + want_waves - 1) / want_waves > 0 ? (n_obs + want_waves - 1) / want_waves : 1;
 
-  std::vector<WinDev> wins(W);
+  std::vector<WinDev>& wins = h->v_wins;
+  wins.assign(W, WinDev{});
   std::vector<PairDev>& pairs = h->h_pairs;
   pairs.assign((size_t)W * P, PairDev{});
-  std::vector<TileDev> tiles;
+  std::vector<TileDev>& tiles = h->v_tiles;
+  tiles.clear();
   tiles.reserve((size_t)want_waves + (size_t)W * P + 8);
-  std::vector<uint32_t> wave_tiles;  // first tile of every wavefront, plus the end
+  std::vector<uint32_t>& wave_tiles = h->v_wave_tiles;  // first tile of every wavefront, plus the end
+  wave_tiles.clear();
   wave_tiles.reserve((size_t)want_waves + 8);
   wave_tiles.push_back(0);
   uint64_t wave_fill = 0;  // residual blocks already given to the current wavefront
-  std::vector<double> initx((size_t)W * MVO_MAXM * 4, 0.0);
+  std::vector<double>& initx = h->v_initx;
+  initx.assign((size_t)W * MVO_MAXM * 4, 0.0);
   uint64_t src = 0, cpos = 0;
   uint32_t slot = 0;
   for (uint32_t w = 0; w < W; ++w) {
@@ -277,60 +313,112 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
   h->c_elems = cpos + 32;
 
   h->h_frames.assign(frames, frames + (size_t)W * N);
-
-  HIP_TRY(h->d_frames.reserve(sizeof(mvo_hip_frame) * (size_t)W * N));
-  HIP_TRY(h->d_initx.reserve(sizeof(double) * initx.size()));
-  HIP_TRY(h->d_wins.reserve(sizeof(WinDev) * W));
-  HIP_TRY(h->d_pairs.reserve(sizeof(PairDev) * pairs.size()));
-  HIP_TRY(h->d_tiles.reserve(sizeof(TileDev) * (tiles.size() + 1)));
-  HIP_TRY(h->d_wave_tiles.reserve(sizeof(uint32_t) * (wave_tiles.size() + 1)));
-  HIP_TRY(h->d_m0.reserve(sizeof(double) * 3 * (n_obs + 1)));
-  HIP_TRY(h->d_m1.reserve(sizeof(double) * 3 * (n_obs + 1)));
-  if (h->pass_mode) HIP_TRY(h->d_c.reserve(sizeof(double) * 3 * h->c_elems));
-  HIP_TRY(h->d_partial.reserve(sizeof(double) * 8 * ((size_t)slot + 1)));
-  HIP_TRY(h->d_pair_u.reserve(sizeof(double) * 4 * pairs.size()));
-  HIP_TRY(h->d_pairsum.reserve(sizeof(double) * 8 * pairs.size()));
-  HIP_TRY(h->d_pairs_unit.reserve(sizeof(PairDev) * pairs.size()));
-  std::vector<PairDev> unit(pairs);  // the same pairs, each reading its own row of d_pairsum
+  std::vector<PairDev>& unit = h->v_unit;  // the same pairs, each reading its own row of d_pairsum
+  unit.assign(pairs.begin(), pairs.end());
   for (size_t q = 0; q < unit.size(); ++q) {
     unit[q].slot_begin = (uint32_t)q;
     unit[q].slot_end = (uint32_t)q + 1;
   }
-  HIP_TRY(h->d_states.reserve(sizeof(LmState) * W));
-  HIP_TRY(h->d_results.reserve(sizeof(LmResult) * W));
-  HIP_TRY(h->d_status.reserve(sizeof(int32_t) * W));
-  HIP_TRY(h->d_done.reserve(sizeof(int32_t) * 4));
-  if (h->h_results_cap < W) {
-    if (h->h_results) (void)hipHostFree(h->h_results);
-    h->h_results = nullptr;
-    h->h_results_cap = 0;
-    HIP_TRY(hipHostMalloc((void**)&h->h_results, sizeof(LmResult) * W, hipHostMallocDefault));
-    h->h_results_cap = W;
-  }
-  if (!h->h_done) HIP_TRY(hipHostMalloc((void**)&h->h_done, sizeof(int32_t) * 4, hipHostMallocDefault));
+
+  // ---- lay the tables out in the arena; rays join them when they are few (one copy in all)
+  const bool rays_in_arena = n_obs <= kArenaRayLimit;
+  size_t off = 0;
+  auto place = [&off](size_t bytes) {
+    const size_t o = off;
+    off = (off + bytes + 255) & ~(size_t)255;
+    return o;
+  };
+  const size_t o_frames = place(sizeof(mvo_hip_frame) * (size_t)W * N);
+  const size_t o_initx = place(sizeof(double) * initx.size());
+  const size_t o_wins = place(sizeof(WinDev) * W);
+  const size_t o_pairs = place(sizeof(PairDev) * pairs.size());
+  const size_t o_unit = place(sizeof(PairDev) * unit.size());
+  const size_t o_tiles = place(sizeof(TileDev) * (tiles.size() + 1));
+  const size_t o_wave = place(sizeof(uint32_t) * (wave_tiles.size() + 1));
+  const size_t o_m0 = rays_in_arena ? place(sizeof(double) * 3 * (n_obs + 1)) : 0;
+  const size_t o_m1 = rays_in_arena ? place(sizeof(double) * 3 * (n_obs + 1)) : 0;
+  const size_t arena_bytes = off;
 
   hipStream_t s = h->stream;
-  HIP_TRY(hipMemcpyAsync(h->d_frames.p, frames, sizeof(mvo_hip_frame) * (size_t)W * N, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(h->d_initx.p, initx.data(), sizeof(double) * initx.size(), hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(h->d_wins.p, wins.data(), sizeof(WinDev) * W, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(h->d_pairs.p, pairs.data(), sizeof(PairDev) * pairs.size(), hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(h->d_pairs_unit.p, unit.data(), sizeof(PairDev) * unit.size(), hipMemcpyHostToDevice, s));
-  if (!tiles.empty())
-    HIP_TRY(hipMemcpyAsync(h->d_tiles.p, tiles.data(), sizeof(TileDev) * tiles.size(), hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(h->d_wave_tiles.p, wave_tiles.data(), sizeof(uint32_t) * wave_tiles.size(),
-                         hipMemcpyHostToDevice, s));
+  if (h->copy_pending) {  // the previous upload may still be reading the staging block
+    HIP_TRY(hipStreamSynchronize(s));
+    h->copy_pending = false;
+  }
+  if (h->h_arena_cap < arena_bytes) {
+    if (h->h_arena) (void)hipHostFree(h->h_arena);
+    h->h_arena = nullptr;
+    h->h_arena_cap = 0;
+    const size_t want = arena_bytes + arena_bytes / 4 + 4096;
+    HIP_TRY(hipHostMalloc((void**)&h->h_arena, want, hipHostMallocDefault));
+    h->h_arena_cap = want;
+  }
+  HIP_TRY(h->d_arena.reserve(arena_bytes));
+  if (!rays_in_arena) {
+    HIP_TRY(h->d_m0.reserve(sizeof(double) * 3 * (n_obs + 1)));
+    HIP_TRY(h->d_m1.reserve(sizeof(double) * 3 * (n_obs + 1)));
+  }
+  if (h->pass_mode) HIP_TRY(h->d_c.reserve(sizeof(double) * 3 * h->c_elems));
+  HIP_TRY(h->d_partial.reserve(sizeof(double) * 8 * ((size_t)slot + 1)));
+  HIP_TRY(h->d_pair_u.reserve(sizeof(double) * 4 * pairs.size()));
+  HIP_TRY(h->d_pairsum.reserve(sizeof(double) * 8 * pairs.size()));
+  HIP_TRY(h->d_states.reserve(sizeof(LmState) * W));
+  {
+    const size_t status_bytes = (sizeof(int32_t) * W + 15) & ~(size_t)15;
+    const size_t mirror_bytes = 16 + sizeof(LmResult) * W;
+    HIP_TRY(h->d_ctl.reserve(status_bytes + mirror_bytes));
+    char* base = h->d_ctl.as<char>();
+    h->d_status = reinterpret_cast<int32_t*>(base);
+    h->d_done = reinterpret_cast<int32_t*>(base + status_bytes);
+    h->d_results = reinterpret_cast<LmResult*>(base + status_bytes + 16);
+    if (h->h_ctl_cap < mirror_bytes) {
+      if (h->h_ctl) (void)hipHostFree(h->h_ctl);
+      h->h_ctl = nullptr;
+      h->h_ctl_cap = 0;
+      HIP_TRY(hipHostMalloc((void**)&h->h_ctl, mirror_bytes + mirror_bytes / 4, hipHostMallocDefault));
+      h->h_ctl_cap = mirror_bytes + mirror_bytes / 4;
+    }
+    h->h_done = reinterpret_cast<int32_t*>(h->h_ctl);
+    h->h_results = reinterpret_cast<LmResult*>(h->h_ctl + 16);
+  }
+
+  char* ha = h->h_arena;
+  char* da = h->d_arena.as<char>();
+  std::memcpy(ha + o_frames, frames, sizeof(mvo_hip_frame) * (size_t)W * N);
+  std::memcpy(ha + o_initx, initx.data(), sizeof(double) * initx.size());
+  std::memcpy(ha + o_wins, wins.data(), sizeof(WinDev) * W);
+  std::memcpy(ha + o_pairs, pairs.data(), sizeof(PairDev) * pairs.size());
+  std::memcpy(ha + o_unit, unit.data(), sizeof(PairDev) * unit.size());
+  if (!tiles.empty()) std::memcpy(ha + o_tiles, tiles.data(), sizeof(TileDev) * tiles.size());
+  std::memcpy(ha + o_wave, wave_tiles.data(), sizeof(uint32_t) * wave_tiles.size());
+  h->t.frames = reinterpret_cast<double*>(da + o_frames);
+  h->t.initx = reinterpret_cast<double*>(da + o_initx);
+  h->t.wins = reinterpret_cast<WinDev*>(da + o_wins);
+  h->t.pairs = reinterpret_cast<PairDev*>(da + o_pairs);
+  h->t.pairs_unit = reinterpret_cast<PairDev*>(da + o_unit);
+  h->t.tiles = reinterpret_cast<TileDev*>(da + o_tiles);
+  h->t.wave_tiles = reinterpret_cast<uint32_t*>(da + o_wave);
+  h->t.m0 = rays_in_arena ? reinterpret_cast<double*>(da + o_m0) : h->d_m0.as<double>();
+  h->t.m1 = rays_in_arena ? reinterpret_cast<double*>(da + o_m1) : h->d_m1.as<double>();
   uint64_t pos = 0;
   for (uint32_t w = 0; w < W; ++w) {
     const uint64_t cnt = obs[w].pair_offsets[P];
     if (cnt) {
-      HIP_TRY(hipMemcpyAsync(h->d_m0.as<double>() + 3 * pos, obs[w].m0, sizeof(double) * 3 * cnt,
-                             hipMemcpyHostToDevice, s));
-      HIP_TRY(hipMemcpyAsync(h->d_m1.as<double>() + 3 * pos, obs[w].m1, sizeof(double) * 3 * cnt,
-                             hipMemcpyHostToDevice, s));
+      if (rays_in_arena) {
+        std::memcpy(ha + o_m0 + sizeof(double) * 3 * pos, obs[w].m0, sizeof(double) * 3 * cnt);
+        std::memcpy(ha + o_m1 + sizeof(double) * 3 * pos, obs[w].m1, sizeof(double) * 3 * cnt);
+      } else {
+        HIP_TRY(hipMemcpyAsync(h->t.m0 + 3 * pos, obs[w].m0, sizeof(double) * 3 * cnt, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(h->t.m1 + 3 * pos, obs[w].m1, sizeof(double) * 3 * cnt, hipMemcpyHostToDevice, s));
+      }
     }
     pos += cnt;
   }
-  HIP_TRY(hipStreamSynchronize(s));  // the staging vectors above die with this scope
+  HIP_TRY(hipMemcpyAsync(da, ha, arena_bytes, hipMemcpyHostToDevice, s));
+  if (rays_in_arena) {
+    h->copy_pending = true;  // pinned source: the copy is asynchronous and the solve is queued behind it
+  } else {
+    HIP_TRY(hipStreamSynchronize(s));  // the caller's ray arrays may change once this call returns
+  }
   h->uploaded = true;
   h->timing.upload_seconds =
       std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
@@ -346,13 +434,13 @@ hipError_t launch_fold(mvo_hip_context* h, bool write_c) {
   if (!blocks) return hipSuccess;
   if (write_c)
     hipLaunchKernelGGL((k_fold<true, false>), dim3(blocks), dim3(FOLD_THREADS), 0, h->stream,
-                       h->d_tiles.as<TileDev>(), h->d_wave_tiles.as<uint32_t>(), h->n_waves,
-                       h->d_frames.as<double>(), h->d_m0.as<double>(), h->d_m1.as<double>(), h->d_c.as<double>(),
+                       h->t.tiles, h->t.wave_tiles, h->n_waves,
+                       h->t.frames, h->t.m0, h->t.m1, h->d_c.as<double>(),
                        (size_t)h->c_elems, h->d_partial.as<double>());
   else
     hipLaunchKernelGGL((k_fold<false, true>), dim3(blocks), dim3(FOLD_THREADS), pass_lds(h), h->stream,
-                       h->d_tiles.as<TileDev>(), h->d_wave_tiles.as<uint32_t>(), h->n_waves,
-                       h->d_frames.as<double>(), h->d_m0.as<double>(), h->d_m1.as<double>(), (double*)nullptr,
+                       h->t.tiles, h->t.wave_tiles, h->n_waves,
+                       h->t.frames, h->t.m0, h->t.m1, (double*)nullptr,
                        (size_t)0, h->d_partial.as<double>());
   return hipGetLastError();
 }
@@ -363,13 +451,13 @@ hipError_t launch_pass(mvo_hip_context* h) {
   if (!blocks) return hipSuccess;
   if (h->opt.use_loss_function)
     hipLaunchKernelGGL((k_pass<true>), dim3(blocks), dim3(FOLD_THREADS), pass_lds(h), h->stream,
-                       h->d_tiles.as<TileDev>(), h->d_wave_tiles.as<uint32_t>(), h->n_waves, h->d_c.as<double>(),
-                       (size_t)h->c_elems, h->d_pair_u.as<double>(), h->d_status.as<int32_t>(),
+                       h->t.tiles, h->t.wave_tiles, h->n_waves, h->d_c.as<double>(),
+                       (size_t)h->c_elems, h->d_pair_u.as<double>(), h->d_status,
                        h->d_partial.as<double>());
   else
     hipLaunchKernelGGL((k_pass<false>), dim3(blocks), dim3(FOLD_THREADS), pass_lds(h), h->stream,
-                       h->d_tiles.as<TileDev>(), h->d_wave_tiles.as<uint32_t>(), h->n_waves, h->d_c.as<double>(),
-                       (size_t)h->c_elems, h->d_pair_u.as<double>(), h->d_status.as<int32_t>(),
+                       h->t.tiles, h->t.wave_tiles, h->n_waves, h->d_c.as<double>(),
+                       (size_t)h->c_elems, h->d_pair_u.as<double>(), h->d_status,
                        h->d_partial.as<double>());
   return hipGetLastError();
 }
@@ -385,18 +473,20 @@ hipError_t launch_lm(mvo_hip_context* h, const SolveParams& prm, bool from_pair_
     configured = dyn;
   }
   hipLaunchKernelGGL(k_lm<NT>, dim3(h->W), dim3(NT), dyn, h->stream, prm, from_pair_sums ? 1 : 0,
-                     h->d_wins.as<WinDev>(),
-                     h->d_frames.as<double>(), h->d_initx.as<double>(),
-                     from_pair_sums ? h->d_pairs_unit.as<PairDev>() : h->d_pairs.as<PairDev>(),
+                     h->t.wins,
+                     h->t.frames, h->t.initx,
+                     from_pair_sums ? h->t.pairs_unit : h->t.pairs,
                      from_pair_sums ? h->d_pairsum.as<double>() : h->d_partial.as<double>(),
-                     h->d_m0.as<double>(), h->d_m1.as<double>(), h->d_pairsum.as<double>(),
-                     h->d_states.as<LmState>(), h->d_results.as<LmResult>(),
-                     h->d_pair_u.as<double>(), h->d_status.as<int32_t>(), h->d_trace.as<TraceRec>(),
-                     h->d_done.as<int32_t>());
+                     h->t.m0, h->t.m1, h->d_pairsum.as<double>(),
+                     h->d_states.as<LmState>(), h->d_results,
+                     h->d_pair_u.as<double>(), h->d_status, h->d_trace.as<TraceRec>(),
+                     h->d_done);
   return hipGetLastError();
 }
 
-hipError_t launch_lm_any(mvo_hip_context* h, const SolveParams& prm, bool from_pair_sums = false) {
+hipError_t launch_lm_any(mvo_hip_context* h, SolveParams prm, bool from_pair_sums = false) {
+  prm.fresh = h->lm_started ? 0 : 1;  // the first launch of a solve starts from a zeroed state
+  h->lm_started = true;
   return h->P <= 64 ? launch_lm<64>(h, prm, from_pair_sums) : launch_lm<256>(h, prm, from_pair_sums);
 }
 
@@ -405,7 +495,7 @@ hipError_t launch_lm_any(mvo_hip_context* h, const SolveParams& prm, bool from_p
 hipError_t launch_reduce_slots(mvo_hip_context* h) {
   const uint32_t n = h->W * h->P;
   hipLaunchKernelGGL(k_reduce_slots, dim3((n * 8 + 255) / 256), dim3(256), 0, h->stream,
-                     h->d_pairs.as<PairDev>(), n, h->d_partial.as<double>(), h->d_pairsum.as<double>());
+                     h->t.pairs, n, h->d_partial.as<double>(), h->d_pairsum.as<double>());
   return hipGetLastError();
 }
 
@@ -415,9 +505,9 @@ int partial_begin(mvo_hip_context* h) {
   hipStream_t s = h->stream;
   const uint32_t n = h->W * h->P;
   if (h->trace_cap > 0) HIP_TRY(h->d_trace.reserve(sizeof(TraceRec) * (size_t)h->trace_cap));
-  HIP_TRY(hipMemsetAsync(h->d_states.p, 0, sizeof(LmState) * h->W, s));
-  HIP_TRY(hipMemsetAsync(h->d_status.p, 0, sizeof(int32_t) * h->W, s));
-  HIP_TRY(hipMemsetAsync(h->d_done.p, 0, sizeof(int32_t) * 4, s));
+  h->lm_started = false;
+  // window status words and the done counter are adjacent: one fill
+  HIP_TRY(hipMemsetAsync(h->d_status, 0, (size_t)((char*)h->d_done - (char*)h->d_status) + 16, s));
   HIP_TRY(hipMemsetAsync(h->d_pairsum.p, 0, sizeof(double) * 8 * (size_t)n, s));
   if (!h->pass_mode) {
     HIP_TRY(launch_fold(h, false));
@@ -449,11 +539,11 @@ int partial_advance(mvo_hip_context* h, int32_t* done) {
   SolveParams prm = make_params(h);
   prm.inline_eval = 0;
   HIP_TRY(launch_lm_any(h, prm, true));
-  HIP_TRY(hipMemcpyAsync(h->h_done, h->d_done.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(h->h_done, h->d_done, sizeof(int32_t), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   const bool all = (uint32_t)h->h_done[0] >= h->W;
   if (all) {
-    HIP_TRY(hipMemcpyAsync(h->h_results, h->d_results.p, sizeof(LmResult) * h->W, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(h->h_results, h->d_results, sizeof(LmResult) * h->W, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
   }
   if (done) *done = all ? 1 : 0;
@@ -464,28 +554,32 @@ int do_solve(mvo_hip_context* h) {
   if (!h->uploaded) return MVO_HIP_ERR_STATE;
   const auto t_begin = std::chrono::steady_clock::now();
   HIP_TRY(hipSetDevice(h->device));
-  int rc = ensure_events(h);
-  if (rc != MVO_HIP_OK) return rc;
+  const bool prof = h->profiling;
+  if (prof) {
+    int rc = ensure_events(h);
+    if (rc != MVO_HIP_OK) return rc;
+  }
   hipStream_t s = h->stream;
   const SolveParams prm = make_params(h);
   if (h->trace_cap > 0) HIP_TRY(h->d_trace.reserve(sizeof(TraceRec) * (size_t)h->trace_cap));
 
-  HIP_TRY(hipMemsetAsync(h->d_states.p, 0, sizeof(LmState) * h->W, s));
-  HIP_TRY(hipMemsetAsync(h->d_status.p, 0, sizeof(int32_t) * h->W, s));
-  HIP_TRY(hipMemsetAsync(h->d_done.p, 0, sizeof(int32_t) * 4, s));
+  h->lm_started = false;
+  // window status words and the done counter are adjacent: one fill.  The LM states need none:
+  // the first k_lm launch starts from zeros of its own (SolveParams::fresh).
+  HIP_TRY(hipMemsetAsync(h->d_status, 0, (size_t)((char*)h->d_done - (char*)h->d_status) + 16, s));
 
   const uint32_t fold_blocks = pass_blocks(h);
   int n_timed = 0;
   auto timed_begin = [&]() -> hipError_t {
-    return n_timed < kMaxTimedLaunches ? hipEventRecord(h->ev[2 + 2 * n_timed], s) : hipSuccess;
+    return prof && n_timed < kMaxTimedLaunches ? hipEventRecord(h->ev[2 + 2 * n_timed], s) : hipSuccess;
   };
   auto timed_end = [&]() -> hipError_t {
-    hipError_t e = n_timed < kMaxTimedLaunches ? hipEventRecord(h->ev[3 + 2 * n_timed], s) : hipSuccess;
+    hipError_t e = prof && n_timed < kMaxTimedLaunches ? hipEventRecord(h->ev[3 + 2 * n_timed], s) : hipSuccess;
     ++n_timed;
     return e;
   };
 
-  HIP_TRY(hipEventRecord(h->ev[0], s));
+  if (prof) HIP_TRY(hipEventRecord(h->ev[0], s));
   int lm_launches = 0, asm_launches = 0;
   if (h->inline_eval) {
     // the whole solve -- observation passes included -- is one launch, one workgroup per window
@@ -532,25 +626,32 @@ int do_solve(mvo_hip_context* h) {
       }
       issued += n;
       if (issued < total_evals) {
-        HIP_TRY(hipMemcpyAsync(h->h_done, h->d_done.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(h->h_done, h->d_done, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         if ((uint32_t)h->h_done[0] >= h->W) break;
       }
     }
   }
-  HIP_TRY(hipEventRecord(h->ev[1], s));
-  HIP_TRY(hipMemcpyAsync(h->h_results, h->d_results.p, sizeof(LmResult) * h->W, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(h->h_done, h->d_done.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  if (prof) HIP_TRY(hipEventRecord(h->ev[1], s));
+  // done counter and results are adjacent on both sides: one copy
+  HIP_TRY(hipMemcpyAsync(h->h_ctl, h->d_done, 16 + sizeof(LmResult) * h->W, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
+  h->copy_pending = false;
   if ((uint32_t)h->h_done[0] != h->W) return MVO_HIP_ERR_DEVICE;  // every window must have terminated
 
   mvo_hip_timing& tm = h->timing;
   tm.solve_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+  tm.device_seconds = 0.0;
+  tm.assembly_seconds = 0.0;
+  tm.assembly_first_seconds = 0.0;
+  tm.assembly_launches = asm_launches;
+  tm.lm_launches = lm_launches;
+  tm.residual_blocks = h->n_obs;
+  tm.assembly_bytes = 0;
+  if (!prof) return MVO_HIP_OK;
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
   tm.device_seconds = ms * 1e-3;
-  tm.assembly_seconds = 0.0;
-  tm.assembly_first_seconds = 0.0;
   const int nt = n_timed < kMaxTimedLaunches ? n_timed : kMaxTimedLaunches;
   double pass_seconds = 0.0;
   for (int i = 0; i < nt; ++i) {
@@ -558,9 +659,6 @@ int do_solve(mvo_hip_context* h) {
     if (i == 0) tm.assembly_first_seconds = ms * 1e-3;
     else pass_seconds += ms * 1e-3;
   }
-  tm.assembly_launches = asm_launches;
-  tm.lm_launches = lm_launches;
-  tm.residual_blocks = h->n_obs;
   if (h->inline_eval) {
     // the passes run inside k_lm: attribute the launch to them (an upper bound on their time)
     tm.assembly_seconds = tm.device_seconds;
@@ -636,7 +734,7 @@ int mvo_hip_create(int device_ordinal, uint32_t max_windows, uint32_t max_frames
     (void)h->d_m0.reserve(sizeof(double) * 3 * (max_observations + 1));
     (void)h->d_m1.reserve(sizeof(double) * 3 * (max_observations + 1));
   }
-  if (max_windows && max_frames) (void)h->d_frames.reserve(sizeof(mvo_hip_frame) * (size_t)max_windows * max_frames);
+  if (max_windows && max_frames) (void)h->d_arena.reserve(sizeof(mvo_hip_frame) * (size_t)max_windows * max_frames);
   *out = h;
   return MVO_HIP_OK;
 }
@@ -645,12 +743,11 @@ void mvo_hip_destroy(mvo_hip_handle h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  DevBuf* bufs[] = {&h->d_frames, &h->d_initx, &h->d_wins, &h->d_pairs, &h->d_tiles, &h->d_wave_tiles, &h->d_m0, &h->d_m1,
-                    &h->d_c, &h->d_partial, &h->d_pair_u, &h->d_states, &h->d_results, &h->d_status,
-                    &h->d_done, &h->d_trace, &h->d_res, &h->d_jac, &h->d_pairsum, &h->d_pairs_unit};
+  DevBuf* bufs[] = {&h->d_arena, &h->d_m0, &h->d_m1, &h->d_c, &h->d_partial, &h->d_pair_u, &h->d_states,
+                    &h->d_ctl, &h->d_trace, &h->d_res, &h->d_jac, &h->d_pairsum};
   for (DevBuf* b : bufs) b->release();
-  if (h->h_results) (void)hipHostFree(h->h_results);
-  if (h->h_done) (void)hipHostFree(h->h_done);
+  if (h->h_arena) (void)hipHostFree(h->h_arena);
+  if (h->h_ctl) (void)hipHostFree(h->h_ctl);
   if (h->events_ready)
     for (auto& e : h->ev) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -703,9 +800,9 @@ int mvo_hip_eval(mvo_hip_handle h, const mvo_hip_frame* frames, uint32_t M, uint
   const uint32_t blocks = (h->n_tiles + FOLD_WAVES - 1) / FOLD_WAVES;
   if (blocks) {
     hipLaunchKernelGGL(k_eval, dim3(blocks), dim3(FOLD_THREADS), 0, h->stream, make_params(h),
-                       h->d_tiles.as<TileDev>(), h->n_tiles, h->d_wins.as<WinDev>(), h->d_pairs.as<PairDev>(),
-                       h->d_frames.as<double>(), h->d_initx.as<double>(), h->d_m0.as<double>(),
-                       h->d_m1.as<double>(), want_res ? h->d_res.as<double>() : (double*)nullptr,
+                       h->t.tiles, h->n_tiles, h->t.wins, h->t.pairs,
+                       h->t.frames, h->t.initx, h->t.m0,
+                       h->t.m1, want_res ? h->d_res.as<double>() : (double*)nullptr,
                        jacobian ? h->d_jac.as<double>() : (double*)nullptr);
     HIP_TRY(hipGetLastError());
   }
@@ -764,6 +861,12 @@ int mvo_hip_partial_sums(mvo_hip_handle h, void* device_buffer, uint64_t n_doubl
   else
     HIP_TRY(hipMemcpyAsync(h->d_pairsum.p, device_buffer, sizeof(double) * n_doubles, hipMemcpyDeviceToDevice, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
+  return MVO_HIP_OK;
+}
+
+int mvo_hip_set_profiling(mvo_hip_handle h, int enabled) {
+  if (!h) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  h->profiling = enabled != 0;
   return MVO_HIP_OK;
 }
 

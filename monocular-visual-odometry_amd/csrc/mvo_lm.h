@@ -506,6 +506,15 @@ __device__ int lm_advance_body(LmRegs& r, SH& sh, const SolveParams& prm, int M,
   }
 }
 
+// t-th block (k, l), k <= l < M, of the upper triangle in row-major order
+__device__ __forceinline__ void upper_block(int M, int t, int& k, int& l) {
+  k = 0;
+#pragma unroll
+  for (int q = 1; q < MVO_MAXM; ++q)
+    if (q < M && t >= q * M - (q * (q - 1)) / 2) k = q;
+  l = k + (t - (k * M - (k * (k - 1)) / 2));
+}
+
 // (a, b) of pair p in the reference's loop order (inverse of pair_index)
 __device__ __forceinline__ void pair_ab(int N, int M, int p, int& a, int& b) {
   a = 0;
@@ -670,7 +679,8 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
   const int lane = tid & 63;
   const bool wave0 = tid < 64;
   LmState* __restrict__ gst = states + w;
-  if (gst->status != 0) return;  // uniform: every thread reads the same word
+  const bool fresh = prm.fresh != 0;
+  if (!fresh && gst->status != 0) return;  // uniform: every thread reads the same word
   const WinDev win = wins[w];
   const int M = win.M, N = win.N, P = win.P;
   const int fix = prm.fix_length;
@@ -680,7 +690,7 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
 
   // solver state HBM -> LDS (all threads), then the point to evaluate is published by wave 0
   for (int i = tid; i < (int)(sizeof(LmState) / 8); i += NT)
-    reinterpret_cast<double*>(&sh.st)[i] = reinterpret_cast<const double*>(gst)[i];
+    reinterpret_cast<double*>(&sh.st)[i] = fresh ? 0.0 : reinterpret_cast<const double*>(gst)[i];
   __syncthreads();
   if (wave0) {
     LmState& st = sh.st;
@@ -716,6 +726,9 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
     __syncthreads();
   }
 
+  PairIn in0;
+  in0.a = in0.b = 0;
+  bool have0 = false;
   while (!need_pass) {
     MVO_STAMP(0);
     // ---------------- evaluation at z: assemble J^T J, J^T r, cost ----------------
@@ -725,15 +738,21 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
       __syncthreads();
     }
     // (1) per frame pair: projected moments.  Loads of all rounds are issued before any use.
+    // Without a loss the moments never change: the first round's inputs stay in registers.
     {
       PairIn in[ROUNDS];
+      if (!have0) {
+        if (tid < P) pair_load(in0, tid, N, M, unit_slots != 0, wp, partial, win.pair_off, fr);
+        have0 = !prm.pass_mode;
+      }
 #pragma unroll
-      for (int rr = 0; rr < ROUNDS; ++rr) {
+      for (int rr = 1; rr < ROUNDS; ++rr) {
         const int p = tid + rr * NT;
         if (p < P) pair_load(in[rr], p, N, M, unit_slots != 0, wp, partial, win.pair_off, fr);
       }
+      if (tid < P) pair_eval(in0, sh, M, prm.pass_mode, pairbuf + (size_t)tid * 10);
 #pragma unroll
-      for (int rr = 0; rr < ROUNDS; ++rr) {
+      for (int rr = 1; rr < ROUNDS; ++rr) {
         const int p = tid + rr * NT;
         if (p < P) pair_eval(in[rr], sh, M, prm.pass_mode, pairbuf + (size_t)p * 10);
       }
@@ -789,52 +808,54 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
     // y_k = sum of q over those containing k.  The pair (k,k) is kept apart: its baseline is
     // s_k v_k alone, so r does not depend on t_k at all (IR.cpp:466-471 normalises the scale
     // away) and its scale row/column is exactly zero instead of rounding noise of the size of S.
-    for (int item = tid; item < MVO_MAXM * MVO_MAXM * 6 + MVO_MAXM * 3 + 1; item += NT) {
-      if (item < MVO_MAXM * MVO_MAXM * 6) {
-        const int kl = item / 6, v = item % 6, k = kl / MVO_MAXM, l = kl % MVO_MAXM;
-        if (l >= k && l < M) {
-          double acc = 0.0;
-#pragma unroll
-          for (int a = 0; a < MVO_MAXM; ++a)
-#pragma unroll
-            for (int j = 0; j < MCX; ++j) {
-              const bool in = a <= k && j >= l && j <= M && !(k == l && a == k && j == k);
-              acc = fma(sh.cls[a * MCX + j][v], in ? 1.0 : 0.0, acc);  // 30 reads issue back to back
-            }
-          sh.W[kl][v] = acc;
+    // One masked sum over the classes serves all three kinds of item (W entry, y entry, cost):
+    // no divergent branches, and only the M (M + 1) / 2 upper blocks are enumerated.
+    {
+      const int nkl = (M * (M + 1)) / 2, nW = nkl * 6, nWy = nW + 3 * M;
+      for (int item = tid; item <= nWy; item += NT) {
+        int k, l, v;
+        double* out;
+        const bool is_cost = item == nWy;
+        if (item < nW) {
+          const int t = item / 6;
+          upper_block(M, t, k, l);
+          v = item - 6 * t;
+          out = &sh.W[k * MVO_MAXM + l][v];
+        } else if (!is_cost) {
+          k = (item - nW) / 3;
+          l = k;
+          v = 6 + (item - nW) - 3 * k;
+          out = &sh.y[k][v - 6];
+        } else {
+          k = M - 1;
+          l = 0;
+          v = 9;
+          out = &sh.cost_z;
         }
-      } else if (item < MVO_MAXM * MVO_MAXM * 6 + MVO_MAXM * 3) {
-        const int k = (item - MVO_MAXM * MVO_MAXM * 6) / 3, v = (item - MVO_MAXM * MVO_MAXM * 6) % 3;
-        if (k < M) {
-          double acc = 0.0;
-#pragma unroll
-          for (int a = 0; a < MVO_MAXM; ++a)
-#pragma unroll
-            for (int j = 0; j < MCX; ++j) {
-              const bool in = a <= k && j >= k && j <= M && !(a == k && j == k);
-              acc = fma(sh.cls[a * MCX + j][6 + v], in ? 1.0 : 0.0, acc);
-            }
-          sh.y[k][v] = acc;
-        }
-      } else {
-        double c = 0.0;
-#pragma unroll
-        for (int a = 0; a < MVO_MAXM; ++a)
+        double acc = 0.0;
+        for (int a = 0; a <= k; ++a) {
+          const int jmin = is_cost ? a : l;
 #pragma unroll
           for (int j = 0; j < MCX; ++j) {
-            const bool in = a < M && j >= a && j <= M;
-            c = fma(sh.cls[a * MCX + j][9], in ? 1.0 : 0.0, c);
+            const bool in = j >= jmin && j <= M && (is_cost || !(k == l && a == k && j == k));
+            const double c = sh.cls[a * MCX + j][v];  // the 6 reads of a row issue back to back
+            acc += in ? c : 0.0;
           }
-        sh.cost_z = c;
+        }
+        *out = acc;
       }
     }
     __syncthreads();
     MVO_STAMP(3);
     // (4) 3x3 blocks G_k^T W_kl G_l (one entry per thread) and gradient entries G_k^T y_k
-    for (int item = tid; item < MVO_MAXM * MVO_MAXM * 9 + MVO_MAXM * 3; item += NT) {
-      if (item < MVO_MAXM * MVO_MAXM * 9) {
-        const int kl = item / 9, i = (item % 9) / 3, jj = item % 3, k = kl / MVO_MAXM, l = kl % MVO_MAXM;
-        if (l >= k && l < M) {
+    {
+      const int nkl = (M * (M + 1)) / 2, nB = nkl * 9;
+      for (int item = tid; item < nB + 3 * M; item += NT) {
+        if (item < nB) {
+          const int t = item / 9, e = item - 9 * t, i = e / 3, jj = e - 3 * i;
+          int k, l;
+          upper_block(M, t, k, l);
+          const int kl = k * MVO_MAXM + l;
           double val = 0.0;
 #pragma unroll
           for (int rr = 0; rr < 3; ++rr) {
@@ -856,10 +877,8 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
           double* __restrict__ Hw = sh.hsel ? sh.st.H : sh.Hz;
           Hw[(3 * k + i) * MVO_MAXC + 3 * l + jj] = val;
           Hw[(3 * l + jj) * MVO_MAXC + 3 * k + i] = val;
-        }
-      } else {
-        const int k = (item - MVO_MAXM * MVO_MAXM * 9) / 3, i = (item - MVO_MAXM * MVO_MAXM * 9) % 3;
-        if (k < M) {
+        } else {
+          const int k = (item - nB) / 3, i = (item - nB) - 3 * k;
           double gi = sh.G[k][i] * sh.y[k][0] + sh.G[k][3 + i] * sh.y[k][1] + sh.G[k][6 + i] * sh.y[k][2];
           if (i < 2) {
             const double* qs = &sh.cls[k * MCX + k][6];

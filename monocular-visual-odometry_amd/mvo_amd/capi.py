@@ -29,6 +29,7 @@ ASSEMBLY_TILED = 2
 EXPORTED_SYMBOLS = [
     "mvo_hip_create", "mvo_hip_destroy", "mvo_hip_refine", "mvo_hip_refine_batch", "mvo_hip_upload",
     "mvo_hip_solve", "mvo_hip_download", "mvo_hip_eval", "mvo_hip_pair_moments", "mvo_hip_set_trace",
+    "mvo_hip_set_profiling",
     "mvo_hip_get_trace", "mvo_hip_get_timing", "mvo_hip_reverse_scale", "mvo_hip_scale",
     "mvo_hip_num_pairs", "mvo_hip_status_string", "mvo_hip_version", "mvo_hip_partial_begin",
     "mvo_hip_partial_pass", "mvo_hip_partial_advance", "mvo_hip_partial_sums",
@@ -134,6 +135,7 @@ def load():
                                    C.POINTER(Observations), C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
         L.mvo_hip_pair_moments.argtypes = [C.c_void_p, C.c_void_p]
         L.mvo_hip_set_trace.argtypes = [C.c_void_p, C.c_int32]
+        L.mvo_hip_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.mvo_hip_partial_begin.argtypes = [C.c_void_p]
         L.mvo_hip_partial_pass.argtypes = [C.c_void_p]
         L.mvo_hip_partial_advance.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
@@ -190,13 +192,15 @@ class _Packed:
 class Solver:
     """One mvo_hip_handle (one GPU, one stream)."""
 
-    def __init__(self, device=0, max_windows=0, max_frames=0, max_observations=0):
+    def __init__(self, device=0, max_windows=0, max_frames=0, max_observations=0, profiling=True):
         self._lib = load()
         self._h = C.c_void_p()
         rc = self._lib.mvo_hip_create(int(device), max_windows, max_frames, max_observations, C.byref(self._h))
         if rc != OK:
             self._h = None
             raise MvoHipError(rc, "mvo_hip_create")
+        # the library's default is off (lowest latency); tests and the bench read device timings
+        self.set_profiling(profiling)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -324,6 +328,11 @@ class Solver:
         if rc != OK:
             raise MvoHipError(rc, "mvo_hip_pair_moments")
         return out
+
+    def set_profiling(self, enabled):
+        rc = self._lib.mvo_hip_set_profiling(self._h, 1 if enabled else 0)
+        if rc != OK:
+            raise MvoHipError(rc, "mvo_hip_set_profiling")
 
     def set_trace(self, capacity):
         rc = self._lib.mvo_hip_set_trace(self._h, int(capacity))

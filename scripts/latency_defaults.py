@@ -11,7 +11,8 @@ import mvo_oracle_py as orc
 for label, w, kw in (("defaults N=3 M=2 60 feat", scene.reference_defaults_window(), {}),
                      ("defaults + Cauchy", scene.reference_defaults_window(), dict(use_loss_function=True)),
                      ("N=10 M=5 300 feat", scene.config1(), {})):
-    with capi.Solver(0) as s:
+  for prof in (False, True):
+    with capi.Solver(0, profiling=prof) as s:
         opt = capi.make_options(**kw)
         for _ in range(20): s.refine(w, opt)
         ts = []
@@ -21,6 +22,6 @@ for label, w, kw in (("defaults N=3 M=2 60 feat", scene.reference_defaults_windo
         t0 = time.perf_counter()
         for _ in range(20): fo, so, _ = orc.refine(w, orc.make_options(**kw))
         cpu = (time.perf_counter() - t0) / 20 * 1e6
-        print(f"{label}: refine() median {np.median(ts):.1f} us, p90 {np.percentile(ts, 90):.1f} us, iterations {sm.iterations}; "
+        print(f"{label} [events {'on' if prof else 'off'}]: refine() median {np.median(ts):.1f} us, p90 {np.percentile(ts, 90):.1f} us, iterations {sm.iterations}; "
               f"timing {s.timing()['upload_seconds']*1e6:.1f} us upload + {s.timing()['solve_seconds']*1e6:.1f} us solve "
               f"(device {s.timing()['device_seconds']*1e6:.1f} us); CPU oracle {cpu:.1f} us")

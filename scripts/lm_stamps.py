@@ -9,7 +9,8 @@ lib = capi.load()
 lib.mvo_hip_debug_stamps.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 names = ["iterations", "per-pair", "class sums", "W/y", "blocks", "lm_advance", "-", "-", "adv:decide", "adv:finalize", "adv:setup", "adv:eliminate", "adv:mcc", "adv:plus", "adv:publish", "-"]
 fixed = dict(max_num_iterations=10, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
-for label, ws in (("config2", [scene.config2()]), ("config4", [scene.config4()]), ("config1 x 64", [scene.config3_window(i) for i in range(64)])):
+for label, ws in (("defaults N=3 M=2", [scene.reference_defaults_window()]), ("config1", [scene.config1()]),
+                  ("config2", [scene.config2()]), ("config4", [scene.config4()]), ("config1 x 64", [scene.config3_window(i) for i in range(64)])):
     with capi.Solver(0) as s:
         s.upload(ws, capi.make_options(**fixed))
         s.solve()
