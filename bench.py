@@ -62,7 +62,24 @@ def build_workload(name, rank):
     return ws, opt, desc
 
 
-def roofline_of(timing):
+def measured_traffic(workload, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/traffic.json,
+    written by scripts/profile.sh on the same workload); None when no such pass was recorded."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["per_workload"][workload]
+    except (OSError, KeyError, ValueError):
+        return None
+    for name, rec in t.items():
+        if name.startswith(kernel):
+            return int(rec.get("fetch_bytes", 0) + rec.get("write_bytes", 0))
+    return None
+
+
+def pass_kernel(workload):
+    return "k_pass<true>" if workload in ("config5", "config4r") else "k_fold<false, true>"
+
+
+def roofline_of(timing, workload=None):
     """achieved = algorithmic bytes per launch / average launch duration of the pass kernel."""
     n = max(1, timing["assembly_launches"])
     dur = timing["assembly_seconds"] / n
@@ -70,7 +87,9 @@ def roofline_of(timing):
         return None
     gbs = timing["assembly_bytes"] / dur / 1e9
     return {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+            "frac": round(gbs / HBM_PEAK_GBS, 4),
+            "traffic": measured_traffic(workload, pass_kernel(workload)) if workload else None,
+            "kernel": pass_kernel(workload) if workload else None,
             "bytes_per_launch": int(timing["assembly_bytes"]), "avg_launch_us": round(dur * 1e6, 3),
             "launches_timed": int(timing["assembly_launches"])}
 
@@ -199,7 +218,7 @@ def main():
     units = 1 if partitioned else world   # a partitioned window is one job, not `world` jobs
     total_its = its_per_step * args.steps * units
     tm["assembly_seconds"], tm["assembly_launches"] = asm_s, asm_n
-    roof = None if partitioned else roofline_of(tm)  # the partitioned path is not event-timed
+    roof = None if partitioned else roofline_of(tm, args.workload)  # the partitioned path is not event-timed
 
     out = {
         "metric": "lm_iterations_per_sec",
@@ -248,11 +267,10 @@ def main():
             k += 1
         big_elapsed = (time.perf_counter() - t1) * k / 6
         tb["assembly_seconds"], tb["assembly_launches"] = asm_s, asm_n
-        rl = roofline_of(tb)
+        rl = roofline_of(tb, "config4r" if robust else "config4")
         rl["workload"] = big_desc
         rl["residual_blocks"] = big_ws[0].n_residual_blocks
         rl["ms_per_solve"] = round(big_elapsed / k * 1e3, 4)
-        rl["kernel"] = "k_pass<robust>" if robust else "k_fold<moments>"
         out["roofline_large"] = rl
         del big_ws
 

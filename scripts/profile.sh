@@ -19,10 +19,14 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/
   python3 "$R/bench.py" --workload config3 --steps 5 --warmup 1 --no-cpu > "$OUT/bench_config3.json" 2> "$OUT/kt_config3.err"
 # 4. HBM traffic counters at config-4 size, one counter per pass (FETCH_SIZE and WRITE_SIZE do not fit together)
 for C in FETCH_SIZE WRITE_SIZE; do
+  for WL in config2 config5 config3; do
+    timeout -s KILL 200 rocprofv3 --pmc $C --output-format csv -d "$OUT/pmc_${C}_${WL}" -- \
+      python3 "$R/bench.py" --workload $WL --steps 3 --warmup 1 --no-cpu --no-large > "$OUT/bench_pmc_${C}_${WL}.json" 2> "$OUT/pmc_${C}_${WL}.err"
+  done
   timeout -s KILL 200 rocprofv3 --pmc $C --output-format csv -d "$OUT/pmc_${C}_config4" -- \
     python3 "$R/bench.py" --workload config4 --steps 3 --warmup 1 --no-cpu > "$OUT/bench_pmc_${C}.json" 2> "$OUT/pmc_${C}.err"
   timeout -s KILL 200 rocprofv3 --pmc $C --output-format csv -d "$OUT/pmc_${C}_config4r" -- \
     python3 "$R/bench.py" --workload config4r --steps 3 --warmup 1 --no-cpu > "$OUT/bench_pmc_${C}_r.json" 2> "$OUT/pmc_${C}_r.err"
 done
-python3 "$R/scripts/summarize_profile.py" "$OUT" > "$OUT/SUMMARY.md"
+python3 "$R/scripts/summarize_profile.py" "$OUT" "$OUT/traffic.json" > "$OUT/SUMMARY.md"
 cat "$OUT/SUMMARY.md"

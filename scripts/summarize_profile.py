@@ -35,7 +35,8 @@ for d in sorted(glob.glob(os.path.join(out, "kt_*"))):
             m = meta[k]
             print(f"| `{k}` | {v[len(v)//2]} | {m[0]} | {m[1]} | {m[2]} | {m[3]} | {m[4]} | {m[5]} |")
         print()
-print("## PMC passes (bench.py --workload config4 / config4r), per dispatch averages\n")
+print("## PMC passes (one counter per run), per dispatch averages\n")
+traffic = collections.defaultdict(dict)  # workload -> kernel -> {fetch_bytes, write_bytes}
 print("FETCH_SIZE / WRITE_SIZE are in KiB. On gfx950 FETCH_SIZE counts 64 B per 128-B request for wide\ncoalesced reads (MI355X_MICROARCH.md, HBM section): corrected read bytes = 2 x FETCH_SIZE x 1024.\n")
 print("| pass | kernel | dispatches | counter | avg value |\n|---|---|---|---|---|")
 for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
@@ -49,3 +50,14 @@ for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
             if k.startswith("__amd"):
                 continue
             print(f"| {os.path.basename(d)} | `{k}` | {len(v)} | {c} | {sum(v)/len(v):.1f} |")
+            wl = os.path.basename(d).split("_")[-1]
+            kern = k.replace("void ", "").split("(")[0]
+            avg_kib = sum(v) / len(v)
+            if c == "FETCH_SIZE":  # gfx950: 64 B counted per 128-B request of a wide coalesced read
+                traffic[wl].setdefault(kern, {})["fetch_bytes"] = int(2 * avg_kib * 1024)
+            elif c == "WRITE_SIZE":
+                traffic[wl].setdefault(kern, {})["write_bytes"] = int(avg_kib * 1024)
+if len(sys.argv) > 2:
+    json.dump({"note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate runs); "
+                       "FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction",
+               "per_workload": traffic}, open(sys.argv[2], "w"), indent=1, sort_keys=True)
