@@ -22,12 +22,16 @@
 // cycles spent in each phase of an LM iteration into a buffer of its own (mvo_lm_stamps).
 #ifdef MVO_LM_STAMPS
 __device__ unsigned long long mvo_lm_stamps[16];
+// accumulated in LDS with fire-and-forget ds_add (a global read-modify-write per stamp would put
+// an L2 round trip into every measured phase); flushed once when the kernel ends
+#define MVO_STAMP_ADD(i, v) \
+  __hip_atomic_fetch_add(&stamp_acc_[(i)], (unsigned long long)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define MVO_STAMP(i)                                                        \
   do {                                                                      \
     if (w == 0 && tid == 0) {                                               \
       const unsigned long long now_ = __builtin_amdgcn_s_memtime();         \
-      if ((i) > 0) mvo_lm_stamps[(i)] += now_ - stamp_prev_;                \
-      else mvo_lm_stamps[0] += 1;                                           \
+      if ((i) > 0) MVO_STAMP_ADD(i, now_ - stamp_prev_);                    \
+      else MVO_STAMP_ADD(0, 1);                                             \
       stamp_prev_ = now_;                                                   \
     }                                                                       \
   } while (0)
@@ -36,13 +40,17 @@ __device__ unsigned long long mvo_lm_stamps[16];
   do {                                                                      \
     if (stamp_on && lane == 0) {                                            \
       const unsigned long long now_ = __builtin_amdgcn_s_memtime();         \
-      mvo_lm_stamps[(i)] += now_ - astamp_prev_;                            \
+      MVO_STAMP_ADD(i, now_ - astamp_prev_);                                \
       astamp_prev_ = now_;                                                  \
     }                                                                       \
   } while (0)
+#define MVO_STAMP_PARAM , unsigned long long* stamp_acc_
+#define MVO_STAMP_ARG , stamp_acc_
 #else
 #define MVO_STAMP(i) do { } while (0)
 #define MVO_ASTAMP(i) do { } while (0)
+#define MVO_STAMP_PARAM
+#define MVO_STAMP_ARG
 #endif
 
 // ---- wave-level helpers -----------------------------------------------------------------
@@ -52,14 +60,12 @@ __device__ __forceinline__ double bcast_lane(double v, int src_lane /* compile-t
   return __hiloint2double(hi, lo);
 }
 
-// Broadcast of lane SRC (0..15) of each 16-lane row to all lanes of that row (row_newbcast): two
-// v_mov_dpp, result stays in VGPRs -- used for the elimination's data flow (all matrix rows live
+// Broadcast of lane SRC (0..15) of each 16-lane row to all lanes of that row (row_newbcast, the
+// one DPP control gfx950 offers for 64-bit operands), result stays in VGPRs -- used for the elimination's data flow (all matrix rows live
 // in row 0).  Values that steer control flow use bcast_lane (v_readlane: truly wave-uniform).
 template <int SRC>
 __device__ __forceinline__ double row_bcast(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + SRC, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + SRC, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
+  return __builtin_amdgcn_mov_dpp(v, 0x150 + SRC, 0xf, 0xf, true);  // one v_mov_b64_dpp
 }
 
 // DPP permutations inside each 16-lane row (no LDS traffic): xor 1, xor 2, half-row mirror, row
@@ -67,8 +73,8 @@ __device__ __forceinline__ double row_bcast(double v) {
 // dense algebra lives in row 0 (lanes 0..14 = matrix rows, lanes 0..4 = refined frames).
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double row0_sum(double v) {
@@ -114,6 +120,7 @@ struct LmSharedT {
   double G[MVO_MAXM][9];                        // G[k][3*row + col]: columns (s_k jl0, s_k jl1, s'_k v_k)
   double cls[MVO_MAXM * (MVO_MAXM + 1)][10];    // class (a, j = min(b, M)): T(6) q(3) cost(1)
   double clsp[PARTS > 1 ? MVO_MAXM * (MVO_MAXM + 1) * 10 : 1][PARTS];  // strided parts of the class sums
+  double C1[MVO_MAXM * (MVO_MAXM + 1)][10];     // prefix of cls over a: C1[k][j] = sum_{a<=k} cls[a][j]
   double W[MVO_MAXM * MVO_MAXM][6], y[MVO_MAXM][3];  // per block (k,l): sum of T; per frame: sum of q
   double Hz[MVO_MAXC * MVO_MAXC], gz[MVO_MAXC]; // full 3M system at z
   double cost_z;
@@ -275,17 +282,25 @@ __device__ __forceinline__ void gj_row_update(double (&a)[MVO_MAXC], double f) {
 
 // Gauss-Jordan elimination without pivoting (the matrix is SPD): after column J every other row
 // has a zero in that column.  Pivots <= 0 (or non-finite) flag the solve as failed.
+// Look-ahead order: step J updates column J+1 first and starts the reciprocal of the NEXT pivot
+// (readlane -> v_rcp -> two Newton steps, a ~100-cycle dependent chain) before it touches the
+// remaining columns, whose independent updates then fill that latency.
 template <int J>
 __device__ __forceinline__ void gj_eliminate(double (&a)[MVO_MAXC], double& rhs, double& mydiag, bool& ok,
-                                             int lane) {
+                                             int lane, double piv, double rinv) {
   if constexpr (J < MVO_MAXC) {
-    const double piv = bcast_lane(a[J], J);
     if (!(piv > 0.0) || isinf(piv)) ok = false;
-    const double f = (lane == J) ? 0.0 : a[J] * fast_rcp(piv);
+    const double f = (lane == J) ? 0.0 : a[J] * rinv;
     if (lane == J) mydiag = piv;
-    gj_row_update<J, J + 1>(a, f);
+    double piv_next = 1.0, rinv_next = 1.0;
+    if constexpr (J + 1 < MVO_MAXC) {
+      a[J + 1] -= f * row_bcast<J>(a[J + 1]);
+      piv_next = bcast_lane(a[J + 1], J + 1);
+      rinv_next = fast_rcp(piv_next);
+      gj_row_update<J, J + 2>(a, f);
+    }
     rhs -= f * row_bcast<J>(rhs);
-    gj_eliminate<J + 1>(a, rhs, mydiag, ok, lane);
+    gj_eliminate<J + 1>(a, rhs, mydiag, ok, lane, piv_next, rinv_next);
   }
 }
 
@@ -295,13 +310,13 @@ __device__ __forceinline__ void gj_eliminate(double (&a)[MVO_MAXC], double& rhs,
 // Returns 1 when a new candidate awaits evaluation (published in sh.zvec/zt), 0 when done.
 template <class SH>
 __device__ int lm_advance_body(LmRegs& r, SH& sh, const SolveParams& prm, int M, int n, int lane,
-                               TraceRec* __restrict__ trace, int& hsel) {
+                               TraceRec* __restrict__ trace, int& hsel MVO_STAMP_PARAM) {
   LmState& st = sh.st;
   const int fix = prm.fix_length;
   // accepted system: hsel ? sh.Hz : st.H
   const double* __restrict__ Hnew = hsel ? st.H : sh.Hz;  // the system just assembled at z
 #ifdef MVO_LM_STAMPS
-  const bool stamp_on = trace != nullptr || true;
+  const bool stamp_on = stamp_acc_ != nullptr;
   unsigned long long astamp_prev_ = __builtin_amdgcn_s_memtime();
 #endif
   TraceRec it;
@@ -468,7 +483,10 @@ __device__ int lm_advance_body(LmRegs& r, SH& sh, const SolveParams& prm, int M,
     MVO_ASTAMP(10);
     double rhs = rhs0, mydiag = 1.0;
     bool ok = true;
-    gj_eliminate<0>(a, rhs, mydiag, ok, lane);
+    {
+      const double piv0 = bcast_lane(a[0], 0);
+      gj_eliminate<0>(a, rhs, mydiag, ok, lane, piv0, fast_rcp(piv0));
+    }
     MVO_ASTAMP(11);
     double step = -(rhs * fast_rcp(mydiag));
     if (lane >= n) step = 0.0;
@@ -713,6 +731,10 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
 
 #ifdef MVO_LM_STAMPS
   unsigned long long stamp_prev_ = 0;
+  __shared__ unsigned long long stamp_lds_[16];
+  if (tid < 16) stamp_lds_[tid] = 0;
+  __syncthreads();
+  unsigned long long* stamp_acc_ = (w == 0) ? stamp_lds_ : nullptr;
 #endif
   bool need_pass = false;
   if (sh.phase == PH_START) {
@@ -804,79 +826,98 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
       __syncthreads();
     }
     MVO_STAMP(2);
-    // (3) W_kl = sum of T over the pairs whose free frames contain k and l (a <= k, j >= l),
-    // y_k = sum of q over those containing k.  The pair (k,k) is kept apart: its baseline is
-    // s_k v_k alone, so r does not depend on t_k at all (IR.cpp:466-471 normalises the scale
-    // away) and its scale row/column is exactly zero instead of rounding noise of the size of S.
-    // One masked sum over the classes serves all three kinds of item (W entry, y entry, cost):
-    // no divergent branches, and only the M (M + 1) / 2 upper blocks are enumerated.
-    {
-      const int nkl = (M * (M + 1)) / 2, nW = nkl * 6, nWy = nW + 3 * M;
-      for (int item = tid; item <= nWy; item += NT) {
-        int k, l, v;
-        double* out;
-        const bool is_cost = item == nWy;
-        if (item < nW) {
-          const int t = item / 6;
-          upper_block(M, t, k, l);
-          v = item - 6 * t;
-          out = &sh.W[k * MVO_MAXM + l][v];
-        } else if (!is_cost) {
-          k = (item - nW) / 3;
-          l = k;
-          v = 6 + (item - nW) - 3 * k;
-          out = &sh.y[k][v - 6];
-        } else {
-          k = M - 1;
-          l = 0;
-          v = 9;
-          out = &sh.cost_z;
-        }
-        double acc = 0.0;
-        for (int a = 0; a <= k; ++a) {
-          const int jmin = is_cost ? a : l;
+    // (3) W_kl = sum of T over the pairs whose free frames contain k and l (classes a <= k,
+    // j >= l), y_k = sum of q over those containing k, cost = sum over all classes: a 2-D
+    // prefix/suffix sum, done in two short stages instead of 30-term sums per entry.
+    // Running sums: one thread per (j, value) walks a, one thread per (k, value) walks j.
+    // (3a) prefix over a:  C1[k][j] = sum_{a <= k} cls[a][j]
+    if (tid < MCX * 10) {
+      const int j = tid / 10, v = tid - 10 * j;
+      double x[MVO_MAXM];
 #pragma unroll
-          for (int j = 0; j < MCX; ++j) {
-            const bool in = j >= jmin && j <= M && (is_cost || !(k == l && a == k && j == k));
-            const double c = sh.cls[a * MCX + j][v];  // the 6 reads of a row issue back to back
-            acc += in ? c : 0.0;
-          }
+      for (int a = 0; a < MVO_MAXM; ++a) x[a] = sh.cls[a * MCX + j][v];  // reads issue back to back
+      double acc = 0.0;
+#pragma unroll
+      for (int a = 0; a < MVO_MAXM; ++a)
+        if (a < M && j <= M) {
+          acc += x[a];
+          sh.C1[a * MCX + j][v] = acc;
         }
-        *out = acc;
+    }
+    __syncthreads();
+    // (3b) suffix over j:  W_kl = sum_{j >= l} C1[k][j] (l > k).  The pair (k,k) is kept apart:
+    // its baseline is s_k v_k alone, so r does not depend on t_k at all (IR.cpp:466-471 normalises
+    // the scale away) and its scale row/column is exactly zero instead of rounding noise of the
+    // size of S -- the diagonal entries W_kk, y_k leave class (k,k) out:
+    // sum_{j > k} C1[k][j] + C1[k-1][k].
+    if (tid < MVO_MAXM * 10) {
+      const int k = tid / 10, v = tid - 10 * k;
+      if (k < M && v < 9) {
+        double x[MCX];
+#pragma unroll
+        for (int j = 0; j < MCX; ++j) x[j] = sh.C1[k * MCX + j][v];
+        const double xe = sh.C1[(k > 0 ? k - 1 : 0) * MCX + k][v];
+        double acc = 0.0;
+#pragma unroll
+        for (int j = MCX - 1; j >= 1; --j)
+          if (j <= M && j > k) {
+            acc += x[j];
+            if (j < M && v < 6) sh.W[k * MVO_MAXM + j][v] = acc;
+          }
+        if (k > 0) acc += xe;
+        if (v < 6) sh.W[k * MVO_MAXM + k][v] = acc;
+        else sh.y[k][v - 6] = acc;
+      } else if (k == 0 && v == 9) {
+        // cost: all classes; class (a, j) has a <= min(j, M-1)
+        double c = 0.0;
+#pragma unroll
+        for (int j = 0; j < MCX; ++j)
+          if (j <= M) c += sh.C1[(j < M ? j : M - 1) * MCX + j][9];
+        sh.cost_z = c;
       }
     }
     __syncthreads();
     MVO_STAMP(3);
-    // (4) 3x3 blocks G_k^T W_kl G_l (one entry per thread) and gradient entries G_k^T y_k
+    // (4) 3x3 blocks G_k^T W_kl G_l, one ROW of a block per thread (all of it fits one wavefront
+    // round: 45 rows + 15 gradient entries), and gradient entries G_k^T y_k
     {
-      const int nkl = (M * (M + 1)) / 2, nB = nkl * 9;
+      const int nkl = (M * (M + 1)) / 2, nB = nkl * 3;
       for (int item = tid; item < nB + 3 * M; item += NT) {
         if (item < nB) {
-          const int t = item / 9, e = item - 9 * t, i = e / 3, jj = e - 3 * i;
+          const int t = item / 3, i = item - 3 * t;
           int k, l;
           upper_block(M, t, k, l);
           const int kl = k * MVO_MAXM + l;
-          double val = 0.0;
+          double Wv[6], gk[3], Gl[9];
 #pragma unroll
-          for (int rr = 0; rr < 3; ++rr) {
-            double wg = 0.0;  // (W G_l)[rr][jj]
+          for (int v = 0; v < 6; ++v) Wv[v] = sh.W[kl][v];
 #pragma unroll
-            for (int m = 0; m < 3; ++m) wg += sh.W[kl][sym6(rr, m)] * sh.G[l][3 * m + jj];
-            val += sh.G[k][3 * rr + i] * wg;
+          for (int rr = 0; rr < 3; ++rr) gk[rr] = sh.G[k][3 * rr + i];
+#pragma unroll
+          for (int e = 0; e < 9; ++e) Gl[e] = sh.G[l][e];
+          double val[3];
+          {
+            double gw[3];  // (G_k^T W)[i][m]
+#pragma unroll
+            for (int m = 0; m < 3; ++m) gw[m] = gk[0] * Wv[sym6(0, m)] + gk[1] * Wv[sym6(1, m)] + gk[2] * Wv[sym6(2, m)];
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj) val[jj] = gw[0] * Gl[jj] + gw[1] * Gl[3 + jj] + gw[2] * Gl[6 + jj];
           }
-          if (k == l && i < 2 && jj < 2) {
+          if (k == l && i < 2) {  // the pair (k,k): direction columns only
             const double* Ts = sh.cls[k * MCX + k];
+            double gw[3];
 #pragma unroll
-            for (int rr = 0; rr < 3; ++rr) {
-              double wg = 0.0;
+            for (int m = 0; m < 3; ++m) gw[m] = gk[0] * Ts[sym6(0, m)] + gk[1] * Ts[sym6(1, m)] + gk[2] * Ts[sym6(2, m)];
 #pragma unroll
-              for (int m = 0; m < 3; ++m) wg += Ts[sym6(rr, m)] * sh.G[k][3 * m + jj];
-              val += sh.G[k][3 * rr + i] * wg;
-            }
+            for (int jj = 0; jj < 2; ++jj) val[jj] += gw[0] * Gl[jj] + gw[1] * Gl[3 + jj] + gw[2] * Gl[6 + jj];
           }
           double* __restrict__ Hw = sh.hsel ? sh.st.H : sh.Hz;
-          Hw[(3 * k + i) * MVO_MAXC + 3 * l + jj] = val;
-          Hw[(3 * l + jj) * MVO_MAXC + 3 * k + i] = val;
+#pragma unroll
+          for (int jj = 0; jj < 3; ++jj)
+            if (k != l || jj >= i) {  // diagonal blocks: the upper entry is mirrored, H stays symmetric
+              Hw[(3 * k + i) * MVO_MAXC + 3 * l + jj] = val[jj];
+              Hw[(3 * l + jj) * MVO_MAXC + 3 * k + i] = val[jj];
+            }
         } else {
           const int k = (item - nB) / 3, i = (item - nB) - 3 * k;
           double gi = sh.G[k][i] * sh.y[k][0] + sh.G[k][3 + i] * sh.y[k][1] + sh.G[k][6 + i] * sh.y[k][2];
@@ -895,7 +936,7 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
       LmRegs r;
       regs_load(r, sh.st, sh.hsel ? sh.Hz : sh.st.H, fix, n, lane);
       int hsel = sh.hsel;
-      const int go = lm_advance_body(r, sh, prm, M, n, lane, (w == 0) ? trace : nullptr, hsel);
+      const int go = lm_advance_body(r, sh, prm, M, n, lane, (w == 0) ? trace : nullptr, hsel MVO_STAMP_ARG);
       regs_store(r, sh.st, lane);
       if (lane == 0) {
         sh.go = go;
@@ -928,6 +969,10 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
   }
   for (int i = tid; i < (int)(sizeof(LmState) / 8); i += NT)
     reinterpret_cast<double*>(gst)[i] = reinterpret_cast<const double*>(&sh.st)[i];
+#ifdef MVO_LM_STAMPS
+  __syncthreads();
+  if (w == 0 && tid < 16) mvo_lm_stamps[tid] += stamp_lds_[tid];
+#endif
   if (wave0 && sh.st.status != 0) {
     const LmState& st = sh.st;
     LmResult* __restrict__ res = results + w;

@@ -63,7 +63,12 @@ def test_two_shards_equal_single_solve(solver, oracle, use_loss):
     assert np.abs(refined(f0[0], 5) - refined(fs, 5)).max() < 1e-9           # summation order only
     fo, so, _ = oracle.refine(w, oracle.make_options(**kw))
     assert np.abs(refined(f0[0], 5) - refined(fo, 5)).max() < 1e-6
-    assert s0[0].iterations == so.iterations == 10
+    assert so.iterations == 10
+    if s0[0].iterations != 10:
+        # tolerances 0: the loop can only stop early on an exactly zero cost change or step,
+        # i.e. once the iterate is converged to the last bit (rounding decides when that happens)
+        assert s0[0].termination == 0 and s0[0].iterations >= 5
+        assert abs(s0[0].final_cost - so.final_cost) <= 1e-12 * so.final_cost
 
 
 def test_default_tolerances_terminate_on_all_ranks(oracle):
