@@ -92,16 +92,16 @@ __device__ __forceinline__ double row0_max(double v) {
   return bcast_lane(v, 0);
 }
 
-// s(t) and s'(t) of IR.cpp:298-309 with one exp (same expressions as d_scale / d_dscale)
+// s(t) and s'(t) of IR.cpp:298-309 with one exp and one reciprocal
 __device__ __forceinline__ void d_scale_both(double t, double max_len, double min_len, double& s, double& sp) {
   const double e = exp(-1.0 * t);
   if (isinf(e)) {
     s = min_len;
     sp = 0.0;
   } else {
-    const double g = 1.0 + e;
-    s = min_len + ((max_len - min_len) / g);
-    sp = (-(max_len - min_len) / (g * g)) * (-e);
+    const double rg = fast_rcp(1.0 + e);  // 1 <= 1 + e < inf: the fast reciprocal is within 1 ulp
+    s = min_len + ((max_len - min_len) * rg);
+    sp = ((max_len - min_len) * rg) * (rg * e);
   }
 }
 
@@ -593,7 +593,7 @@ __device__ __forceinline__ void pair_eval(const PairIn& in, const SH& sh, int M,
   by += in.off[1];
   bz += in.off[2];
   const double nb = sqrt(bx * bx + by * by + bz * bz);
-  const double inb = 1.0 / nb, inb2 = inb * inb;
+  const double inb = fast_rcp(nb), inb2 = inb * inb;
   const double u0 = bx * inb, u1 = by * inb, u2 = bz * inb;
   const double* S = in.S;
   const double Su0 = S[0] * u0 + S[1] * u1 + S[2] * u2;
