@@ -1,0 +1,115 @@
+"""Self-checks of the bundle-adjustment oracle (oracle/mvo_ba_oracle.c).  PARITY UNPINNED: the
+reference has no explicit-landmark BA, so the oracle is pinned by finite
+differences, by an independent dense numpy assembly of the normal equations, and by recovering
+noise-free synthetic scenes."""
+import numpy as np
+import pytest
+
+import mvo_ba_oracle_py as bo
+from mvo_amd import ba_scene
+
+
+def _small():
+    return ba_scene.make_ba_scene(6, 4, 40, seed=5)
+
+
+def test_observation_jacobian_matches_central_differences():
+    sc = _small()
+    rng = np.random.default_rng(0)
+    for o in rng.integers(0, sc.n_observations, 8):
+        j = int(np.searchsorted(sc.lm_offsets, o, side="right") - 1)
+        pose, X, ray = sc.poses[sc.obs_frame[o]], sc.X[j], sc.obs_ray[o]
+        r, jc, jx = bo.obs_jacobian(pose, X, ray)
+        h = 1e-6
+        for k in range(6):
+            d = np.zeros(6); d[k] = h
+            rp, _, _ = bo.obs_jacobian(bo.pose_plus(pose, d), X, ray)
+            rm, _, _ = bo.obs_jacobian(bo.pose_plus(pose, -d), X, ray)
+            assert np.allclose((rp - rm) / (2 * h), jc[:, k], rtol=1e-6, atol=1e-8)
+        for k in range(3):
+            d = np.zeros(3); d[k] = h
+            rp, _, _ = bo.obs_jacobian(pose, X + d, ray)
+            rm, _, _ = bo.obs_jacobian(pose, X - d, ray)
+            assert np.allclose((rp - rm) / (2 * h), jx[:, k], rtol=1e-6, atol=1e-8)
+
+
+def test_pose_plus_is_a_rotation_and_reduces_to_identity():
+    sc = _small()
+    p = bo.pose_plus(sc.poses[0], np.array([0.01, -0.02, 0.03, 1.0, 2.0, 3.0]))
+    R = p[:9].reshape(3, 3)
+    assert np.allclose(R @ R.T, np.eye(3), atol=1e-14) and np.isclose(np.linalg.det(R), 1.0)
+    assert np.allclose(p[9:], sc.poses[0, 9:] + [1.0, 2.0, 3.0])
+    assert np.array_equal(bo.pose_plus(sc.poses[1], np.zeros(6)), sc.poses[1])
+
+
+@pytest.mark.parametrize("loss", [0, 1, 2])
+def test_reduced_system_equals_dense_schur_complement(loss):
+    """Assemble the full (6M + 3L) normal equations densely in numpy from the oracle's per-observation
+    Jacobians and eliminate the landmarks with numpy: S, rhs must match the oracle's."""
+    sc = _small()
+    opt = bo.make_options(loss=loss, loss_scale=0.002)
+    radius = 37.0
+    M, L = sc.M, sc.n_landmarks
+    n = 6 * M + 3 * L
+    H, g, cost = np.zeros((n, n)), np.zeros(n), 0.0
+    for j in range(L):
+        for o in range(int(sc.lm_offsets[j]), int(sc.lm_offsets[j + 1])):
+            f = int(sc.obs_frame[o])
+            r, jc, jx = bo.obs_jacobian(sc.poses[f], sc.X[j], sc.obs_ray[o])
+            s = float(r @ r)
+            a = opt.loss_scale
+            if loss == 1:
+                w, rho = 1 / (1 + s / a**2), a**2 * np.log1p(s / a**2)
+            elif loss == 2 and s > a**2:
+                w, rho = a / np.sqrt(s), 2 * a * np.sqrt(s) - a**2
+            else:
+                w, rho = 1.0, s
+            cost += 0.5 * rho
+            row = np.zeros((2, n))
+            if f < M:
+                row[:, 6 * f:6 * f + 6] = jc
+            row[:, 6 * M + 3 * j:6 * M + 3 * j + 3] = jx
+            H += w * row.T @ row
+            g += w * row.T @ r
+    D2 = np.clip(np.diag(H), 1e-6, 1e32) / radius
+    Hd = H + np.diag(D2)
+    nc = 6 * M
+    B, E, Cm = Hd[:nc, :nc], Hd[:nc, nc:], Hd[nc:, nc:]
+    S_ref = B - E @ np.linalg.solve(Cm, E.T)
+    rhs_ref = g[:nc] - E @ np.linalg.solve(Cm, g[nc:])
+    S, rhs, grad, c = bo.reduced(sc, opt, radius)
+    assert np.isclose(c, cost, rtol=1e-12)
+    assert np.allclose(grad, g, rtol=1e-10, atol=1e-14)
+    assert np.allclose(S, S_ref, rtol=1e-9, atol=1e-9 * np.abs(S_ref).max())
+    assert np.allclose(rhs, rhs_ref, rtol=1e-9, atol=1e-9 * np.abs(rhs_ref).max())
+    assert np.allclose(S, S.T, atol=1e-12 * np.abs(S).max())
+
+
+def test_noise_free_scene_is_recovered():
+    sc = ba_scene.make_ba_scene(8, 6, 120, seed=11, noise_sigma=0.0)
+    opt = bo.make_options(max_num_iterations=30, function_tolerance=1e-16, gradient_tolerance=1e-14,
+                          parameter_tolerance=1e-14)
+    poses, X, s, tr = bo.refine(sc, opt)
+    assert s.final_cost < 1e-20 < s.initial_cost
+    assert np.abs(poses[:, 9:] - sc.true_poses[:, 9:]).max() < 1e-8
+    assert np.abs(poses[:, :9] - sc.true_poses[:, :9]).max() < 1e-9
+    assert np.abs(X - sc.true_X).max() < 1e-6
+    assert all(a.cost >= b.cost for a, b in zip(tr, tr[1:]))  # monotonic
+
+
+def test_fixed_iterations_and_trace_shape():
+    sc = ba_scene.ba_config1()
+    opt = bo.make_options(max_num_iterations=6, function_tolerance=0.0, gradient_tolerance=0.0,
+                          parameter_tolerance=0.0)
+    poses, X, s, tr = bo.refine(sc, opt)
+    assert s.iterations == 6 and s.termination == 1 and len(tr) == 7
+    assert s.final_cost < 0.01 * s.initial_cost
+    assert np.array_equal(poses[sc.M:], sc.poses[sc.M:])  # fixed frames untouched
+
+
+def test_outliers_with_cauchy_beat_plain_least_squares():
+    sc = ba_scene.make_ba_scene(10, 8, 200, seed=13, outlier_fraction=0.1)
+    plain = bo.refine(sc, bo.make_options(max_num_iterations=25))
+    robust = bo.refine(sc, bo.make_options(max_num_iterations=25, loss=1, loss_scale=0.003))
+    err = lambda p: np.abs(p[:sc.M, 9:] - sc.true_poses[:sc.M, 9:]).max()
+    assert err(robust[0]) < 0.3 * err(plain[0])
