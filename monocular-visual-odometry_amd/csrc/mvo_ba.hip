@@ -1,0 +1,1206 @@
+// mvo_ba.hip -- explicit-landmark window bundle adjustment on gfx950: the C ABI of
+// include/mvo_hip_ba.h.  No counterpart in the reference; the
+// problem statement and solver rules are written down in include/mvo_hip_ba.h.  No CPU fallback:
+// every entry point needs a HIP device.
+//
+// One LM iteration = five launches, enqueued without host round trips:
+//   k_ba_schur    one WAVEFRONT per landmark: per-observation residual + analytic Jacobians,
+//                 landmark block C_j (wave reduction), (C_j + D)^-1, Y = E C^-1, and the outer
+//                 products Y_s E_s'^T accumulated into the workgroup's copy of the reduced camera
+//                 system in LDS (ds_add_f64 -- LDS atomics, never global ones)
+//   k_ba_reduce   sums the per-workgroup copies (fixed order)
+//   k_ba_solve    one workgroup: damping, dense Cholesky of the <= 168 x 168 system in LDS with the
+//                 right-hand side as an extra row, back substitution, candidate poses
+//   k_ba_step     one wavefront per landmark: back substitution of the landmark step, candidate
+//                 landmark, cost at the candidate
+//   k_ba_decide   trust-region accept/reject on the device-resident state
+#include "../../include/mvo_hip_ba.h"
+#include "../../include/mvo_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "mvo_wave.h"
+
+#define BA_THREADS 256
+#define BA_WAVES 4
+#define BA_MAXF MVO_HIP_BA_MAX_FREE_FRAMES
+#define BA_STAGE 37                      // doubles per free observation in a wave's LDS stage
+#define BA_WAVE_LDS (BA_STAGE * BA_MAXF + 12)
+#define BA_SOLVE_THREADS 512
+#define BA_NOSLOT 0xFFFFu
+
+struct BaParams {
+  double ftol, gtol, ptol, loss_scale, initial_radius;
+  int32_t max_it, loss, M, N;
+  uint32_t L, n_blk, n_wg, trace_cap;
+};
+
+struct BaState {
+  double radius, decf, cost, initial_cost, gmax, mcc_c, step2_c, xnorm2_c;
+  int32_t cur, iteration, status, termination, nsucc, nunsucc, num_invalid, step_bad, ntrace, pad;
+};
+
+struct BaTrace {  // == mvo_hip_ba_iteration
+  double cost, cost_change, gradient_max_norm, step_norm, relative_decrease, trust_region_radius;
+  int32_t step_is_valid, step_is_successful;
+};
+static_assert(sizeof(BaTrace) == sizeof(mvo_hip_ba_iteration), "trace record layout");
+static_assert(sizeof(mvo_hip_ba_pose) == 96, "pose record layout");
+
+// ---------------------------------------------------------------------------------------------
+// device math
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double ba_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+
+__device__ __forceinline__ void ba_loss(int loss, double a, double s, double& rho, double& w) {
+  const double b = a * a;
+  if (loss == MVO_HIP_BA_LOSS_CAUCHY) {
+    rho = b * log(1.0 + s / b);
+    w = 1.0 / (1.0 + s / b);
+  } else if (loss == MVO_HIP_BA_LOSS_HUBER && s > b) {
+    const double rt = sqrt(s);
+    rho = 2.0 * a * rt - b;
+    w = a / rt;
+  } else {
+    rho = s;
+    w = 1.0;
+  }
+}
+
+// q = R^T (X - p), residual against the normalised image point (u, v)
+__device__ __forceinline__ void ba_project(const double* __restrict__ pose, const double X[3], double& a, double& b,
+                                           double& c) {
+  const double d0 = X[0] - pose[9], d1 = X[1] - pose[10], d2 = X[2] - pose[11];
+  a = pose[0] * d0 + pose[3] * d1 + pose[6] * d2;
+  b = pose[1] * d0 + pose[4] * d1 + pose[7] * d2;
+  c = pose[2] * d0 + pose[5] * d1 + pose[8] * d2;
+}
+
+struct BaObs {
+  double r0, r1, w, rho;
+  double jc[12];  // 2 x 6: omega, p
+  double jx[6];   // 2 x 3
+};
+
+__device__ __forceinline__ void ba_obs_eval(const double* __restrict__ pose, const double X[3], double u, double v,
+                                            int loss, double ls, BaObs& e) {
+  double a, b, c;
+  ba_project(pose, X, a, b, c);
+  const double ic = ba_rcp(c);
+  const double ai = a * ic, bi = b * ic;
+  e.r0 = ai - u;
+  e.r1 = bi - v;
+  ba_loss(loss, ls, e.r0 * e.r0 + e.r1 * e.r1, e.rho, e.w);
+  // J_X = Pi R^T with Pi = [[1/c, 0, -a/c^2], [0, 1/c, -b/c^2]]
+  const double pa = -ai * ic, pb = -bi * ic;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    e.jx[k] = ic * pose[3 * k] + pa * pose[3 * k + 2];
+    e.jx[3 + k] = ic * pose[3 * k + 1] + pb * pose[3 * k + 2];
+    e.jc[3 + k] = -e.jx[k];  // J_p = -J_X
+    e.jc[9 + k] = -e.jx[3 + k];
+  }
+  // J_omega = Pi [q]x for R <- R Exp(omega)
+  e.jc[0] = ai * bi;
+  e.jc[1] = -1.0 - ai * ai;
+  e.jc[2] = bi;
+  e.jc[6] = 1.0 + bi * bi;
+  e.jc[7] = -ai * bi;
+  e.jc[8] = -ai;
+}
+
+__device__ __forceinline__ double ba_clamp_diag(double v) { return fmin(fmax(v, 1e-6), 1e32); }
+
+// inverse of a symmetric 3x3 given as (xx, xy, xz, yy, yz, zz); same packing out
+__device__ __forceinline__ void ba_inv3(const double C[6], double Ci[6]) {
+  const double co0 = C[3] * C[5] - C[4] * C[4], co1 = C[2] * C[4] - C[1] * C[5], co2 = C[1] * C[4] - C[2] * C[3];
+  const double id = 1.0 / (C[0] * co0 + C[1] * co1 + C[2] * co2);
+  Ci[0] = co0 * id;
+  Ci[1] = co1 * id;
+  Ci[2] = co2 * id;
+  Ci[3] = (C[0] * C[5] - C[2] * C[2]) * id;
+  Ci[4] = (C[1] * C[2] - C[0] * C[4]) * id;
+  Ci[5] = (C[0] * C[3] - C[1] * C[1]) * id;
+}
+
+// upper block triangle of the reduced camera system, block-row-major, 36 doubles per block
+__device__ __host__ __forceinline__ uint32_t ba_blk(uint32_t M, uint32_t f, uint32_t f2) {  // f <= f2
+  return f * M - (f * (f - 1)) / 2 + (f2 - f);
+}
+
+__device__ __forceinline__ double ba_wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double ba_wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ void lds_add(double* p, double v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_ba_schur
+// partS[g][n_blk * 36], partV[g][18 M + 2] = rhs(6M) | g_c(6M) | diag(B)(6M) | cost | gmax(landmarks)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BA_THREADS) void k_ba_schur(BaParams prm, const BaState* __restrict__ st,
+                                                        double radius_override,
+                                                        const double* __restrict__ poses2,
+                                                        const double* __restrict__ X2,
+                                                        const uint32_t* __restrict__ lm_off,
+                                                        const uint32_t* __restrict__ lm_nfree,
+                                                        const uint32_t* __restrict__ obs_frame,
+                                                        const double2* __restrict__ obs_uv,
+                                                        const uint32_t* __restrict__ wg_lm,
+                                                        double* __restrict__ partS, double* __restrict__ partV) {
+  extern __shared__ double lds[];
+  if (st->status != 0) return;
+  const int M = prm.M, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t nS = prm.n_blk * 36, nV = 18 * M;
+  double* S = lds;
+  double* V = S + nS;  // rhs | gc | bdiag
+  double* my = V + nV + (size_t)wave * BA_WAVE_LDS;
+  __shared__ double red[2 * BA_WAVES];
+  for (uint32_t i = tid; i < nS + nV; i += BA_THREADS) lds[i] = 0.0;
+  __syncthreads();
+  const int cur = st->cur;
+  const double radius = radius_override > 0.0 ? radius_override : st->radius;
+  const double inv_radius = 1.0 / radius;
+  const double* __restrict__ poses = poses2 + (size_t)cur * 12 * prm.N;
+  const double* __restrict__ Xs = X2 + (size_t)cur * 3 * prm.L;
+  const uint32_t g = blockIdx.x;
+  double cost_acc = 0.0, gmax_acc = 0.0;
+  for (uint32_t lm = wg_lm[g] + wave; lm < wg_lm[g + 1]; lm += BA_WAVES) {
+    const uint32_t o0 = lm_off[lm], T = lm_off[lm + 1] - o0, Tf = lm_nfree[lm];
+    const double X[3] = {Xs[3 * lm], Xs[3 * lm + 1], Xs[3 * lm + 2]};
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, acc8 = 0.0;  // C(6) gl(2) | gl[2]
+    for (uint32_t base = 0; base < T; base += 64) {
+      const uint32_t t = base + lane;
+      if (t < T) {
+        const uint32_t word = obs_frame[o0 + t], f = word & 0xFFFFu, slot = word >> 16;
+        const double2 uv = obs_uv[o0 + t];
+        BaObs e;
+        ba_obs_eval(poses + 12 * f, X, uv.x, uv.y, prm.loss, prm.loss_scale, e);
+        cost_acc += 0.5 * e.rho;
+        const double w = e.w;
+        acc[0] += w * (e.jx[0] * e.jx[0] + e.jx[3] * e.jx[3]);
+        acc[1] += w * (e.jx[0] * e.jx[1] + e.jx[3] * e.jx[4]);
+        acc[2] += w * (e.jx[0] * e.jx[2] + e.jx[3] * e.jx[5]);
+        acc[3] += w * (e.jx[1] * e.jx[1] + e.jx[4] * e.jx[4]);
+        acc[4] += w * (e.jx[1] * e.jx[2] + e.jx[4] * e.jx[5]);
+        acc[5] += w * (e.jx[2] * e.jx[2] + e.jx[5] * e.jx[5]);
+        acc[6] += w * (e.jx[0] * e.r0 + e.jx[3] * e.r1);
+        acc[7] += w * (e.jx[1] * e.r0 + e.jx[4] * e.r1);
+        acc8 += w * (e.jx[2] * e.r0 + e.jx[5] * e.r1);
+        if (slot != BA_NOSLOT) {
+          double* sg = my + slot * BA_STAGE;
+#pragma unroll
+          for (int p = 0; p < 6; ++p)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) sg[3 * p + q] = w * (e.jc[p] * e.jx[q] + e.jc[6 + p] * e.jx[3 + q]);  // E
+          sg[36] = (double)f;
+          double* Bff = S + ba_blk(M, f, f) * 36;
+#pragma unroll
+          for (int p = 0; p < 6; ++p) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) lds_add(Bff + 6 * p + q, w * (e.jc[p] * e.jc[q] + e.jc[6 + p] * e.jc[6 + q]));
+            const double gcp = w * (e.jc[p] * e.r0 + e.jc[6 + p] * e.r1);
+            lds_add(V + 6 * f + p, gcp);
+            lds_add(V + 6 * M + 6 * f + p, gcp);
+            lds_add(V + 12 * M + 6 * f + p, w * (e.jc[p] * e.jc[p] + e.jc[6 + p] * e.jc[6 + p]));
+          }
+        }
+      }
+    }
+    double tot[8];
+    wave_reduce8_all(acc, lane, tot);
+    const double gl2 = ba_wave_sum(acc8);
+    const double gl[3] = {tot[6], tot[7], gl2};
+    gmax_acc = fmax(gmax_acc, fmax(fabs(gl[0]), fmax(fabs(gl[1]), fabs(gl[2]))));
+    if (Tf == 0) continue;  // seen from fixed frames only: nothing for the camera system
+    double C[6] = {tot[0], tot[1], tot[2], tot[3], tot[4], tot[5]}, Ci[6];
+    C[0] += ba_clamp_diag(C[0]) * inv_radius;
+    C[3] += ba_clamp_diag(C[3]) * inv_radius;
+    C[5] += ba_clamp_diag(C[5]) * inv_radius;
+    ba_inv3(C, Ci);
+    __builtin_amdgcn_wave_barrier();
+    if ((uint32_t)lane < Tf) {  // Y = E C^-1, rhs -= Y g_l
+      double* sg = my + lane * BA_STAGE;
+      const int f = (int)sg[36];
+#pragma unroll
+      for (int p = 0; p < 6; ++p) {
+        const double e0 = sg[3 * p], e1 = sg[3 * p + 1], e2 = sg[3 * p + 2];
+        const double y0 = e0 * Ci[0] + e1 * Ci[1] + e2 * Ci[2];
+        const double y1 = e0 * Ci[1] + e1 * Ci[3] + e2 * Ci[4];
+        const double y2 = e0 * Ci[2] + e1 * Ci[4] + e2 * Ci[5];
+        sg[18 + 3 * p] = y0;
+        sg[18 + 3 * p + 1] = y1;
+        sg[18 + 3 * p + 2] = y2;
+        lds_add(V + 6 * f + p, -(y0 * gl[0] + y1 * gl[1] + y2 * gl[2]));
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t npairs = (Tf * (Tf + 1)) / 2;
+    for (uint32_t q = lane; q < npairs; q += 64) {
+      // q = s2 (s2 + 1) / 2 + s, s <= s2 (slots are sorted by frame on upload)
+      uint32_t s2 = (uint32_t)((sqrtf(8.0f * (float)q + 1.0f) - 1.0f) * 0.5f);
+      while ((s2 + 1) * (s2 + 2) / 2 <= q) ++s2;
+      while (s2 * (s2 + 1) / 2 > q) --s2;
+      const uint32_t s = q - s2 * (s2 + 1) / 2;
+      const double* ys = my + s * BA_STAGE + 18;
+      const double* es = my + s2 * BA_STAGE;
+      const uint32_t f = (uint32_t)my[s * BA_STAGE + 36], f2 = (uint32_t)my[s2 * BA_STAGE + 36];
+      double Y[18], E[18];
+#pragma unroll
+      for (int i = 0; i < 18; ++i) {
+        Y[i] = ys[i];
+        E[i] = es[i];
+      }
+      double* blk = S + ba_blk(M, f, f2) * 36;
+      const bool twin = (f == f2) && (s != s2);  // two observations of the landmark in one frame
+#pragma unroll
+      for (int p = 0; p < 6; ++p)
+#pragma unroll
+        for (int c2 = 0; c2 < 6; ++c2) {
+          const double v = -(Y[3 * p] * E[3 * c2] + Y[3 * p + 1] * E[3 * c2 + 1] + Y[3 * p + 2] * E[3 * c2 + 2]);
+          lds_add(blk + 6 * p + c2, v);
+          if (twin) lds_add(blk + 6 * c2 + p, v);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  // workgroup totals
+  cost_acc = ba_wave_sum(cost_acc);
+  gmax_acc = ba_wave_max(gmax_acc);
+  if (lane == 0) {
+    red[wave] = cost_acc;
+    red[BA_WAVES + wave] = gmax_acc;
+  }
+  __syncthreads();
+  double* __restrict__ oS = partS + (size_t)g * nS;
+  double* __restrict__ oV = partV + (size_t)g * (nV + 2);
+  for (uint32_t i = tid; i < nS; i += BA_THREADS) oS[i] = S[i];
+  for (uint32_t i = tid; i < nV; i += BA_THREADS) oV[i] = V[i];
+  if (tid == 0) {
+    oV[nV] = (red[0] + red[1]) + (red[2] + red[3]);
+    oV[nV + 1] = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
+  }
+}
+
+// sums the per-workgroup copies in workgroup order; the last entry of V is a maximum
+__global__ __launch_bounds__(256) void k_ba_reduce(BaParams prm, const BaState* __restrict__ st,
+                                                  const double* __restrict__ partS,
+                                                  const double* __restrict__ partV, double* __restrict__ redS,
+                                                  double* __restrict__ redV) {
+  if (st->status != 0) return;
+  const uint32_t nS = prm.n_blk * 36, nV = 18 * prm.M + 2;
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < nS) {
+    double a = 0.0;
+    for (uint32_t g = 0; g < prm.n_wg; ++g) a += partS[(size_t)g * nS + i];
+    redS[i] = a;
+  } else if (i < nS + nV) {
+    const uint32_t k = i - nS;
+    double a = 0.0;
+    if (k == nV - 1)
+      for (uint32_t g = 0; g < prm.n_wg; ++g) a = fmax(a, partV[(size_t)g * nV + k]);
+    else
+      for (uint32_t g = 0; g < prm.n_wg; ++g) a += partV[(size_t)g * nV + k];
+    redV[k] = a;
+  }
+}
+
+// R <- R Exp(w), p <- p + dp
+__device__ __forceinline__ void ba_pose_plus(const double* __restrict__ in, const double d[6], double* __restrict__ out) {
+  const double wx = d[0], wy = d[1], wz = d[2];
+  const double th2 = wx * wx + wy * wy + wz * wz, th = sqrt(th2);
+  double A, B;
+  if (th < 1e-8) {
+    A = 1.0 - th2 / 6.0;
+    B = 0.5 - th2 / 24.0;
+  } else {
+    A = sin(th) / th;
+    B = (1.0 - cos(th)) / th2;
+  }
+  const double E[9] = {1.0 - B * (wy * wy + wz * wz), -A * wz + B * wx * wy, A * wy + B * wx * wz,
+                       A * wz + B * wx * wy, 1.0 - B * (wx * wx + wz * wz), -A * wx + B * wy * wz,
+                       -A * wy + B * wx * wz, A * wx + B * wy * wz, 1.0 - B * (wx * wx + wy * wy)};
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) out[3 * i + j] = in[3 * i] * E[j] + in[3 * i + 1] * E[3 + j] + in[3 * i + 2] * E[6 + j];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) out[9 + k] = in[9 + k] + d[3 + k];
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_ba_solve: one workgroup.  Packed lower triangle of the damped system plus the right-hand side
+// as row n in LDS; right-looking Cholesky; the forward substitution falls out of the extra row;
+// the back substitution runs in wavefront 0 without barriers.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t tri(uint32_t i, uint32_t j) { return (i * (i + 1)) / 2 + j; }  // j <= i
+
+__global__ __launch_bounds__(BA_SOLVE_THREADS) void k_ba_solve(BaParams prm, BaState* __restrict__ st,
+                                                              const double* __restrict__ redS,
+                                                              const double* __restrict__ redV,
+                                                              double* __restrict__ poses2,
+                                                              double* __restrict__ delta_c) {
+  extern __shared__ double A[];  // (n + 1)(n + 2) / 2
+  __shared__ double xs[6 * BA_MAXF], dc2[6 * BA_MAXF];
+  __shared__ int bad_flag;
+  if (st->status != 0) return;
+  const uint32_t M = prm.M, n = 6 * M, tid = threadIdx.x;
+  const double radius = st->radius;
+  // gradient tolerance first: it is tested at the top of an iteration
+  double gm = redV[18 * M + 1];
+  for (uint32_t i = 0; i < n; ++i) gm = fmax(gm, fabs(redV[6 * M + i]));  // uniform, L2-resident
+  if (gm <= prm.gtol) {
+    if (tid == 0) {
+      st->gmax = gm;
+      st->status = 1;
+      st->termination = 0;
+    }
+    return;
+  }
+  if (tid == 0) bad_flag = 0;
+  for (uint32_t e = tid; e < (n + 1) * (n + 2) / 2; e += BA_SOLVE_THREADS) {
+    // e -> (i, j), j <= i
+    uint32_t i = (uint32_t)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+    while ((i + 1) * (i + 2) / 2 <= e) ++i;
+    while (i * (i + 1) / 2 > e) --i;
+    const uint32_t j = e - i * (i + 1) / 2;
+    double v;
+    if (i == n) {
+      v = j < n ? redV[j] : 0.0;
+    } else {
+      const uint32_t fi = i / 6, fj = j / 6;
+      v = redS[ba_blk(M, fj, fi) * 36 + (j - 6 * fj) * 6 + (i - 6 * fi)];
+      if (i == j) {
+        const double d2 = ba_clamp_diag(redV[12 * M + i]) / radius;
+        v += d2;
+        dc2[i] = d2;
+      }
+    }
+    A[e] = v;
+  }
+  __syncthreads();
+  for (uint32_t k = 0; k < n; ++k) {
+    const double d = A[tri(k, k)];
+    if (!(d > 0.0) || isinf(d)) {
+      if (tid == 0) bad_flag = 1;
+      break;  // uniform
+    }
+    const double inv = 1.0 / sqrt(d);
+    __syncthreads();  // every thread has read the pivot
+    for (uint32_t i = k + tid; i <= n; i += BA_SOLVE_THREADS) A[tri(i, k)] *= inv;  // L[k..n][k]; [k][k] = sqrt(d)
+    __syncthreads();
+    // trailing update: rows i in (k, n], columns j in (k, i]
+    const uint32_t m = n - k;  // rows
+    for (uint32_t e = tid; e < m * (m + 1) / 2; e += BA_SOLVE_THREADS) {
+      uint32_t a = (uint32_t)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+      while ((a + 1) * (a + 2) / 2 <= e) ++a;
+      while (a * (a + 1) / 2 > e) --a;
+      const uint32_t b = e - a * (a + 1) / 2;
+      const uint32_t i = k + 1 + a, j = k + 1 + b;
+      A[tri(i, j)] -= A[tri(i, k)] * A[tri(j, k)];
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  const bool bad = bad_flag != 0;
+  if (tid < 64 && !bad) {
+    // back substitution L^T x = y (y = row n), lanes own components lane, lane + 64, lane + 128
+    double y[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const uint32_t i = tid + 64 * c;
+      y[c] = i < n ? A[tri(n, i)] : 0.0;
+    }
+    for (int k = (int)n - 1; k >= 0; --k) {
+      const int c = k >> 6, src = k & 63;
+      const double yk = c == 0 ? y[0] : (c == 1 ? y[1] : y[2]);
+      const double xk = __shfl(yk, src, 64) / A[tri(k, k)];
+      if ((int)tid == src) xs[k] = xk;
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) {
+        const int j = (int)tid + 64 * cc;
+        if (j < k) y[cc] -= A[tri(k, j)] * xk;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {
+    double mcc = 0.0, s2 = 0.0, xn2 = 0.0;
+    bool nonfinite = false;
+    if (!bad) {
+      for (uint32_t i = tid; i < n; i += 64) {
+        const double dcv = -xs[i];
+        if (!isfinite(dcv)) nonfinite = true;
+        delta_c[i] = dcv;
+        mcc += dcv * (dc2[i] * dcv - redV[6 * M + i]);
+        s2 += dcv * dcv;
+      }
+      const int cur = st->cur;
+      if (tid < M) {
+        double d[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) d[q] = -xs[6 * tid + q];
+        const double* in = poses2 + ((size_t)cur * prm.N + tid) * 12;
+        ba_pose_plus(in, d, poses2 + ((size_t)(1 - cur) * prm.N + tid) * 12);
+        xn2 = in[9] * in[9] + in[10] * in[10] + in[11] * in[11];
+      }
+    }
+    mcc = ba_wave_sum(mcc);
+    s2 = ba_wave_sum(s2);
+    xn2 = ba_wave_sum(xn2);
+    const bool any_nonfinite = __any(nonfinite);
+    if (tid == 0) {
+      st->iteration += 1;
+      st->gmax = gm;
+      st->step_bad = (bad || any_nonfinite) ? 1 : 0;
+      st->mcc_c = mcc;
+      st->step2_c = s2;
+      st->xnorm2_c = xn2;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_ba_step: mode 0 = cost at the current point (start of a solve); mode 1 = landmark back
+// substitution dl = -(C + D)^-1 (g_l + E^T dc), candidate landmark, cost at the candidate.
+// partT[g][4] = cost | model-cost-change part | |dl|^2 | |X|^2
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BA_THREADS) void k_ba_step(BaParams prm, const BaState* __restrict__ st, int mode,
+                                                       const double* __restrict__ poses2, double* __restrict__ X2,
+                                                       const double* __restrict__ delta_c,
+                                                       const uint32_t* __restrict__ lm_off,
+                                                       const uint32_t* __restrict__ obs_frame,
+                                                       const double2* __restrict__ obs_uv,
+                                                       const uint32_t* __restrict__ wg_lm,
+                                                       double* __restrict__ partT) {
+  __shared__ double red[4 * BA_WAVES];
+  if (st->status != 0) return;
+  if (mode == 1 && st->step_bad) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cur = st->cur, M = prm.M;
+  const double inv_radius = 1.0 / st->radius;
+  const double* __restrict__ poses = poses2 + (size_t)cur * 12 * prm.N;
+  const double* __restrict__ posesc = poses2 + (size_t)(1 - cur) * 12 * prm.N;
+  const double* __restrict__ Xs = X2 + (size_t)cur * 3 * prm.L;
+  double* __restrict__ Xc = X2 + (size_t)(1 - cur) * 3 * prm.L;
+  const uint32_t g = blockIdx.x;
+  double cost_acc = 0.0, mcc_acc = 0.0, s2_acc = 0.0, xn2_acc = 0.0;  // the last three: wave-uniform
+  for (uint32_t lm = wg_lm[g] + wave; lm < wg_lm[g + 1]; lm += BA_WAVES) {
+    const uint32_t o0 = lm_off[lm], T = lm_off[lm + 1] - o0;
+    const double X[3] = {Xs[3 * lm], Xs[3 * lm + 1], Xs[3 * lm + 2]};
+    double Xn[3] = {X[0], X[1], X[2]};
+    if (mode == 1) {
+      double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, acc2[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // C(6) gl(2) | gl[2] t(3)
+      for (uint32_t base = 0; base < T; base += 64) {
+        const uint32_t t = base + lane;
+        if (t < T) {
+          const uint32_t word = obs_frame[o0 + t], f = word & 0xFFFFu;
+          const double2 uv = obs_uv[o0 + t];
+          BaObs e;
+          ba_obs_eval(poses + 12 * f, X, uv.x, uv.y, prm.loss, prm.loss_scale, e);
+          const double w = e.w;
+          acc[0] += w * (e.jx[0] * e.jx[0] + e.jx[3] * e.jx[3]);
+          acc[1] += w * (e.jx[0] * e.jx[1] + e.jx[3] * e.jx[4]);
+          acc[2] += w * (e.jx[0] * e.jx[2] + e.jx[3] * e.jx[5]);
+          acc[3] += w * (e.jx[1] * e.jx[1] + e.jx[4] * e.jx[4]);
+          acc[4] += w * (e.jx[1] * e.jx[2] + e.jx[4] * e.jx[5]);
+          acc[5] += w * (e.jx[2] * e.jx[2] + e.jx[5] * e.jx[5]);
+          acc[6] += w * (e.jx[0] * e.r0 + e.jx[3] * e.r1);
+          acc[7] += w * (e.jx[1] * e.r0 + e.jx[4] * e.r1);
+          acc2[0] += w * (e.jx[2] * e.r0 + e.jx[5] * e.r1);
+          if ((int)f < M) {  // E^T dc = w J_X^T (J_c dc)
+            double jd0 = 0.0, jd1 = 0.0;
+#pragma unroll
+            for (int p = 0; p < 6; ++p) {
+              const double dcp = delta_c[6 * f + p];
+              jd0 += e.jc[p] * dcp;
+              jd1 += e.jc[6 + p] * dcp;
+            }
+            acc2[1] += w * (e.jx[0] * jd0 + e.jx[3] * jd1);
+            acc2[2] += w * (e.jx[1] * jd0 + e.jx[4] * jd1);
+            acc2[3] += w * (e.jx[2] * jd0 + e.jx[5] * jd1);
+          }
+        }
+      }
+      double tot[8], tot2[8];
+      wave_reduce8_all(acc, lane, tot);
+      wave_reduce8_all(acc2, lane, tot2);
+      const double gl[3] = {tot[6], tot[7], tot2[0]};
+      double C[6] = {tot[0], tot[1], tot[2], tot[3], tot[4], tot[5]}, Ci[6];
+      const double D[3] = {ba_clamp_diag(C[0]) * inv_radius, ba_clamp_diag(C[3]) * inv_radius,
+                           ba_clamp_diag(C[5]) * inv_radius};
+      C[0] += D[0];
+      C[3] += D[1];
+      C[5] += D[2];
+      ba_inv3(C, Ci);
+      const double t0 = gl[0] + tot2[1], t1 = gl[1] + tot2[2], t2 = gl[2] + tot2[3];
+      const double dl[3] = {-(Ci[0] * t0 + Ci[1] * t1 + Ci[2] * t2), -(Ci[1] * t0 + Ci[3] * t1 + Ci[4] * t2),
+                            -(Ci[2] * t0 + Ci[4] * t1 + Ci[5] * t2)};
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        Xn[q] = X[q] + dl[q];
+        mcc_acc += dl[q] * (D[q] * dl[q] - gl[q]);
+        s2_acc += dl[q] * dl[q];
+        xn2_acc += X[q] * X[q];
+      }
+      if (lane < 3) Xc[3 * lm + lane] = lane == 0 ? Xn[0] : (lane == 1 ? Xn[1] : Xn[2]);
+    }
+    const double* __restrict__ pp = mode == 1 ? posesc : poses;
+    for (uint32_t base = 0; base < T; base += 64) {
+      const uint32_t t = base + lane;
+      if (t < T) {
+        const uint32_t f = obs_frame[o0 + t] & 0xFFFFu;
+        const double2 uv = obs_uv[o0 + t];
+        double a, b, c;
+        ba_project(pp + 12 * f, Xn, a, b, c);
+        const double ic = ba_rcp(c);
+        const double r0 = a * ic - uv.x, r1 = b * ic - uv.y;
+        double rho, w;
+        ba_loss(prm.loss, prm.loss_scale, r0 * r0 + r1 * r1, rho, w);
+        cost_acc += 0.5 * rho;
+      }
+    }
+  }
+  cost_acc = ba_wave_sum(cost_acc);
+  if (lane == 0) {
+    red[wave] = cost_acc;
+    red[BA_WAVES + wave] = mcc_acc;
+    red[2 * BA_WAVES + wave] = s2_acc;
+    red[3 * BA_WAVES + wave] = xn2_acc;
+  }
+  __syncthreads();
+  if (tid < 4) partT[(size_t)g * 4 + tid] = (red[4 * tid] + red[4 * tid + 1]) + (red[4 * tid + 2] + red[4 * tid + 3]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_ba_decide: the trust-region rules of include/mvo_hip_ba.h on the device-resident state
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_ba_decide(BaParams prm, BaState* __restrict__ st, int mode,
+                                                 const double* __restrict__ partT, BaTrace* __restrict__ trace) {
+  if (st->status != 0) return;
+  const int lane = threadIdx.x;
+  double v[4] = {0, 0, 0, 0};
+  const bool have = mode == 0 || !st->step_bad;
+  if (have)
+    for (uint32_t g = lane; g < prm.n_wg; g += 64)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] += partT[(size_t)g * 4 + k];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = ba_wave_sum(v[k]);
+  if (lane != 0) return;
+  BaState s = *st;
+  BaTrace it;
+  it.cost = it.cost_change = it.gradient_max_norm = it.step_norm = it.relative_decrease = 0.0;
+  it.trust_region_radius = 0.0;
+  it.step_is_valid = it.step_is_successful = 0;
+  if (mode == 0) {
+    s.cost = s.initial_cost = v[0];
+    it.cost = s.cost;
+    it.trust_region_radius = s.radius;
+    it.step_is_valid = it.step_is_successful = 1;
+    if (trace && s.ntrace < (int)prm.trace_cap) trace[s.ntrace] = it;
+    ++s.ntrace;
+    if (prm.max_it <= 0) {
+      s.status = 1;
+      s.termination = 1;
+    }
+    *st = s;
+    return;
+  }
+  it.gradient_max_norm = s.gmax;
+  const double mcc = 0.5 * (s.mcc_c + v[1]);
+  const double step2 = s.step2_c + v[2];
+  bool bad = s.step_bad || !isfinite(step2) || !(mcc > 0.0);
+  if (bad) {
+    if (++s.num_invalid >= 5) {
+      s.status = 1;
+      s.termination = 2;
+    } else {
+      s.radius *= 0.5;
+      it.cost = s.cost;
+      it.trust_region_radius = s.radius;
+      ++s.nunsucc;
+      if (trace && s.ntrace < (int)prm.trace_cap) trace[s.ntrace] = it;
+      ++s.ntrace;
+      if (s.iteration >= prm.max_it) {
+        s.status = 1;
+        s.termination = 1;
+      }
+    }
+    *st = s;
+    return;
+  }
+  s.num_invalid = 0;
+  it.step_is_valid = 1;
+  it.step_norm = sqrt(step2);
+  if (it.step_norm <= prm.ptol * (sqrt(s.xnorm2_c + v[3]) + prm.ptol)) {
+    s.status = 1;
+    s.termination = 0;
+    s.iteration -= 1;
+    *st = s;
+    return;
+  }
+  const double cost_c = v[0];
+  it.cost_change = s.cost - cost_c;
+  it.relative_decrease = it.cost_change / mcc;
+  const double cost_before = s.cost;
+  if (it.relative_decrease > 1e-3) {
+    s.cur ^= 1;
+    s.cost = cost_c;
+    const double q = 2.0 * it.relative_decrease - 1.0;
+    s.radius = s.radius / fmax(1.0 / 3.0, 1.0 - q * q * q);
+    s.radius = fmin(1e16, s.radius);
+    s.decf = 2.0;
+    it.step_is_successful = 1;
+    ++s.nsucc;
+  } else {
+    s.radius = s.radius / s.decf;
+    s.decf *= 2.0;
+    ++s.nunsucc;
+  }
+  it.cost = s.cost;
+  it.trust_region_radius = s.radius;
+  if (trace && s.ntrace < (int)prm.trace_cap) trace[s.ntrace] = it;
+  ++s.ntrace;
+  if (it.step_is_successful && fabs(it.cost_change) <= prm.ftol * cost_before) {
+    s.status = 1;
+    s.termination = 0;
+  } else if (s.radius <= 1e-32) {
+    s.status = 1;
+    s.termination = 0;
+  } else if (s.iteration >= prm.max_it) {
+    s.status = 1;
+    s.termination = 1;
+  }
+  *st = s;
+}
+
+// debug: residuals of every observation at the current point, caller's observation order
+__global__ __launch_bounds__(256) void k_ba_residuals(BaParams prm, uint64_t n_obs, const double* __restrict__ poses,
+                                                     const double* __restrict__ Xs,
+                                                     const uint32_t* __restrict__ obs_lm,
+                                                     const uint32_t* __restrict__ obs_frame,
+                                                     const double2* __restrict__ obs_uv,
+                                                     const uint32_t* __restrict__ obs_src,
+                                                     double* __restrict__ out) {
+  const uint64_t o = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (o >= n_obs) return;
+  const uint32_t lm = obs_lm[o], f = obs_frame[o] & 0xFFFFu;
+  const double X[3] = {Xs[3 * lm], Xs[3 * lm + 1], Xs[3 * lm + 2]};
+  double a, b, c;
+  ba_project(poses + 12 * f, X, a, b, c);
+  const double2 uv = obs_uv[o];
+  const uint32_t dst = obs_src[o];
+  out[2 * (size_t)dst] = a / c - uv.x;
+  out[2 * (size_t)dst + 1] = b / c - uv.y;
+}
+
+// =============================================================================================
+// host side
+// =============================================================================================
+namespace {
+
+struct Buf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    const size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <class T>
+  T* as() const { return static_cast<T*>(p); }
+};
+
+constexpr int kMaxSchurEvents = 64;
+
+}  // namespace
+
+struct mvo_hip_ba_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipError_t last_hip_error = hipSuccess;
+  Buf d_poses, d_X, d_lm_off, d_lm_nfree, d_obs_frame, d_obs_uv, d_obs_lm, d_obs_src, d_wg_lm, d_partS, d_partV,
+      d_redS, d_redV, d_partT, d_delta, d_state, d_trace, d_res;
+  bool uploaded = false;
+  BaParams prm{};
+  uint64_t n_obs = 0;
+  std::vector<mvo_hip_ba_pose> h_poses0;  // the uploaded point (solve restarts from it)
+  std::vector<double> h_X0;
+  std::vector<mvo_hip_ba_pose> h_poses;   // result of the last solve
+  std::vector<double> h_X;
+  BaState h_state{};
+  bool solved = false;
+  int32_t trace_cap = 0;
+  bool profiling = false;
+  hipEvent_t ev[2 + 2 * kMaxSchurEvents] = {};
+  bool events_ready = false;
+  mvo_hip_ba_timing timing{};
+  size_t schur_lds = 0, solve_lds = 0;
+};
+
+namespace {
+
+#define BA_TRY(expr)                                                                      \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess) {                                                               \
+      h->last_hip_error = e_;                                                             \
+      return e_ == hipErrorOutOfMemory ? MVO_HIP_ERR_OUT_OF_MEMORY : MVO_HIP_ERR_DEVICE; \
+    }                                                                                     \
+  } while (0)
+
+int ba_upload(mvo_hip_ba_context* h, const mvo_hip_ba_pose* poses, uint32_t M, uint32_t N, const double* X,
+              const mvo_hip_ba_observations* obs, const mvo_hip_ba_options* opt) {
+  const auto t0 = std::chrono::steady_clock::now();
+  if (!poses || !X || !obs || !opt || !obs->landmark_offsets) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  if (M == 0 || N <= M) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  if (M > MVO_HIP_BA_MAX_FREE_FRAMES || N > MVO_HIP_BA_MAX_FRAMES) return MVO_HIP_ERR_UNSUPPORTED;
+  if (opt->max_num_iterations < 0 || opt->loss < 0 || opt->loss > 2) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  if (opt->loss != 0 && !(opt->loss_scale > 0.0)) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  const uint32_t L = obs->n_landmarks;
+  if (L == 0 || obs->landmark_offsets[0] != 0) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  for (uint32_t j = 0; j < L; ++j)
+    if (obs->landmark_offsets[j + 1] < obs->landmark_offsets[j]) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  const uint64_t n_obs = obs->landmark_offsets[L];
+  if (n_obs >= (1ull << 31)) return MVO_HIP_ERR_UNSUPPORTED;
+  if (n_obs && (!obs->frame || !obs->rays)) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  BA_TRY(hipSetDevice(h->device));
+  h->uploaded = false;
+  h->solved = false;
+
+  // per-landmark observation lists sorted by frame; free observations get consecutive slots
+  std::vector<uint32_t> lm_off(L + 1), lm_nfree(L), frame_word(n_obs), obs_lm(n_obs), obs_src(n_obs);
+  std::vector<double> uv(2 * n_obs);
+  std::vector<uint32_t> order;
+  for (uint32_t j = 0; j < L; ++j) {
+    const uint64_t o0 = obs->landmark_offsets[j], o1 = obs->landmark_offsets[j + 1];
+    lm_off[j] = (uint32_t)o0;
+    order.resize(o1 - o0);
+    for (uint64_t o = o0; o < o1; ++o) {
+      if (obs->frame[o] >= N) return MVO_HIP_ERR_INVALID_ARGUMENT;
+      if (!(obs->rays[3 * o + 2] > 0.0)) return MVO_HIP_ERR_INVALID_ARGUMENT;
+      order[o - o0] = (uint32_t)o;
+    }
+    std::stable_sort(order.begin(), order.end(),
+                     [&](uint32_t a, uint32_t b) { return obs->frame[a] < obs->frame[b]; });
+    uint32_t slot = 0;
+    for (uint64_t k = 0; k < o1 - o0; ++k) {
+      const uint32_t src = order[k], f = obs->frame[src];
+      const uint64_t dst = o0 + k;
+      uint32_t sl = BA_NOSLOT;
+      if (f < M) {
+        if (slot >= BA_MAXF) return MVO_HIP_ERR_UNSUPPORTED;  // > 28 observations of one landmark in free frames
+        sl = slot++;
+      }
+      frame_word[dst] = f | (sl << 16);
+      obs_lm[dst] = j;
+      obs_src[dst] = src;
+      uv[2 * dst] = obs->rays[3 * (size_t)src] / obs->rays[3 * (size_t)src + 2];
+      uv[2 * dst + 1] = obs->rays[3 * (size_t)src + 1] / obs->rays[3 * (size_t)src + 2];
+    }
+    lm_nfree[j] = slot;
+  }
+  lm_off[L] = (uint32_t)n_obs;
+
+  // landmarks -> workgroups: contiguous ranges of about equal observation count
+  int n_cu = 256;
+  (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device);
+  uint32_t n_wg = (uint32_t)std::min<uint64_t>((uint64_t)n_cu, std::max<uint64_t>(1, (L + 4 * BA_WAVES - 1) / (4 * BA_WAVES)));
+  std::vector<uint32_t> wg_lm(n_wg + 1, L);
+  wg_lm[0] = 0;
+  {
+    uint32_t g = 1;
+    for (uint32_t j = 0; j < L && g < n_wg; ++j)  // load = observations + one unit per landmark
+      while (g < n_wg && (uint64_t)lm_off[j + 1] + (j + 1) >= (n_obs + L) * g / n_wg) wg_lm[g++] = j + 1;
+    for (; g < n_wg; ++g) wg_lm[g] = L;
+    wg_lm[n_wg] = L;
+    for (uint32_t q = 1; q <= n_wg; ++q)
+      if (wg_lm[q] < wg_lm[q - 1]) wg_lm[q] = wg_lm[q - 1];
+  }
+
+  BaParams& prm = h->prm;
+  prm.ftol = opt->function_tolerance;
+  prm.gtol = opt->gradient_tolerance;
+  prm.ptol = opt->parameter_tolerance;
+  prm.loss_scale = opt->loss_scale;
+  prm.initial_radius = opt->initial_radius > 0.0 ? opt->initial_radius : 1e4;
+  prm.max_it = opt->max_num_iterations;
+  prm.loss = opt->loss;
+  prm.M = (int32_t)M;
+  prm.N = (int32_t)N;
+  prm.L = L;
+  prm.n_blk = M * (M + 1) / 2;
+  prm.n_wg = n_wg;
+  prm.trace_cap = (uint32_t)h->trace_cap;
+  h->n_obs = n_obs;
+  h->h_poses0.assign(poses, poses + N);
+  h->h_X0.assign(X, X + 3 * (size_t)L);
+
+  const size_t nS = (size_t)prm.n_blk * 36, nV = 18 * (size_t)M + 2;
+  BA_TRY(h->d_poses.reserve(sizeof(double) * 24 * N));
+  BA_TRY(h->d_X.reserve(sizeof(double) * 6 * (size_t)L));
+  BA_TRY(h->d_lm_off.reserve(sizeof(uint32_t) * (L + 1)));
+  BA_TRY(h->d_lm_nfree.reserve(sizeof(uint32_t) * L));
+  BA_TRY(h->d_obs_frame.reserve(sizeof(uint32_t) * (n_obs + 1)));
+  BA_TRY(h->d_obs_uv.reserve(sizeof(double) * 2 * (n_obs + 1)));
+  BA_TRY(h->d_obs_lm.reserve(sizeof(uint32_t) * (n_obs + 1)));
+  BA_TRY(h->d_obs_src.reserve(sizeof(uint32_t) * (n_obs + 1)));
+  BA_TRY(h->d_wg_lm.reserve(sizeof(uint32_t) * (n_wg + 1)));
+  BA_TRY(h->d_partS.reserve(sizeof(double) * nS * n_wg));
+  BA_TRY(h->d_partV.reserve(sizeof(double) * nV * n_wg));
+  BA_TRY(h->d_redS.reserve(sizeof(double) * nS));
+  BA_TRY(h->d_redV.reserve(sizeof(double) * nV));
+  BA_TRY(h->d_partT.reserve(sizeof(double) * 4 * n_wg));
+  BA_TRY(h->d_delta.reserve(sizeof(double) * 6 * M));
+  BA_TRY(h->d_state.reserve(sizeof(BaState)));
+  hipStream_t s = h->stream;
+  BA_TRY(hipMemcpyAsync(h->d_lm_off.p, lm_off.data(), sizeof(uint32_t) * (L + 1), hipMemcpyHostToDevice, s));
+  BA_TRY(hipMemcpyAsync(h->d_lm_nfree.p, lm_nfree.data(), sizeof(uint32_t) * L, hipMemcpyHostToDevice, s));
+  BA_TRY(hipMemcpyAsync(h->d_wg_lm.p, wg_lm.data(), sizeof(uint32_t) * (n_wg + 1), hipMemcpyHostToDevice, s));
+  if (n_obs) {
+    BA_TRY(hipMemcpyAsync(h->d_obs_frame.p, frame_word.data(), sizeof(uint32_t) * n_obs, hipMemcpyHostToDevice, s));
+    BA_TRY(hipMemcpyAsync(h->d_obs_uv.p, uv.data(), sizeof(double) * 2 * n_obs, hipMemcpyHostToDevice, s));
+    BA_TRY(hipMemcpyAsync(h->d_obs_lm.p, obs_lm.data(), sizeof(uint32_t) * n_obs, hipMemcpyHostToDevice, s));
+    BA_TRY(hipMemcpyAsync(h->d_obs_src.p, obs_src.data(), sizeof(uint32_t) * n_obs, hipMemcpyHostToDevice, s));
+  }
+  BA_TRY(hipStreamSynchronize(s));
+
+  h->schur_lds = sizeof(double) * (nS + 18 * (size_t)M + (size_t)BA_WAVES * BA_WAVE_LDS);
+  h->solve_lds = sizeof(double) * ((size_t)(6 * M + 1) * (6 * M + 2) / 2);
+  BA_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ba_schur), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)h->schur_lds));
+  BA_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ba_solve), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)h->solve_lds));
+  h->uploaded = true;
+  h->timing.upload_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return MVO_HIP_OK;
+}
+
+// (re)load the uploaded point into both parameter buffers and reset the solver state
+int ba_reset_point(mvo_hip_ba_context* h) {
+  hipStream_t s = h->stream;
+  const uint32_t N = h->prm.N, L = h->prm.L;
+  for (int c = 0; c < 2; ++c) {
+    BA_TRY(hipMemcpyAsync(h->d_poses.as<double>() + (size_t)c * 12 * N, h->h_poses0.data(), sizeof(double) * 12 * N,
+                          hipMemcpyHostToDevice, s));
+    BA_TRY(hipMemcpyAsync(h->d_X.as<double>() + (size_t)c * 3 * L, h->h_X0.data(), sizeof(double) * 3 * L,
+                          hipMemcpyHostToDevice, s));
+  }
+  BaState st{};
+  st.radius = h->prm.initial_radius;
+  st.decf = 2.0;
+  h->h_state = st;
+  BA_TRY(hipMemcpyAsync(h->d_state.p, &h->h_state, sizeof(BaState), hipMemcpyHostToDevice, s));
+  BA_TRY(hipStreamSynchronize(s));  // h_state is reused as the read-back target
+  return MVO_HIP_OK;
+}
+
+hipError_t launch_schur(mvo_hip_ba_context* h, double radius_override) {
+  hipLaunchKernelGGL(k_ba_schur, dim3(h->prm.n_wg), dim3(BA_THREADS), h->schur_lds, h->stream, h->prm,
+                     h->d_state.as<BaState>(), radius_override, h->d_poses.as<double>(), h->d_X.as<double>(),
+                     h->d_lm_off.as<uint32_t>(), h->d_lm_nfree.as<uint32_t>(), h->d_obs_frame.as<uint32_t>(),
+                     h->d_obs_uv.as<double2>(), h->d_wg_lm.as<uint32_t>(), h->d_partS.as<double>(),
+                     h->d_partV.as<double>());
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  const uint32_t n = h->prm.n_blk * 36 + 18 * h->prm.M + 2;
+  hipLaunchKernelGGL(k_ba_reduce, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->prm, h->d_state.as<BaState>(),
+                     h->d_partS.as<double>(), h->d_partV.as<double>(), h->d_redS.as<double>(),
+                     h->d_redV.as<double>());
+  return hipGetLastError();
+}
+
+hipError_t launch_step(mvo_hip_ba_context* h, int mode) {
+  hipLaunchKernelGGL(k_ba_step, dim3(h->prm.n_wg), dim3(BA_THREADS), 0, h->stream, h->prm, h->d_state.as<BaState>(),
+                     mode, h->d_poses.as<double>(), h->d_X.as<double>(), h->d_delta.as<double>(),
+                     h->d_lm_off.as<uint32_t>(), h->d_obs_frame.as<uint32_t>(), h->d_obs_uv.as<double2>(),
+                     h->d_wg_lm.as<uint32_t>(), h->d_partT.as<double>());
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_ba_decide, dim3(1), dim3(64), 0, h->stream, h->prm, h->d_state.as<BaState>(), mode,
+                     h->d_partT.as<double>(), h->d_trace.as<BaTrace>());
+  return hipGetLastError();
+}
+
+int ba_solve(mvo_hip_ba_context* h) {
+  if (!h->uploaded) return MVO_HIP_ERR_STATE;
+  const auto t0 = std::chrono::steady_clock::now();
+  BA_TRY(hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  h->prm.trace_cap = (uint32_t)h->trace_cap;
+  if (h->trace_cap > 0) BA_TRY(h->d_trace.reserve(sizeof(BaTrace) * (size_t)h->trace_cap));
+  const bool prof = h->profiling;
+  if (prof && !h->events_ready) {
+    for (auto& e : h->ev) BA_TRY(hipEventCreate(&e));
+    h->events_ready = true;
+  }
+  int rc = ba_reset_point(h);
+  if (rc != MVO_HIP_OK) return rc;
+  int n_schur = 0;
+  if (prof) BA_TRY(hipEventRecord(h->ev[0], s));
+  BA_TRY(launch_step(h, 0));
+  const int chunk = 4;
+  for (int issued = 0; issued < h->prm.max_it;) {
+    const int n = std::min(chunk, h->prm.max_it - issued);
+    for (int i = 0; i < n; ++i) {
+      const bool timed = prof && n_schur < kMaxSchurEvents;
+      if (timed) BA_TRY(hipEventRecord(h->ev[2 + 2 * n_schur], s));
+      BA_TRY(launch_schur(h, 0.0));
+      if (timed) BA_TRY(hipEventRecord(h->ev[3 + 2 * n_schur], s));
+      ++n_schur;
+      hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(BA_SOLVE_THREADS), h->solve_lds, s, h->prm,
+                         h->d_state.as<BaState>(), h->d_redS.as<double>(), h->d_redV.as<double>(),
+                         h->d_poses.as<double>(), h->d_delta.as<double>());
+      BA_TRY(hipGetLastError());
+      BA_TRY(launch_step(h, 1));
+    }
+    issued += n;
+    BA_TRY(hipMemcpyAsync(&h->h_state, h->d_state.p, sizeof(BaState), hipMemcpyDeviceToHost, s));
+    BA_TRY(hipStreamSynchronize(s));
+    if (h->h_state.status != 0) break;
+  }
+  if (prof) BA_TRY(hipEventRecord(h->ev[1], s));
+  BA_TRY(hipMemcpyAsync(&h->h_state, h->d_state.p, sizeof(BaState), hipMemcpyDeviceToHost, s));
+  BA_TRY(hipStreamSynchronize(s));
+  if (h->h_state.status == 0) return MVO_HIP_ERR_DEVICE;  // the loop above always runs to a verdict
+  const uint32_t N = h->prm.N, L = h->prm.L;
+  const int cur = h->h_state.cur;
+  h->h_poses.resize(N);
+  h->h_X.resize(3 * (size_t)L);
+  BA_TRY(hipMemcpyAsync(h->h_poses.data(), h->d_poses.as<double>() + (size_t)cur * 12 * N, sizeof(double) * 12 * N,
+                        hipMemcpyDeviceToHost, s));
+  BA_TRY(hipMemcpyAsync(h->h_X.data(), h->d_X.as<double>() + (size_t)cur * 3 * L, sizeof(double) * 3 * L,
+                        hipMemcpyDeviceToHost, s));
+  BA_TRY(hipStreamSynchronize(s));
+  h->solved = true;
+  mvo_hip_ba_timing& tm = h->timing;
+  tm.solve_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  tm.device_seconds = tm.schur_seconds = 0.0;
+  tm.observations = h->n_obs;
+  tm.schur_bytes = 20ull * h->n_obs + 24ull * L;  // (u, v) + frame word per observation, X per landmark
+  // launches that found the solve finished return at once: count only the linearisations that ran
+  const int ran = std::min(n_schur, h->h_state.iteration + (h->h_state.termination == 0 ? 1 : 0));
+  tm.schur_launches = 0;
+  if (prof) {
+    float ms = 0.f;
+    BA_TRY(hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
+    tm.device_seconds = ms * 1e-3;
+    for (int i = 0; i < std::min(ran, kMaxSchurEvents); ++i) {
+      BA_TRY(hipEventElapsedTime(&ms, h->ev[2 + 2 * i], h->ev[3 + 2 * i]));
+      tm.schur_seconds += ms * 1e-3;
+      ++tm.schur_launches;
+    }
+  }
+  return MVO_HIP_OK;
+}
+
+int ba_download(mvo_hip_ba_context* h, mvo_hip_ba_pose* poses, double* X, mvo_hip_ba_summary* sm) {
+  if (!h->uploaded || !h->solved) return MVO_HIP_ERR_STATE;
+  if (poses) std::memcpy(poses, h->h_poses.data(), sizeof(mvo_hip_ba_pose) * h->prm.M);  // only the free frames change
+  if (X) std::memcpy(X, h->h_X.data(), sizeof(double) * 3 * (size_t)h->prm.L);
+  if (sm) {
+    sm->termination = h->h_state.termination;
+    sm->iterations = h->h_state.iteration;
+    sm->num_successful_steps = h->h_state.nsucc;
+    sm->num_unsuccessful_steps = h->h_state.nunsucc;
+    sm->initial_cost = h->h_state.initial_cost;
+    sm->final_cost = h->h_state.cost;
+  }
+  return MVO_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mvo_hip_ba_create(int device_ordinal, mvo_hip_ba_handle* out) {
+  if (!out) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return MVO_HIP_ERR_NO_DEVICE;
+  if (device_ordinal < 0 || device_ordinal >= count) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  mvo_hip_ba_context* h = new (std::nothrow) mvo_hip_ba_context();
+  if (!h) return MVO_HIP_ERR_OUT_OF_MEMORY;
+  h->device = device_ordinal;
+  if (hipSetDevice(device_ordinal) != hipSuccess ||
+      hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete h;
+    return MVO_HIP_ERR_DEVICE;
+  }
+  *out = h;
+  return MVO_HIP_OK;
+}
+
+void mvo_hip_ba_destroy(mvo_hip_ba_handle h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  Buf* bufs[] = {&h->d_poses, &h->d_X, &h->d_lm_off, &h->d_lm_nfree, &h->d_obs_frame, &h->d_obs_uv, &h->d_obs_lm,
+                 &h->d_obs_src, &h->d_wg_lm, &h->d_partS, &h->d_partV, &h->d_redS, &h->d_redV, &h->d_partT,
+                 &h->d_delta, &h->d_state, &h->d_trace, &h->d_res};
+  for (Buf* b : bufs) b->release();
+  if (h->events_ready)
+    for (auto& e : h->ev) (void)hipEventDestroy(e);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int mvo_hip_ba_upload(mvo_hip_ba_handle h, const mvo_hip_ba_pose* poses, uint32_t M, uint32_t N,
+                      const double* landmarks, const mvo_hip_ba_observations* observations,
+                      const mvo_hip_ba_options* options) {
+  if (!h) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  return ba_upload(h, poses, M, N, landmarks, observations, options);
+}
+
+int mvo_hip_ba_solve(mvo_hip_ba_handle h) { return h ? ba_solve(h) : MVO_HIP_ERR_INVALID_ARGUMENT; }
+
+int mvo_hip_ba_download(mvo_hip_ba_handle h, mvo_hip_ba_pose* poses, double* landmarks, mvo_hip_ba_summary* summary) {
+  return h ? ba_download(h, poses, landmarks, summary) : MVO_HIP_ERR_INVALID_ARGUMENT;
+}
+
+int mvo_hip_ba_refine(mvo_hip_ba_handle h, mvo_hip_ba_pose* poses, uint32_t M, uint32_t N, double* landmarks,
+                      const mvo_hip_ba_observations* observations, const mvo_hip_ba_options* options,
+                      mvo_hip_ba_summary* summary) {
+  if (!h) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  int rc = ba_upload(h, poses, M, N, landmarks, observations, options);
+  if (rc != MVO_HIP_OK) return rc;
+  rc = ba_solve(h);
+  if (rc != MVO_HIP_OK) return rc;
+  return ba_download(h, poses, landmarks, summary);
+}
+
+int mvo_hip_ba_eval(mvo_hip_ba_handle h, double* residuals, double* cost) {
+  if (!h) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  if (!h->uploaded) return MVO_HIP_ERR_STATE;
+  BA_TRY(hipSetDevice(h->device));
+  int rc = ba_reset_point(h);
+  if (rc != MVO_HIP_OK) return rc;
+  hipStream_t s = h->stream;
+  if (residuals && h->n_obs) {
+    BA_TRY(h->d_res.reserve(sizeof(double) * 2 * h->n_obs));
+    hipLaunchKernelGGL(k_ba_residuals, dim3((uint32_t)((h->n_obs + 255) / 256)), dim3(256), 0, s, h->prm, h->n_obs,
+                       h->d_poses.as<double>(), h->d_X.as<double>(), h->d_obs_lm.as<uint32_t>(),
+                       h->d_obs_frame.as<uint32_t>(), h->d_obs_uv.as<double2>(), h->d_obs_src.as<uint32_t>(),
+                       h->d_res.as<double>());
+    BA_TRY(hipGetLastError());
+    BA_TRY(hipMemcpyAsync(residuals, h->d_res.p, sizeof(double) * 2 * h->n_obs, hipMemcpyDeviceToHost, s));
+  }
+  if (cost) {
+    BaParams keep = h->prm;
+    h->prm.trace_cap = 0;
+    hipError_t e = launch_step(h, 0);
+    h->prm = keep;
+    BA_TRY(e);
+    BaState st;
+    BA_TRY(hipMemcpyAsync(&st, h->d_state.p, sizeof(BaState), hipMemcpyDeviceToHost, s));
+    BA_TRY(hipStreamSynchronize(s));
+    *cost = st.cost;
+  }
+  BA_TRY(hipStreamSynchronize(s));
+  return MVO_HIP_OK;
+}
+
+int mvo_hip_ba_reduced(mvo_hip_ba_handle h, double radius, double* S, double* rhs, double* camera_gradient,
+                       double* gradient_max_norm, double* cost) {
+  if (!h || !(radius > 0.0)) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  if (!h->uploaded) return MVO_HIP_ERR_STATE;
+  BA_TRY(hipSetDevice(h->device));
+  int rc = ba_reset_point(h);
+  if (rc != MVO_HIP_OK) return rc;
+  BA_TRY(launch_schur(h, radius));
+  const uint32_t M = h->prm.M, n = 6 * M;
+  std::vector<double> blocks((size_t)h->prm.n_blk * 36), V(18 * (size_t)M + 2);
+  BA_TRY(hipMemcpyAsync(blocks.data(), h->d_redS.p, sizeof(double) * blocks.size(), hipMemcpyDeviceToHost, h->stream));
+  BA_TRY(hipMemcpyAsync(V.data(), h->d_redV.p, sizeof(double) * V.size(), hipMemcpyDeviceToHost, h->stream));
+  BA_TRY(hipStreamSynchronize(h->stream));
+  if (S) {
+    for (uint32_t f = 0; f < M; ++f)
+      for (uint32_t f2 = f; f2 < M; ++f2) {
+        const double* b = blocks.data() + (size_t)ba_blk(M, f, f2) * 36;
+        for (int p = 0; p < 6; ++p)
+          for (int q = 0; q < 6; ++q) {
+            S[(size_t)(6 * f + p) * n + 6 * f2 + q] = b[6 * p + q];
+            S[(size_t)(6 * f2 + q) * n + 6 * f + p] = b[6 * p + q];
+          }
+      }
+    for (uint32_t i = 0; i < n; ++i)  // the damping k_ba_solve adds when it loads the system
+      S[(size_t)i * n + i] += std::fmin(std::fmax(V[12 * M + i], 1e-6), 1e32) / radius;
+  }
+  double gm = V[18 * M + 1];
+  for (uint32_t i = 0; i < n; ++i) {
+    if (rhs) rhs[i] = V[i];
+    if (camera_gradient) camera_gradient[i] = V[6 * M + i];
+    gm = std::fmax(gm, std::fabs(V[6 * M + i]));
+  }
+  if (gradient_max_norm) *gradient_max_norm = gm;
+  if (cost) *cost = V[18 * M];
+  return MVO_HIP_OK;
+}
+
+int mvo_hip_ba_set_trace(mvo_hip_ba_handle h, int32_t capacity) {
+  if (!h || capacity < 0) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  h->trace_cap = capacity;
+  return MVO_HIP_OK;
+}
+
+int mvo_hip_ba_get_trace(mvo_hip_ba_handle h, mvo_hip_ba_iteration* rows, int32_t capacity, int32_t* n_rows) {
+  if (!h || !n_rows) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  if (!h->solved) return MVO_HIP_ERR_STATE;
+  *n_rows = h->h_state.ntrace;
+  int32_t n = std::min(h->h_state.ntrace, h->trace_cap);
+  n = std::min(n, capacity);
+  if (rows && n > 0) {
+    BA_TRY(hipSetDevice(h->device));
+    BA_TRY(hipMemcpy(rows, h->d_trace.p, sizeof(mvo_hip_ba_iteration) * (size_t)n, hipMemcpyDeviceToHost));
+  }
+  return MVO_HIP_OK;
+}
+
+int mvo_hip_ba_set_profiling(mvo_hip_ba_handle h, int enabled) {
+  if (!h) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  h->profiling = enabled != 0;
+  return MVO_HIP_OK;
+}
+
+int mvo_hip_ba_get_timing(mvo_hip_ba_handle h, mvo_hip_ba_timing* out) {
+  if (!h || !out) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  *out = h->timing;
+  return MVO_HIP_OK;
+}
+
+}  // extern "C"
