@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of libmvo_hip's sliding-window refinement on MI355X.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload config2|config3|config4|config5]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload config2|config3|config4|config4r|config5|ba2|ba4|ba5]
+
+(ba*: the explicit-landmark bundle adjustment of include/mvo_hip_ba.h -- SURVEY.md 8f rank 1, no
+reference counterpart -- on BASELINE.json's config shapes; see bench_ba below.)
 
 A "step" is one complete refine() of the workload with the observations already resident in HBM
 (mvo_hip_upload done before the timed region; mvo_hip_solve + mvo_hip_download inside it):
@@ -131,6 +134,101 @@ def cpu_baseline(ws, opt_kw, use_loss):
             "residual_blocks_per_s": round(sample.n_residual_blocks * its / el, 1)}
 
 
+def bench_ba(args, rank, local_rank, world, barrier, dist, torch):
+    """Explicit-landmark window BA.  ba2 = configs[1] shape (30 keyframes, 5 000 landmarks, 100 000
+    observations), ba5 = the same with 20 % outliers under a Cauchy loss, ba4 = configs[3] shape
+    (200 keyframes, 200 000 landmarks, 10 M observations; 28 free frames).  With N > 1 every rank
+    solves its own scene (independent sequences, no collective): weak scaling."""
+    from mvo_amd import ba_capi, ba_scene
+
+    fixed = dict(max_num_iterations=10, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
+    if args.workload == "ba2":
+        sc, kw = ba_scene.ba_config2(seed=2002 + rank), dict(fixed)
+        desc = "ba2: 30 keyframes (28 free), 5000 landmarks x 20 frames = 100k observations, fixed 10 LM iterations"
+    elif args.workload == "ba5":
+        sc, kw = ba_scene.ba_config2(seed=2005 + rank, outlier_fraction=0.2), dict(loss=1, loss_scale=0.003, **fixed)
+        desc = "ba5: ba2 data with 20% outlier observations, Cauchy(0.003) IRLS, fixed 10 LM iterations"
+    elif args.workload == "ba4":
+        sc, kw = ba_scene.ba_config4(seed=2004 + rank), dict(fixed)
+        desc = "ba4: 200 keyframes (28 free), 200k landmarks x 50 frames = 10M observations, fixed 10 LM iterations"
+    else:
+        raise SystemExit(f"unknown workload {args.workload}")
+    solver = ba_capi.BaSolver(local_rank)
+    t0 = time.perf_counter()
+    solver.upload(sc, ba_capi.make_options(**kw))
+    upload_s = time.perf_counter() - t0
+    for _ in range(args.warmup):
+        solver.solve()
+    barrier()
+    t0 = time.perf_counter()
+    sch_s, sch_n, dev_s = 0.0, 0, 0.0
+    for _ in range(args.steps):
+        solver.solve()
+        poses, X, summ = solver.download()
+        tm = solver.timing()
+        sch_s += tm["schur_seconds"]
+        sch_n += tm["schur_launches"]
+        dev_s += tm["device_seconds"]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    its = summ.iterations
+    roof = None
+    if sch_n:
+        dur = sch_s / sch_n
+        gbs = tm["schur_bytes"] / dur / 1e9
+        roof = {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.workload, "k_ba_schur"),
+                "kernel": "k_ba_schur", "bytes_per_launch": int(tm["schur_bytes"]),
+                "avg_launch_us": round(dur * 1e6, 3), "launches_timed": int(sch_n)}
+    out = {
+        "metric": "lm_iterations_per_sec", "value": round(its * args.steps * world / elapsed, 3),
+        "unit": "LM iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": desc, "keyframes": sc.N, "free_keyframes": sc.M, "landmarks_per_gpu": sc.n_landmarks,
+                   "observations_per_gpu": sc.n_observations, "lm_iterations": its,
+                   "parallelism": f"{world} x independent scenes, no collective"},
+        "residual_jacobian_obs_per_sec": round(sc.n_observations * its * args.steps * world / elapsed, 1),
+        "device_ms_per_step": round(dev_s / args.steps * 1e3, 5),
+        "upload_seconds_pcie_inclusive": round(upload_s, 6),
+        "final_cost": summ.final_cost, "initial_cost": summ.initial_cost,
+        "roofline": roof,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import mvo_ba_oracle_py as bo
+
+        sample, note = sc, "the whole scene"
+        if sc.n_observations > 300_000:  # bound the CPU leg: the first 5000 landmarks
+            import numpy as np
+            from dataclasses import replace
+
+            k = 5000
+            e = int(sc.lm_offsets[k])
+            sample = replace(sc, X=sc.X[:k], lm_offsets=sc.lm_offsets[:k + 1], obs_frame=sc.obs_frame[:e],
+                             obs_ray=sc.obs_ray[:e], true_X=sc.true_X[:k])
+            note = f"its first {k} landmarks"
+        okw = dict(kw)
+        okw["max_num_iterations"] = 3
+        t1 = time.perf_counter()
+        _, _, so, _ = bo.refine(sample, bo.make_options(**okw))
+        el = time.perf_counter() - t1
+        out["cpu_baseline"] = {"value": round(so.iterations / el, 3), "unit": "LM iterations/s", "cores": 1,
+                               "kind": "port",
+                               "sample": f"{so.iterations} LM iterations of {note} ({sample.n_observations} observations) "
+                                         f"in {el:.2f} s on one host core (self-oracle: no reference counterpart)",
+                               "observations_per_s": round(sample.n_observations * so.iterations / el, 1)}
+    else:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    solver.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -164,6 +262,12 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if args.workload.startswith("ba"):
+        bench_ba(args, rank, local_rank, world, barrier, dist, torch)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     # config4 / config4r with N > 1: ONE window, residual blocks range-partitioned over the ranks,
     # per-pair sums all-reduced over RCCL before every (identical) LM step -- strong scaling.

@@ -40,7 +40,7 @@
 struct BaParams {
   double ftol, gtol, ptol, loss_scale, initial_radius;
   int32_t max_it, loss, M, N;
-  uint32_t L, n_blk, n_wg, trace_cap;
+  uint32_t L, n_blk, n_wg, n_wg_step, trace_cap, pad;
 };
 
 struct BaState {
@@ -305,26 +305,45 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_schur(BaParams prm, const BaS
   }
 }
 
-// sums the per-workgroup copies in workgroup order; the last entry of V is a maximum
+// Sums the per-workgroup copies: a block handles 32 entries, 8 threads per entry each summing a
+// contiguous slice of the workgroups (loads in flight together), slices combined in order through
+// LDS -- a fixed summation order.  The last entry of V is a maximum.
 __global__ __launch_bounds__(256) void k_ba_reduce(BaParams prm, const BaState* __restrict__ st,
                                                   const double* __restrict__ partS,
                                                   const double* __restrict__ partV, double* __restrict__ redS,
                                                   double* __restrict__ redV) {
+  __shared__ double sl[8][32];
   if (st->status != 0) return;
   const uint32_t nS = prm.n_blk * 36, nV = 18 * prm.M + 2;
-  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-  if (i < nS) {
-    double a = 0.0;
-    for (uint32_t g = 0; g < prm.n_wg; ++g) a += partS[(size_t)g * nS + i];
-    redS[i] = a;
-  } else if (i < nS + nV) {
-    const uint32_t k = i - nS;
-    double a = 0.0;
-    if (k == nV - 1)
-      for (uint32_t g = 0; g < prm.n_wg; ++g) a = fmax(a, partV[(size_t)g * nV + k]);
-    else
-      for (uint32_t g = 0; g < prm.n_wg; ++g) a += partV[(size_t)g * nV + k];
-    redV[k] = a;
+  const uint32_t e = threadIdx.x & 31, slice = threadIdx.x >> 5;
+  const uint32_t i = blockIdx.x * 32 + e;
+  const uint32_t per = (prm.n_wg + 7) / 8, g0 = slice * per, g1 = min(g0 + per, prm.n_wg);
+  const bool inS = i < nS, inV = !inS && i < nS + nV;
+  const bool is_max = inV && (i - nS) == nV - 1;
+  const double* __restrict__ src = inS ? partS + i : partV + (i - nS);
+  const size_t stride = inS ? nS : nV;
+  double a = 0.0;
+  if (inS || inV) {
+    uint32_t g = g0;
+    for (; g + 4 <= g1; g += 4) {
+      const double v0 = src[(size_t)g * stride], v1 = src[(size_t)(g + 1) * stride],
+                   v2 = src[(size_t)(g + 2) * stride], v3 = src[(size_t)(g + 3) * stride];
+      if (is_max) a = fmax(fmax(fmax(a, v0), fmax(v1, v2)), v3);
+      else a = (((a + v0) + v1) + v2) + v3;
+    }
+    for (; g < g1; ++g) {
+      const double v = src[(size_t)g * stride];
+      a = is_max ? fmax(a, v) : a + v;
+    }
+  }
+  sl[slice][e] = a;
+  __syncthreads();
+  if (slice == 0 && (inS || inV)) {
+    double t = sl[0][e];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) t = is_max ? fmax(t, sl[q][e]) : t + sl[q][e];
+    if (inS) redS[i] = t;
+    else redV[i - nS] = t;
   }
 }
 
@@ -352,9 +371,15 @@ __device__ __forceinline__ void ba_pose_plus(const double* __restrict__ in, cons
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_ba_solve: one workgroup.  Packed lower triangle of the damped system plus the right-hand side
-// as row n in LDS; right-looking Cholesky; the forward substitution falls out of the extra row;
-// the back substitution runs in wavefront 0 without barriers.
+// k_ba_solve: one workgroup, one THREAD PER 6 x 6 BLOCK of the lower block triangle of the damped
+// reduced camera system, the block held in 36 registers for the whole factorisation; the
+// right-hand side rides along as block row M (forward substitution for free).  Right-looking
+// block L D L^T (no square roots): per block column kb
+//   (1) the diagonal thread factors its block and publishes l (unit lower), d, 1/d      -> LDS
+//   (2) the panel threads (ib > kb, jb = kb) compute X = A l^-T, W = X d^-1, publish both -> LDS
+//   (3) every trailing thread (ib >= jb > kb) subtracts W_ib X_jb^T from its registers
+// -- two barriers per block column, no LDS read-modify-write.  The factor is then dumped to LDS
+// and wavefront 0 runs the scalar back substitution without barriers.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t tri(uint32_t i, uint32_t j) { return (i * (i + 1)) / 2 + j; }  // j <= i
 
@@ -363,8 +388,10 @@ __global__ __launch_bounds__(BA_SOLVE_THREADS) void k_ba_solve(BaParams prm, BaS
                                                               const double* __restrict__ redV,
                                                               double* __restrict__ poses2,
                                                               double* __restrict__ delta_c) {
-  extern __shared__ double A[];  // (n + 1)(n + 2) / 2
-  __shared__ double xs[6 * BA_MAXF], dc2[6 * BA_MAXF];
+  extern __shared__ double Lf[];  // (M+1)(M+2)/2 blocks x 36: the factor, block (ib, jb) at tri(ib, jb)
+  __shared__ double pubX[2][BA_MAXF + 1][36], pubW[2][BA_MAXF + 1][36];
+  __shared__ double dl[2][36], dd[2][6], dinvs[2][6];
+  __shared__ double xs[6 * BA_MAXF], dc2[6 * BA_MAXF], dinv[6 * BA_MAXF];
   __shared__ int bad_flag;
   if (st->status != 0) return;
   const uint32_t M = prm.M, n = 6 * M, tid = threadIdx.x;
@@ -381,68 +408,132 @@ __global__ __launch_bounds__(BA_SOLVE_THREADS) void k_ba_solve(BaParams prm, BaS
     return;
   }
   if (tid == 0) bad_flag = 0;
-  for (uint32_t e = tid; e < (n + 1) * (n + 2) / 2; e += BA_SOLVE_THREADS) {
-    // e -> (i, j), j <= i
-    uint32_t i = (uint32_t)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
-    while ((i + 1) * (i + 2) / 2 <= e) ++i;
-    while (i * (i + 1) / 2 > e) --i;
-    const uint32_t j = e - i * (i + 1) / 2;
-    double v;
-    if (i == n) {
-      v = j < n ? redV[j] : 0.0;
+  // thread -> block (ib, jb), jb <= ib <= M
+  const uint32_t nba = (M + 1) * (M + 2) / 2;
+  uint32_t ib = (uint32_t)((sqrtf(8.0f * (float)tid + 1.0f) - 1.0f) * 0.5f);
+  while ((ib + 1) * (ib + 2) / 2 <= tid) ++ib;
+  while (ib * (ib + 1) / 2 > tid) --ib;
+  const uint32_t jb = tid - ib * (ib + 1) / 2;
+  const bool have = tid < nba;
+  double a[36];
+#pragma unroll
+  for (int e = 0; e < 36; ++e) a[e] = 0.0;
+  if (have) {
+    if (ib == M) {  // right-hand side, row 0 of the block
+#pragma unroll
+      for (int c = 0; c < 6; ++c) a[c] = redV[6 * jb + c];
     } else {
-      const uint32_t fi = i / 6, fj = j / 6;
-      v = redS[ba_blk(M, fj, fi) * 36 + (j - 6 * fj) * 6 + (i - 6 * fi)];
-      if (i == j) {
-        const double d2 = ba_clamp_diag(redV[12 * M + i]) / radius;
-        v += d2;
-        dc2[i] = d2;
+      const double* __restrict__ src = redS + (size_t)ba_blk(M, jb, ib) * 36;  // stored as block (jb, ib)
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) a[6 * r + c] = src[6 * c + r];
+      if (ib == jb) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+          const double d2 = ba_clamp_diag(redV[12 * M + 6 * ib + r]) / radius;
+          a[7 * r] += d2;
+          dc2[6 * ib + r] = d2;
+        }
       }
     }
-    A[e] = v;
   }
   __syncthreads();
-  for (uint32_t k = 0; k < n; ++k) {
-    const double d = A[tri(k, k)];
-    if (!(d > 0.0) || isinf(d)) {
-      if (tid == 0) bad_flag = 1;
-      break;  // uniform
+  for (uint32_t kb = 0; kb < M; ++kb) {
+    const int buf = kb & 1;
+    if (have && ib == kb && jb == kb) {  // (1) l d l^T of the diagonal block (lower part of a)
+      bool ok = true;
+      double d[6], iv[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        double dcv = a[7 * c];
+#pragma unroll
+        for (int p = 0; p < c; ++p) dcv -= a[6 * c + p] * a[6 * c + p] * d[p];
+        if (!(dcv > 0.0) || isinf(dcv)) ok = false;
+        d[c] = dcv;
+        iv[c] = 1.0 / dcv;
+#pragma unroll
+        for (int r = c + 1; r < 6; ++r) {
+          double v = a[6 * r + c];
+#pragma unroll
+          for (int p = 0; p < c; ++p) v -= a[6 * r + p] * a[6 * c + p] * d[p];
+          a[6 * r + c] = v * iv[c];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 36; ++e) dl[buf][e] = a[e];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        dd[buf][c] = d[c];
+        dinvs[buf][c] = iv[c];
+        dinv[6 * kb + c] = iv[c];
+      }
+      if (!ok) bad_flag = 1;
     }
-    const double inv = 1.0 / sqrt(d);
-    __syncthreads();  // every thread has read the pivot
-    for (uint32_t i = k + tid; i <= n; i += BA_SOLVE_THREADS) A[tri(i, k)] *= inv;  // L[k..n][k]; [k][k] = sqrt(d)
     __syncthreads();
-    // trailing update: rows i in (k, n], columns j in (k, i]
-    const uint32_t m = n - k;  // rows
-    for (uint32_t e = tid; e < m * (m + 1) / 2; e += BA_SOLVE_THREADS) {
-      uint32_t a = (uint32_t)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
-      while ((a + 1) * (a + 2) / 2 <= e) ++a;
-      while (a * (a + 1) / 2 > e) --a;
-      const uint32_t b = e - a * (a + 1) / 2;
-      const uint32_t i = k + 1 + a, j = k + 1 + b;
-      A[tri(i, j)] -= A[tri(i, k)] * A[tri(j, k)];
+    if (bad_flag) break;  // uniform
+    if (have && jb == kb && ib > kb) {  // (2) X = A l^-T (row by row), W = X d^-1
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          double v = a[6 * r + c];
+#pragma unroll
+          for (int p = 0; p < c; ++p) v -= a[6 * r + p] * dl[buf][6 * c + p];
+          a[6 * r + c] = v;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          pubX[buf][ib][6 * r + c] = a[6 * r + c];
+          a[6 * r + c] *= dinvs[buf][c];
+          pubW[buf][ib][6 * r + c] = a[6 * r + c];
+        }
     }
     __syncthreads();
+    if (have && jb > kb) {  // (3) A_(ib,jb) -= W_ib X_jb^T
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        double w[6];
+#pragma unroll
+        for (int p = 0; p < 6; ++p) w[p] = pubW[buf][ib][6 * r + p];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          double acc = a[6 * r + c];
+#pragma unroll
+          for (int p = 0; p < 6; ++p) acc -= w[p] * pubX[buf][jb][6 * c + p];
+          a[6 * r + c] = acc;
+        }
+      }
+    }
   }
   __syncthreads();
   const bool bad = bad_flag != 0;
+  if (have && !bad) {
+#pragma unroll
+    for (int e = 0; e < 36; ++e) Lf[(size_t)tid * 36 + e] = a[e];
+  }
+  __syncthreads();
   if (tid < 64 && !bad) {
-    // back substitution L^T x = y (y = row n), lanes own components lane, lane + 64, lane + 128
+    // back substitution L^T x = w (w = row 0 of the block row M); lanes own components lane, +64, +128
     double y[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const uint32_t i = tid + 64 * c;
-      y[c] = i < n ? A[tri(n, i)] : 0.0;
+      y[c] = i < n ? Lf[(size_t)tri(M, i / 6) * 36 + i % 6] : 0.0;
     }
     for (int k = (int)n - 1; k >= 0; --k) {
       const int c = k >> 6, src = k & 63;
       const double yk = c == 0 ? y[0] : (c == 1 ? y[1] : y[2]);
-      const double xk = __shfl(yk, src, 64) / A[tri(k, k)];
+      const double xk = __shfl(yk, src, 64);
       if ((int)tid == src) xs[k] = xk;
+      const uint32_t kb6 = (uint32_t)k / 6, kr = (uint32_t)k % 6;
 #pragma unroll
       for (int cc = 0; cc < 3; ++cc) {
-        const int j = (int)tid + 64 * cc;
-        if (j < k) y[cc] -= A[tri(k, j)] * xk;
+        const uint32_t j = tid + 64 * cc;
+        if ((int)j < k) y[cc] -= Lf[(size_t)tri(kb6, j / 6) * 36 + 6 * kr + j % 6] * xk;
       }
     }
   }
@@ -606,7 +697,7 @@ __global__ __launch_bounds__(64) void k_ba_decide(BaParams prm, BaState* __restr
   double v[4] = {0, 0, 0, 0};
   const bool have = mode == 0 || !st->step_bad;
   if (have)
-    for (uint32_t g = lane; g < prm.n_wg; g += 64)
+    for (uint32_t g = lane; g < prm.n_wg_step; g += 64)
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] += partT[(size_t)g * 4 + k];
 #pragma unroll
@@ -754,7 +845,7 @@ struct mvo_hip_ba_context {
   int device = 0;
   hipStream_t stream = nullptr;
   hipError_t last_hip_error = hipSuccess;
-  Buf d_poses, d_X, d_lm_off, d_lm_nfree, d_obs_frame, d_obs_uv, d_obs_lm, d_obs_src, d_wg_lm, d_partS, d_partV,
+  Buf d_poses, d_X, d_lm_off, d_lm_nfree, d_obs_frame, d_obs_uv, d_obs_lm, d_obs_src, d_wg_lm, d_wg_lm_step, d_partS, d_partV,
       d_redS, d_redV, d_partT, d_delta, d_state, d_trace, d_res;
   bool uploaded = false;
   BaParams prm{};
@@ -837,21 +928,24 @@ int ba_upload(mvo_hip_ba_context* h, const mvo_hip_ba_pose* poses, uint32_t M, u
   }
   lm_off[L] = (uint32_t)n_obs;
 
-  // landmarks -> workgroups: contiguous ranges of about equal observation count
+  // landmarks -> workgroups: contiguous ranges of about equal load (observations + one unit per
+  // landmark).  k_ba_schur holds the reduced camera system per workgroup: one workgroup per CU;
+  // k_ba_step has no such state and is cut finer, for occupancy.
   int n_cu = 256;
   (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device);
-  uint32_t n_wg = (uint32_t)std::min<uint64_t>((uint64_t)n_cu, std::max<uint64_t>(1, (L + 4 * BA_WAVES - 1) / (4 * BA_WAVES)));
-  std::vector<uint32_t> wg_lm(n_wg + 1, L);
-  wg_lm[0] = 0;
-  {
+  auto partition = [&](uint32_t n_wg) {
+    std::vector<uint32_t> w(n_wg + 1, L);
+    w[0] = 0;
     uint32_t g = 1;
-    for (uint32_t j = 0; j < L && g < n_wg; ++j)  // load = observations + one unit per landmark
-      while (g < n_wg && (uint64_t)lm_off[j + 1] + (j + 1) >= (n_obs + L) * g / n_wg) wg_lm[g++] = j + 1;
-    for (; g < n_wg; ++g) wg_lm[g] = L;
-    wg_lm[n_wg] = L;
+    for (uint32_t j = 0; j < L && g < n_wg; ++j)
+      while (g < n_wg && (uint64_t)lm_off[j + 1] + (j + 1) >= (n_obs + L) * g / n_wg) w[g++] = j + 1;
     for (uint32_t q = 1; q <= n_wg; ++q)
-      if (wg_lm[q] < wg_lm[q - 1]) wg_lm[q] = wg_lm[q - 1];
-  }
+      if (w[q] < w[q - 1]) w[q] = w[q - 1];
+    return w;
+  };
+  const uint32_t n_wg = (uint32_t)std::min<uint64_t>((uint64_t)n_cu, std::max<uint64_t>(1, (L + 4 * BA_WAVES - 1) / (4 * BA_WAVES)));
+  const uint32_t n_wg_step = (uint32_t)std::min<uint64_t>(8ull * n_cu, std::max<uint64_t>(1, (L + 2 * BA_WAVES - 1) / (2 * BA_WAVES)));
+  const std::vector<uint32_t> wg_lm = partition(n_wg), wg_lm_step = partition(n_wg_step);
 
   BaParams& prm = h->prm;
   prm.ftol = opt->function_tolerance;
@@ -866,6 +960,7 @@ int ba_upload(mvo_hip_ba_context* h, const mvo_hip_ba_pose* poses, uint32_t M, u
   prm.L = L;
   prm.n_blk = M * (M + 1) / 2;
   prm.n_wg = n_wg;
+  prm.n_wg_step = n_wg_step;
   prm.trace_cap = (uint32_t)h->trace_cap;
   h->n_obs = n_obs;
   h->h_poses0.assign(poses, poses + N);
@@ -881,17 +976,19 @@ int ba_upload(mvo_hip_ba_context* h, const mvo_hip_ba_pose* poses, uint32_t M, u
   BA_TRY(h->d_obs_lm.reserve(sizeof(uint32_t) * (n_obs + 1)));
   BA_TRY(h->d_obs_src.reserve(sizeof(uint32_t) * (n_obs + 1)));
   BA_TRY(h->d_wg_lm.reserve(sizeof(uint32_t) * (n_wg + 1)));
+  BA_TRY(h->d_wg_lm_step.reserve(sizeof(uint32_t) * (n_wg_step + 1)));
   BA_TRY(h->d_partS.reserve(sizeof(double) * nS * n_wg));
   BA_TRY(h->d_partV.reserve(sizeof(double) * nV * n_wg));
   BA_TRY(h->d_redS.reserve(sizeof(double) * nS));
   BA_TRY(h->d_redV.reserve(sizeof(double) * nV));
-  BA_TRY(h->d_partT.reserve(sizeof(double) * 4 * n_wg));
+  BA_TRY(h->d_partT.reserve(sizeof(double) * 4 * n_wg_step));
   BA_TRY(h->d_delta.reserve(sizeof(double) * 6 * M));
   BA_TRY(h->d_state.reserve(sizeof(BaState)));
   hipStream_t s = h->stream;
   BA_TRY(hipMemcpyAsync(h->d_lm_off.p, lm_off.data(), sizeof(uint32_t) * (L + 1), hipMemcpyHostToDevice, s));
   BA_TRY(hipMemcpyAsync(h->d_lm_nfree.p, lm_nfree.data(), sizeof(uint32_t) * L, hipMemcpyHostToDevice, s));
   BA_TRY(hipMemcpyAsync(h->d_wg_lm.p, wg_lm.data(), sizeof(uint32_t) * (n_wg + 1), hipMemcpyHostToDevice, s));
+  BA_TRY(hipMemcpyAsync(h->d_wg_lm_step.p, wg_lm_step.data(), sizeof(uint32_t) * (n_wg_step + 1), hipMemcpyHostToDevice, s));
   if (n_obs) {
     BA_TRY(hipMemcpyAsync(h->d_obs_frame.p, frame_word.data(), sizeof(uint32_t) * n_obs, hipMemcpyHostToDevice, s));
     BA_TRY(hipMemcpyAsync(h->d_obs_uv.p, uv.data(), sizeof(double) * 2 * n_obs, hipMemcpyHostToDevice, s));
@@ -901,7 +998,7 @@ int ba_upload(mvo_hip_ba_context* h, const mvo_hip_ba_pose* poses, uint32_t M, u
   BA_TRY(hipStreamSynchronize(s));
 
   h->schur_lds = sizeof(double) * (nS + 18 * (size_t)M + (size_t)BA_WAVES * BA_WAVE_LDS);
-  h->solve_lds = sizeof(double) * ((size_t)(6 * M + 1) * (6 * M + 2) / 2);
+  h->solve_lds = sizeof(double) * 36 * ((size_t)(M + 1) * (M + 2) / 2);
   BA_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ba_schur), hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)h->schur_lds));
   BA_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ba_solve), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -939,17 +1036,17 @@ hipError_t launch_schur(mvo_hip_ba_context* h, double radius_override) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   const uint32_t n = h->prm.n_blk * 36 + 18 * h->prm.M + 2;
-  hipLaunchKernelGGL(k_ba_reduce, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->prm, h->d_state.as<BaState>(),
+  hipLaunchKernelGGL(k_ba_reduce, dim3((n + 31) / 32), dim3(256), 0, h->stream, h->prm, h->d_state.as<BaState>(),
                      h->d_partS.as<double>(), h->d_partV.as<double>(), h->d_redS.as<double>(),
                      h->d_redV.as<double>());
   return hipGetLastError();
 }
 
 hipError_t launch_step(mvo_hip_ba_context* h, int mode) {
-  hipLaunchKernelGGL(k_ba_step, dim3(h->prm.n_wg), dim3(BA_THREADS), 0, h->stream, h->prm, h->d_state.as<BaState>(),
-                     mode, h->d_poses.as<double>(), h->d_X.as<double>(), h->d_delta.as<double>(),
-                     h->d_lm_off.as<uint32_t>(), h->d_obs_frame.as<uint32_t>(), h->d_obs_uv.as<double2>(),
-                     h->d_wg_lm.as<uint32_t>(), h->d_partT.as<double>());
+  hipLaunchKernelGGL(k_ba_step, dim3(h->prm.n_wg_step), dim3(BA_THREADS), 0, h->stream, h->prm,
+                     h->d_state.as<BaState>(), mode, h->d_poses.as<double>(), h->d_X.as<double>(),
+                     h->d_delta.as<double>(), h->d_lm_off.as<uint32_t>(), h->d_obs_frame.as<uint32_t>(),
+                     h->d_obs_uv.as<double2>(), h->d_wg_lm_step.as<uint32_t>(), h->d_partT.as<double>());
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_ba_decide, dim3(1), dim3(64), 0, h->stream, h->prm, h->d_state.as<BaState>(), mode,
@@ -1071,7 +1168,7 @@ void mvo_hip_ba_destroy(mvo_hip_ba_handle h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   Buf* bufs[] = {&h->d_poses, &h->d_X, &h->d_lm_off, &h->d_lm_nfree, &h->d_obs_frame, &h->d_obs_uv, &h->d_obs_lm,
-                 &h->d_obs_src, &h->d_wg_lm, &h->d_partS, &h->d_partV, &h->d_redS, &h->d_redV, &h->d_partT,
+                 &h->d_obs_src, &h->d_wg_lm, &h->d_wg_lm_step, &h->d_partS, &h->d_partV, &h->d_redS, &h->d_redV, &h->d_partT,
                  &h->d_delta, &h->d_state, &h->d_trace, &h->d_res};
   for (Buf* b : bufs) b->release();
   if (h->events_ready)
