@@ -184,6 +184,11 @@ def bench_ba(args, rank, local_rank, world, barrier, dist, torch):
                 "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.workload, "k_ba_schur"),
                 "kernel": "k_ba_schur", "bytes_per_launch": int(tm["schur_bytes"]),
                 "avg_launch_us": round(dur * 1e6, 3), "launches_timed": int(sch_n)}
+        # k_ba_schur is fp64-VALU bound, not HBM bound: quote it against the vector fp64 peak too
+        # (AMD's published MI355X figure, 78.6 TFLOP/s; the microarchitecture guide lists none)
+        tf = tm["schur_flops"] / dur / 1e12
+        roof_compute = {"bound": "fp64-valu", "achieved": round(tf, 3), "peak": 78.6, "unit": "TFLOP/s",
+                        "frac": round(tf / 78.6, 4), "flops_per_launch": int(tm["schur_flops"])}
     out = {
         "metric": "lm_iterations_per_sec", "value": round(its * args.steps * world / elapsed, 3),
         "unit": "LM iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -197,6 +202,7 @@ def bench_ba(args, rank, local_rank, world, barrier, dist, torch):
         "upload_seconds_pcie_inclusive": round(upload_s, 6),
         "final_cost": summ.final_cost, "initial_cost": summ.initial_cost,
         "roofline": roof,
+        "roofline_compute": roof_compute if sch_n else None,
     }
     if rank == 0 and world == 1 and not args.no_cpu:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))

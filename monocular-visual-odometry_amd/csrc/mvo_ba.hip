@@ -5,9 +5,9 @@
 //
 // One LM iteration = five launches, enqueued without host round trips:
 //   k_ba_schur    one WAVEFRONT per landmark: per-observation residual + analytic Jacobians,
-//                 landmark block C_j (wave reduction), (C_j + D)^-1, Y = E C^-1, and the outer
-//                 products Y_s E_s'^T accumulated into the workgroup's copy of the reduced camera
-//                 system in LDS (ds_add_f64 -- LDS atomics, never global ones)
+//                 landmark block C_j (wave reduction), (C_j + D)^-1, Y = E C^-1 staged in LDS; then
+//                 one THREAD per 6 x 6 block of the reduced camera system, the block in registers
+//                 for the whole kernel, subtracts Y_s E_s'^T (no atomics, fixed order)
 //   k_ba_reduce   sums the per-workgroup copies (fixed order)
 //   k_ba_solve    one workgroup: damping, dense Cholesky of the <= 168 x 168 system in LDS with the
 //                 right-hand side as an extra row, back substitution, candidate poses
@@ -32,8 +32,10 @@
 #define BA_THREADS 256
 #define BA_WAVES 4
 #define BA_MAXF MVO_HIP_BA_MAX_FREE_FRAMES
-#define BA_STAGE 37                      // doubles per free observation in a wave's LDS stage
-#define BA_WAVE_LDS (BA_STAGE * BA_MAXF + 12)
+#define BA_SCHUR_THREADS 512
+#define BA_SCHUR_WAVES 8
+#define BA_STAGE 51                      // doubles per free observation in a wave's LDS stage:
+                                         // E(18) Y(18) sqrt(w) J_c(12) sqrt(w) r(2) frame(1)
 #define BA_SOLVE_THREADS 512
 #define BA_NOSLOT 0xFFFFu
 
@@ -152,156 +154,255 @@ __device__ __forceinline__ double ba_wave_max(double v) {
   return v;
 }
 
-__device__ __forceinline__ void lds_add(double* p, double v) {
-  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
 // ---------------------------------------------------------------------------------------------
-// k_ba_schur
+// k_ba_schur: 8 wavefronts per workgroup, one workgroup per CU.
+//   phase A  one WAVEFRONT per landmark (8 at a time): lanes walk the landmark's observations --
+//            residual, analytic Jacobians, loss weight; C_j and g_l by a wave reduction;
+//            (C_j + D)^-1; per free observation the blocks E, Y = E C^-1, sqrt(w) J_c and
+//            sqrt(w) r are staged in the wave's LDS area
+//   phase B  one THREAD per 6 x 6 block (f, f2), f <= f2, of the reduced camera system: the block
+//            lives in 36 registers for the whole kernel; for each staged landmark that is seen in
+//            both frames it subtracts Y_s E_s2^T; diagonal owners also add J_c^T J_c and keep
+//            the frame's vectors (rhs, raw gradient, diag B)
+// No atomics of any kind, no LDS read-modify-write, fixed summation order => bitwise reproducible.
 // partS[g][n_blk * 36], partV[g][18 M + 2] = rhs(6M) | g_c(6M) | diag(B)(6M) | cost | gmax(landmarks)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BA_THREADS) void k_ba_schur(BaParams prm, const BaState* __restrict__ st,
-                                                        double radius_override,
-                                                        const double* __restrict__ poses2,
-                                                        const double* __restrict__ X2,
-                                                        const uint32_t* __restrict__ lm_off,
-                                                        const uint32_t* __restrict__ lm_nfree,
-                                                        const uint32_t* __restrict__ obs_frame,
-                                                        const double2* __restrict__ obs_uv,
-                                                        const uint32_t* __restrict__ wg_lm,
-                                                        double* __restrict__ partS, double* __restrict__ partV) {
-  extern __shared__ double lds[];
+struct SchurHdr {  // per staged landmark
+  double gl[3];
+  int32_t n_free, pad;
+  int8_t slot_of[BA_MAXF + 4];  // frame -> slot of the landmark's observation in it, -1 if none
+};
+
+struct LmPre {  // one landmark's header and first 64 observations, fetched one group ahead
+  uint32_t o0, T, Tf, word;
+  double X[3];
+  double2 uv;
+};
+
+template <bool POSES_IN_LDS>
+__global__ __launch_bounds__(BA_SCHUR_THREADS) void k_ba_schur(BaParams prm, const BaState* __restrict__ st,
+                                                              double radius_override,
+                                                              const double* __restrict__ poses2,
+                                                              const double* __restrict__ X2,
+                                                              const uint32_t* __restrict__ lm_off,
+                                                              const uint32_t* __restrict__ lm_nfree,
+                                                              const uint32_t* __restrict__ obs_frame,
+                                                              const double2* __restrict__ obs_uv,
+                                                              const uint32_t* __restrict__ wg_lm,
+                                                              double* __restrict__ partS,
+                                                              double* __restrict__ partV) {
+  extern __shared__ double lds_poses[];  // 12 N doubles when POSES_IN_LDS
+  __shared__ double stage[BA_SCHUR_WAVES][BA_MAXF * BA_STAGE];
+  __shared__ SchurHdr hdr[BA_SCHUR_WAVES];
+  __shared__ double red[2 * BA_SCHUR_WAVES];
   if (st->status != 0) return;
   const int M = prm.M, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t nS = prm.n_blk * 36, nV = 18 * M;
-  double* S = lds;
-  double* V = S + nS;  // rhs | gc | bdiag
-  double* my = V + nV + (size_t)wave * BA_WAVE_LDS;
-  __shared__ double red[2 * BA_WAVES];
-  for (uint32_t i = tid; i < nS + nV; i += BA_THREADS) lds[i] = 0.0;
-  __syncthreads();
   const int cur = st->cur;
   const double radius = radius_override > 0.0 ? radius_override : st->radius;
   const double inv_radius = 1.0 / radius;
-  const double* __restrict__ poses = poses2 + (size_t)cur * 12 * prm.N;
+  const double* __restrict__ poses_g = poses2 + (size_t)cur * 12 * prm.N;
   const double* __restrict__ Xs = X2 + (size_t)cur * 3 * prm.L;
   const uint32_t g = blockIdx.x;
+  if (POSES_IN_LDS) {
+    for (int i = tid; i < 12 * prm.N; i += BA_SCHUR_THREADS) lds_poses[i] = poses_g[i];
+    __syncthreads();
+  }
+  const double* poses = POSES_IN_LDS ? lds_poses : poses_g;
+  // block owned by this thread: tid = ba_blk(M, bf, bf2)
+  const bool owner = (uint32_t)tid < prm.n_blk;
+  int bf = 0;
+  for (int q = 1; q < M; ++q)
+    if ((uint32_t)tid >= ba_blk(M, q, q)) bf = q;
+  const int bf2 = bf + (tid - (int)ba_blk(M, bf, bf));
+  const bool diag_owner = owner && bf == bf2;
+  double acc[36], vr[6], vg[6], vb[6];
+#pragma unroll
+  for (int e = 0; e < 36; ++e) acc[e] = 0.0;
+#pragma unroll
+  for (int e = 0; e < 6; ++e) vr[e] = vg[e] = vb[e] = 0.0;
+  double* my = stage[wave];
   double cost_acc = 0.0, gmax_acc = 0.0;
-  for (uint32_t lm = wg_lm[g] + wave; lm < wg_lm[g + 1]; lm += BA_WAVES) {
-    const uint32_t o0 = lm_off[lm], T = lm_off[lm + 1] - o0, Tf = lm_nfree[lm];
-    const double X[3] = {Xs[3 * lm], Xs[3 * lm + 1], Xs[3 * lm + 2]};
-    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, acc8 = 0.0;  // C(6) gl(2) | gl[2]
-    for (uint32_t base = 0; base < T; base += 64) {
-      const uint32_t t = base + lane;
-      if (t < T) {
-        const uint32_t word = obs_frame[o0 + t], f = word & 0xFFFFu, slot = word >> 16;
-        const double2 uv = obs_uv[o0 + t];
-        BaObs e;
-        ba_obs_eval(poses + 12 * f, X, uv.x, uv.y, prm.loss, prm.loss_scale, e);
-        cost_acc += 0.5 * e.rho;
-        const double w = e.w;
-        acc[0] += w * (e.jx[0] * e.jx[0] + e.jx[3] * e.jx[3]);
-        acc[1] += w * (e.jx[0] * e.jx[1] + e.jx[3] * e.jx[4]);
-        acc[2] += w * (e.jx[0] * e.jx[2] + e.jx[3] * e.jx[5]);
-        acc[3] += w * (e.jx[1] * e.jx[1] + e.jx[4] * e.jx[4]);
-        acc[4] += w * (e.jx[1] * e.jx[2] + e.jx[4] * e.jx[5]);
-        acc[5] += w * (e.jx[2] * e.jx[2] + e.jx[5] * e.jx[5]);
-        acc[6] += w * (e.jx[0] * e.r0 + e.jx[3] * e.r1);
-        acc[7] += w * (e.jx[1] * e.r0 + e.jx[4] * e.r1);
-        acc8 += w * (e.jx[2] * e.r0 + e.jx[5] * e.r1);
-        if (slot != BA_NOSLOT) {
-          double* sg = my + slot * BA_STAGE;
+  const uint32_t lm_begin = wg_lm[g], lm_end = wg_lm[g + 1];
+  // software pipeline over the landmarks of this wavefront: the header of landmark i+2 and the
+  // observations of landmark i+1 are in flight while landmark i is processed
+  auto fetch_hdr = [&](uint32_t lm, LmPre& p) {
+    p.o0 = p.T = p.Tf = 0;
+    if (lm < lm_end) {
+      p.o0 = lm_off[lm];
+      p.T = lm_off[lm + 1] - p.o0;
+      p.Tf = lm_nfree[lm];
+      p.X[0] = Xs[3 * lm];
+      p.X[1] = Xs[3 * lm + 1];
+      p.X[2] = Xs[3 * lm + 2];
+    }
+  };
+  auto fetch_obs = [&](LmPre& p) {
+    if ((uint32_t)lane < p.T) {
+      p.word = obs_frame[p.o0 + lane];
+      p.uv = obs_uv[p.o0 + lane];
+    }
+  };
+  LmPre pa, pb;
+  fetch_hdr(lm_begin + wave, pa);
+  fetch_obs(pa);
+  fetch_hdr(lm_begin + wave + BA_SCHUR_WAVES, pb);
+  for (uint32_t lm0 = lm_begin; lm0 < lm_end; lm0 += BA_SCHUR_WAVES) {
+    // ---------------- phase A ----------------
+    const uint32_t lm = lm0 + wave;
+    const LmPre pc = pa;
+    fetch_obs(pb);
+    pa = pb;
+    fetch_hdr(lm + 2 * BA_SCHUR_WAVES, pb);
+    const uint32_t Tf = pc.Tf;
+    if (lm < lm_end) {
+      const uint32_t o0 = pc.o0, T = pc.T;
+      const double X[3] = {pc.X[0], pc.X[1], pc.X[2]};
+      if (Tf && lane < BA_MAXF + 4) hdr[wave].slot_of[lane] = -1;
+      __builtin_amdgcn_wave_barrier();
+      double a8[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a9 = 0.0;  // C(6) gl(2) | gl[2]
+      for (uint32_t base = 0; base < T; base += 64) {
+        const uint32_t t = base + lane;
+        if (t < T) {
+          uint32_t word = pc.word;
+          double2 uv = pc.uv;
+          if (base) {
+            word = obs_frame[o0 + t];
+            uv = obs_uv[o0 + t];
+          }
+          const uint32_t f = word & 0xFFFFu, slot = word >> 16;
+          BaObs e;
+          ba_obs_eval(poses + 12 * f, X, uv.x, uv.y, prm.loss, prm.loss_scale, e);
+          cost_acc += 0.5 * e.rho;
+          const double w = e.w;
+          a8[0] += w * (e.jx[0] * e.jx[0] + e.jx[3] * e.jx[3]);
+          a8[1] += w * (e.jx[0] * e.jx[1] + e.jx[3] * e.jx[4]);
+          a8[2] += w * (e.jx[0] * e.jx[2] + e.jx[3] * e.jx[5]);
+          a8[3] += w * (e.jx[1] * e.jx[1] + e.jx[4] * e.jx[4]);
+          a8[4] += w * (e.jx[1] * e.jx[2] + e.jx[4] * e.jx[5]);
+          a8[5] += w * (e.jx[2] * e.jx[2] + e.jx[5] * e.jx[5]);
+          a8[6] += w * (e.jx[0] * e.r0 + e.jx[3] * e.r1);
+          a8[7] += w * (e.jx[1] * e.r0 + e.jx[4] * e.r1);
+          a9 += w * (e.jx[2] * e.r0 + e.jx[5] * e.r1);
+          if (slot != BA_NOSLOT) {
+            double* sg = my + slot * BA_STAGE;
+            const double sw = sqrt(w);
 #pragma unroll
-          for (int p = 0; p < 6; ++p)
+            for (int p = 0; p < 6; ++p)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) sg[3 * p + q] = w * (e.jc[p] * e.jx[q] + e.jc[6 + p] * e.jx[3 + q]);  // E
-          sg[36] = (double)f;
-          double* Bff = S + ba_blk(M, f, f) * 36;
+              for (int q = 0; q < 3; ++q) sg[3 * p + q] = w * (e.jc[p] * e.jx[q] + e.jc[6 + p] * e.jx[3 + q]);  // E
+#pragma unroll
+            for (int p = 0; p < 12; ++p) sg[36 + p] = sw * e.jc[p];
+            sg[48] = sw * e.r0;
+            sg[49] = sw * e.r1;
+            sg[50] = (double)f;
+            hdr[wave].slot_of[f] = (int8_t)slot;
+          }
+        }
+      }
+    double tot[8];
+      wave_reduce8_all(a8, lane, tot);
+      const double gl2 = ba_wave_sum(a9);
+      gmax_acc = fmax(gmax_acc, fmax(fabs(tot[6]), fmax(fabs(tot[7]), fabs(gl2))));
+      if (Tf) {
+        double C[6] = {tot[0], tot[1], tot[2], tot[3], tot[4], tot[5]}, Ci[6];
+        C[0] += ba_clamp_diag(C[0]) * inv_radius;
+        C[3] += ba_clamp_diag(C[3]) * inv_radius;
+        C[5] += ba_clamp_diag(C[5]) * inv_radius;
+        ba_inv3(C, Ci);
+        __builtin_amdgcn_wave_barrier();
+        if ((uint32_t)lane < Tf) {  // Y = E C^-1
+          double* sg = my + lane * BA_STAGE;
+#pragma unroll
+          for (int p = 0; p < 6; ++p) {
+            const double e0 = sg[3 * p], e1 = sg[3 * p + 1], e2 = sg[3 * p + 2];
+            sg[18 + 3 * p] = e0 * Ci[0] + e1 * Ci[1] + e2 * Ci[2];
+            sg[18 + 3 * p + 1] = e0 * Ci[1] + e1 * Ci[3] + e2 * Ci[4];
+            sg[18 + 3 * p + 2] = e0 * Ci[2] + e1 * Ci[4] + e2 * Ci[5];
+          }
+        }
+        if (lane == 0) {
+          hdr[wave].gl[0] = tot[6];
+          hdr[wave].gl[1] = tot[7];
+          hdr[wave].gl[2] = gl2;
+        }
+      }
+    }
+    if (lane == 0) hdr[wave].n_free = (int32_t)Tf;
+    __syncthreads();
+    // ---------------- phase B ----------------
+    if (owner) {
+#pragma unroll 1
+      for (int q = 0; q < BA_SCHUR_WAVES; ++q) {
+        if (hdr[q].n_free == 0) continue;  // uniform
+        const int s = hdr[q].slot_of[bf], s2 = hdr[q].slot_of[bf2];
+        if (s < 0 || s2 < 0) continue;
+        const double* __restrict__ ys = stage[q] + s * BA_STAGE + 18;
+        const double* __restrict__ es = stage[q] + s2 * BA_STAGE;
+        double Y[18], E[18];
+#pragma unroll
+        for (int i = 0; i < 18; ++i) {
+          Y[i] = ys[i];
+          E[i] = es[i];
+        }
+#pragma unroll
+        for (int p = 0; p < 6; ++p)
+#pragma unroll
+          for (int c = 0; c < 6; ++c)
+            acc[6 * p + c] -= Y[3 * p] * E[3 * c] + Y[3 * p + 1] * E[3 * c + 1] + Y[3 * p + 2] * E[3 * c + 2];
+        if (diag_owner) {  // B_ff += J_c^T J_c, g_c += J_c^T r, rhs += g_c - Y g_l
+          const double* __restrict__ js = stage[q] + s * BA_STAGE + 36;
+          double J[12];
+#pragma unroll
+          for (int i = 0; i < 12; ++i) J[i] = js[i];
+          const double r0 = js[12], r1 = js[13];
+          const double g0 = hdr[q].gl[0], g1 = hdr[q].gl[1], g2 = hdr[q].gl[2];
 #pragma unroll
           for (int p = 0; p < 6; ++p) {
 #pragma unroll
-            for (int q = 0; q < 6; ++q) lds_add(Bff + 6 * p + q, w * (e.jc[p] * e.jc[q] + e.jc[6 + p] * e.jc[6 + q]));
-            const double gcp = w * (e.jc[p] * e.r0 + e.jc[6 + p] * e.r1);
-            lds_add(V + 6 * f + p, gcp);
-            lds_add(V + 6 * M + 6 * f + p, gcp);
-            lds_add(V + 12 * M + 6 * f + p, w * (e.jc[p] * e.jc[p] + e.jc[6 + p] * e.jc[6 + p]));
+            for (int c = 0; c < 6; ++c) acc[6 * p + c] += J[p] * J[c] + J[6 + p] * J[6 + c];
+            const double gcp = J[p] * r0 + J[6 + p] * r1;
+            vg[p] += gcp;
+            vr[p] += gcp - (Y[3 * p] * g0 + Y[3 * p + 1] * g1 + Y[3 * p + 2] * g2);
+            vb[p] += J[p] * J[p] + J[6 + p] * J[6 + p];
           }
         }
       }
     }
-    double tot[8];
-    wave_reduce8_all(acc, lane, tot);
-    const double gl2 = ba_wave_sum(acc8);
-    const double gl[3] = {tot[6], tot[7], gl2};
-    gmax_acc = fmax(gmax_acc, fmax(fabs(gl[0]), fmax(fabs(gl[1]), fabs(gl[2]))));
-    if (Tf == 0) continue;  // seen from fixed frames only: nothing for the camera system
-    double C[6] = {tot[0], tot[1], tot[2], tot[3], tot[4], tot[5]}, Ci[6];
-    C[0] += ba_clamp_diag(C[0]) * inv_radius;
-    C[3] += ba_clamp_diag(C[3]) * inv_radius;
-    C[5] += ba_clamp_diag(C[5]) * inv_radius;
-    ba_inv3(C, Ci);
-    __builtin_amdgcn_wave_barrier();
-    if ((uint32_t)lane < Tf) {  // Y = E C^-1, rhs -= Y g_l
-      double* sg = my + lane * BA_STAGE;
-      const int f = (int)sg[36];
-#pragma unroll
-      for (int p = 0; p < 6; ++p) {
-        const double e0 = sg[3 * p], e1 = sg[3 * p + 1], e2 = sg[3 * p + 2];
-        const double y0 = e0 * Ci[0] + e1 * Ci[1] + e2 * Ci[2];
-        const double y1 = e0 * Ci[1] + e1 * Ci[3] + e2 * Ci[4];
-        const double y2 = e0 * Ci[2] + e1 * Ci[4] + e2 * Ci[5];
-        sg[18 + 3 * p] = y0;
-        sg[18 + 3 * p + 1] = y1;
-        sg[18 + 3 * p + 2] = y2;
-        lds_add(V + 6 * f + p, -(y0 * gl[0] + y1 * gl[1] + y2 * gl[2]));
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-    const uint32_t npairs = (Tf * (Tf + 1)) / 2;
-    for (uint32_t q = lane; q < npairs; q += 64) {
-      // q = s2 (s2 + 1) / 2 + s, s <= s2 (slots are sorted by frame on upload)
-      uint32_t s2 = (uint32_t)((sqrtf(8.0f * (float)q + 1.0f) - 1.0f) * 0.5f);
-      while ((s2 + 1) * (s2 + 2) / 2 <= q) ++s2;
-      while (s2 * (s2 + 1) / 2 > q) --s2;
-      const uint32_t s = q - s2 * (s2 + 1) / 2;
-      const double* ys = my + s * BA_STAGE + 18;
-      const double* es = my + s2 * BA_STAGE;
-      const uint32_t f = (uint32_t)my[s * BA_STAGE + 36], f2 = (uint32_t)my[s2 * BA_STAGE + 36];
-      double Y[18], E[18];
-#pragma unroll
-      for (int i = 0; i < 18; ++i) {
-        Y[i] = ys[i];
-        E[i] = es[i];
-      }
-      double* blk = S + ba_blk(M, f, f2) * 36;
-      const bool twin = (f == f2) && (s != s2);  // two observations of the landmark in one frame
-#pragma unroll
-      for (int p = 0; p < 6; ++p)
-#pragma unroll
-        for (int c2 = 0; c2 < 6; ++c2) {
-          const double v = -(Y[3 * p] * E[3 * c2] + Y[3 * p + 1] * E[3 * c2 + 1] + Y[3 * p + 2] * E[3 * c2 + 2]);
-          lds_add(blk + 6 * p + c2, v);
-          if (twin) lds_add(blk + 6 * c2 + p, v);
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
   }
   // workgroup totals
   cost_acc = ba_wave_sum(cost_acc);
   gmax_acc = ba_wave_max(gmax_acc);
   if (lane == 0) {
     red[wave] = cost_acc;
-    red[BA_WAVES + wave] = gmax_acc;
+    red[BA_SCHUR_WAVES + wave] = gmax_acc;
   }
   __syncthreads();
   double* __restrict__ oS = partS + (size_t)g * nS;
   double* __restrict__ oV = partV + (size_t)g * (nV + 2);
-  for (uint32_t i = tid; i < nS; i += BA_THREADS) oS[i] = S[i];
-  for (uint32_t i = tid; i < nV; i += BA_THREADS) oV[i] = V[i];
+  if (owner) {
+#pragma unroll
+    for (int e = 0; e < 36; ++e) oS[(size_t)tid * 36 + e] = acc[e];
+    if (diag_owner) {
+#pragma unroll
+      for (int p = 0; p < 6; ++p) {
+        oV[6 * bf + p] = vr[p];
+        oV[6 * M + 6 * bf + p] = vg[p];
+        oV[12 * M + 6 * bf + p] = vb[p];
+      }
+    }
+  }
   if (tid == 0) {
-    oV[nV] = (red[0] + red[1]) + (red[2] + red[3]);
-    oV[nV + 1] = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
+    double c = 0.0, m = 0.0;
+#pragma unroll
+    for (int q = 0; q < BA_SCHUR_WAVES; ++q) {
+      c += red[q];
+      m = fmax(m, red[BA_SCHUR_WAVES + q]);
+    }
+    oV[nV] = c;
+    oV[nV + 1] = m;
   }
 }
 
@@ -389,16 +490,25 @@ __global__ __launch_bounds__(BA_SOLVE_THREADS) void k_ba_solve(BaParams prm, BaS
                                                               double* __restrict__ poses2,
                                                               double* __restrict__ delta_c) {
   extern __shared__ double Lf[];  // (M+1)(M+2)/2 blocks x 36: the factor, block (ib, jb) at tri(ib, jb)
-  __shared__ double pubX[2][BA_MAXF + 1][36], pubW[2][BA_MAXF + 1][36];
-  __shared__ double dl[2][36], dd[2][6], dinvs[2][6];
-  __shared__ double xs[6 * BA_MAXF], dc2[6 * BA_MAXF], dinv[6 * BA_MAXF];
+  // X rows are read at a per-lane block index: 37-double rows keep those reads off a common bank
+  __shared__ double pubX[2][BA_MAXF + 1][37], pubW[2][BA_MAXF + 1][36];
+  __shared__ double dl[2][36], dinvs[2][6];
+  __shared__ double xs[6 * BA_MAXF], dc2[6 * BA_MAXF];
   __shared__ int bad_flag;
   if (st->status != 0) return;
   const uint32_t M = prm.M, n = 6 * M, tid = threadIdx.x;
   const double radius = st->radius;
   // gradient tolerance first: it is tested at the top of an iteration
+  __shared__ double gmw[BA_SOLVE_THREADS / 64];
+  {
+    double v = tid < n ? fabs(redV[6 * M + tid]) : 0.0;
+    v = ba_wave_max(v);
+    if ((tid & 63) == 0) gmw[tid >> 6] = v;
+  }
+  __syncthreads();
   double gm = redV[18 * M + 1];
-  for (uint32_t i = 0; i < n; ++i) gm = fmax(gm, fabs(redV[6 * M + i]));  // uniform, L2-resident
+#pragma unroll
+  for (int q = 0; q < BA_SOLVE_THREADS / 64; ++q) gm = fmax(gm, gmw[q]);
   if (gm <= prm.gtol) {
     if (tid == 0) {
       st->gmax = gm;
@@ -451,7 +561,7 @@ __global__ __launch_bounds__(BA_SOLVE_THREADS) void k_ba_solve(BaParams prm, BaS
         for (int p = 0; p < c; ++p) dcv -= a[6 * c + p] * a[6 * c + p] * d[p];
         if (!(dcv > 0.0) || isinf(dcv)) ok = false;
         d[c] = dcv;
-        iv[c] = 1.0 / dcv;
+        iv[c] = ba_rcp(dcv);
 #pragma unroll
         for (int r = c + 1; r < 6; ++r) {
           double v = a[6 * r + c];
@@ -464,9 +574,7 @@ __global__ __launch_bounds__(BA_SOLVE_THREADS) void k_ba_solve(BaParams prm, BaS
       for (int e = 0; e < 36; ++e) dl[buf][e] = a[e];
 #pragma unroll
       for (int c = 0; c < 6; ++c) {
-        dd[buf][c] = d[c];
         dinvs[buf][c] = iv[c];
-        dinv[6 * kb + c] = iv[c];
       }
       if (!ok) bad_flag = 1;
     }
@@ -493,20 +601,22 @@ __global__ __launch_bounds__(BA_SOLVE_THREADS) void k_ba_solve(BaParams prm, BaS
         }
     }
     __syncthreads();
-    if (have && jb > kb) {  // (3) A_(ib,jb) -= W_ib X_jb^T
+    if (have && jb > kb) {  // (3) A_(ib,jb) -= W_ib X_jb^T, both operands read once
+      double x[36], wv[36];
 #pragma unroll
-      for (int r = 0; r < 6; ++r) {
-        double w[6];
+      for (int e = 0; e < 36; ++e) {
+        x[e] = pubX[buf][jb][e];
+        wv[e] = pubW[buf][ib][e];
+      }
 #pragma unroll
-        for (int p = 0; p < 6; ++p) w[p] = pubW[buf][ib][6 * r + p];
+      for (int r = 0; r < 6; ++r)
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
           double acc = a[6 * r + c];
 #pragma unroll
-          for (int p = 0; p < 6; ++p) acc -= w[p] * pubX[buf][jb][6 * c + p];
+          for (int p = 0; p < 6; ++p) acc -= wv[6 * r + p] * x[6 * c + p];
           a[6 * r + c] = acc;
         }
-      }
     }
   }
   __syncthreads();
@@ -861,7 +971,8 @@ struct mvo_hip_ba_context {
   hipEvent_t ev[2 + 2 * kMaxSchurEvents] = {};
   bool events_ready = false;
   mvo_hip_ba_timing timing{};
-  size_t schur_lds = 0, solve_lds = 0;
+  size_t solve_lds = 0;
+  uint64_t schur_flops = 0;
 };
 
 namespace {
@@ -914,6 +1025,7 @@ int ba_upload(mvo_hip_ba_context* h, const mvo_hip_ba_pose* poses, uint32_t M, u
       const uint32_t src = order[k], f = obs->frame[src];
       const uint64_t dst = o0 + k;
       uint32_t sl = BA_NOSLOT;
+      if (f < M && k > 0 && obs->frame[order[k - 1]] == f) return MVO_HIP_ERR_UNSUPPORTED;  // one observation per (landmark, frame)
       if (f < M) {
         if (slot >= BA_MAXF) return MVO_HIP_ERR_UNSUPPORTED;  // > 28 observations of one landmark in free frames
         sl = slot++;
@@ -927,6 +1039,11 @@ int ba_upload(mvo_hip_ba_context* h, const mvo_hip_ba_pose* poses, uint32_t M, u
     lm_nfree[j] = slot;
   }
   lm_off[L] = (uint32_t)n_obs;
+  {
+    uint64_t fl = 96ull * n_obs;
+    for (uint32_t j = 0; j < L; ++j) fl += 380ull * lm_nfree[j] + 216ull * ((uint64_t)lm_nfree[j] * (lm_nfree[j] + 1) / 2);
+    h->schur_flops = fl;
+  }
 
   // landmarks -> workgroups: contiguous ranges of about equal load (observations + one unit per
   // landmark).  k_ba_schur holds the reduced camera system per workgroup: one workgroup per CU;
@@ -943,7 +1060,7 @@ int ba_upload(mvo_hip_ba_context* h, const mvo_hip_ba_pose* poses, uint32_t M, u
       if (w[q] < w[q - 1]) w[q] = w[q - 1];
     return w;
   };
-  const uint32_t n_wg = (uint32_t)std::min<uint64_t>((uint64_t)n_cu, std::max<uint64_t>(1, (L + 4 * BA_WAVES - 1) / (4 * BA_WAVES)));
+  const uint32_t n_wg = (uint32_t)std::min<uint64_t>((uint64_t)n_cu, std::max<uint64_t>(1, (L + 2 * BA_SCHUR_WAVES - 1) / (2 * BA_SCHUR_WAVES)));
   const uint32_t n_wg_step = (uint32_t)std::min<uint64_t>(8ull * n_cu, std::max<uint64_t>(1, (L + 2 * BA_WAVES - 1) / (2 * BA_WAVES)));
   const std::vector<uint32_t> wg_lm = partition(n_wg), wg_lm_step = partition(n_wg_step);
 
@@ -997,10 +1114,9 @@ int ba_upload(mvo_hip_ba_context* h, const mvo_hip_ba_pose* poses, uint32_t M, u
   }
   BA_TRY(hipStreamSynchronize(s));
 
-  h->schur_lds = sizeof(double) * (nS + 18 * (size_t)M + (size_t)BA_WAVES * BA_WAVE_LDS);
+  BA_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ba_schur<true>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 12 * 512 * (int)sizeof(double)));
   h->solve_lds = sizeof(double) * 36 * ((size_t)(M + 1) * (M + 2) / 2);
-  BA_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ba_schur), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             (int)h->schur_lds));
   BA_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ba_solve), hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)h->solve_lds));
   h->uploaded = true;
@@ -1028,7 +1144,11 @@ int ba_reset_point(mvo_hip_ba_context* h) {
 }
 
 hipError_t launch_schur(mvo_hip_ba_context* h, double radius_override) {
-  hipLaunchKernelGGL(k_ba_schur, dim3(h->prm.n_wg), dim3(BA_THREADS), h->schur_lds, h->stream, h->prm,
+  // poses of up to 512 frames are staged in LDS (48 KB); larger windows read them through L2
+  const bool in_lds = h->prm.N <= 512;
+  const size_t dyn = in_lds ? sizeof(double) * 12 * (size_t)h->prm.N : 0;
+  auto kern = in_lds ? &k_ba_schur<true> : &k_ba_schur<false>;
+  hipLaunchKernelGGL(kern, dim3(h->prm.n_wg), dim3(BA_SCHUR_THREADS), dyn, h->stream, h->prm,
                      h->d_state.as<BaState>(), radius_override, h->d_poses.as<double>(), h->d_X.as<double>(),
                      h->d_lm_off.as<uint32_t>(), h->d_lm_nfree.as<uint32_t>(), h->d_obs_frame.as<uint32_t>(),
                      h->d_obs_uv.as<double2>(), h->d_wg_lm.as<uint32_t>(), h->d_partS.as<double>(),
@@ -1110,6 +1230,7 @@ int ba_solve(mvo_hip_ba_context* h) {
   tm.device_seconds = tm.schur_seconds = 0.0;
   tm.observations = h->n_obs;
   tm.schur_bytes = 20ull * h->n_obs + 24ull * L;  // (u, v) + frame word per observation, X per landmark
+  tm.schur_flops = h->schur_flops;
   // launches that found the solve finished return at once: count only the linearisations that ran
   const int ran = std::min(n_schur, h->h_state.iteration + (h->h_state.termination == 0 ? 1 : 0));
   tm.schur_launches = 0;

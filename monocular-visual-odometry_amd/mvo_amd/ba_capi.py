@@ -43,7 +43,8 @@ class Iteration(C.Structure):
 class Timing(C.Structure):
     _fields_ = [("upload_seconds", C.c_double), ("solve_seconds", C.c_double), ("device_seconds", C.c_double),
                 ("schur_seconds", C.c_double), ("schur_launches", C.c_int32), ("reserved", C.c_int32),
-                ("observations", C.c_uint64), ("schur_bytes", C.c_uint64)]
+                ("observations", C.c_uint64), ("schur_bytes", C.c_uint64),
+                ("schur_flops", C.c_uint64)]
 
 
 def make_options(max_num_iterations=10, loss=LOSS_NONE, loss_scale=0.01, function_tolerance=1e-6,

@@ -40,7 +40,7 @@ def test_ba_header_symbols_are_exported_and_bound():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/mvo_hip_ba.h but not exported"
     assert C.sizeof(ba_capi.Options) == 48 and C.sizeof(ba_capi.Summary) == 32
-    assert C.sizeof(ba_capi.Iteration) == 56 and C.sizeof(ba_capi.Timing) == 56
+    assert C.sizeof(ba_capi.Iteration) == 56 and C.sizeof(ba_capi.Timing) == 64
     with pytest.raises(capi.MvoHipError) as e:
         ba_capi.BaSolver(0)
     assert e.value.status == capi.ERR_NO_DEVICE
