@@ -115,6 +115,27 @@ int mvo_hip_ba_eval(mvo_hip_ba_handle h, double *residuals, double *cost);
 int mvo_hip_ba_reduced(mvo_hip_ba_handle h, double radius, double *S, double *rhs, double *camera_gradient,
                        double *gradient_max_norm, double *cost);
 
+/* Landmark-partitioned solve over several GPUs (BASELINE.json configs[3]: "partitioned over 8 GPUs
+ * with RCCL all-reduce of Schur blocks").  Every rank uploads ALL poses and ITS range of the
+ * landmarks with their observations.  The reduced camera system and the step sums are additive
+ * over landmarks; the caller all-reduces them between the calls and every rank then takes the
+ * identical LM step (no broadcast).  One iteration:
+ *     partial_linearize;  exchange(0, out) -> all-reduce SUM -> exchange(0, in);
+ *                         exchange(1, out) -> all-reduce MAX -> exchange(1, in);
+ *     partial_solve;      exchange(2, out) -> all-reduce SUM -> exchange(2, in);
+ *     partial_decide(1, &done)
+ * preceded once by partial_begin; exchange(2 ...); partial_decide(0, &done).  When done is set the
+ * results are ready for mvo_hip_ba_download (poses identical on every rank, landmarks = the rank's
+ * own).  exchange copies between the library's buffers and a caller-owned DEVICE buffer
+ * (direction 0: library -> buffer, 1: buffer -> library); sizes: which 0:
+ * 18 M (M + 1) + 18 M + 1 doubles, which 1: 1, which 2: 4.  Every call drains the stream. */
+int mvo_hip_ba_partial_begin(mvo_hip_ba_handle h);
+int mvo_hip_ba_partial_linearize(mvo_hip_ba_handle h);
+int mvo_hip_ba_partial_solve(mvo_hip_ba_handle h);
+int mvo_hip_ba_partial_decide(mvo_hip_ba_handle h, int mode, int32_t *done);
+int mvo_hip_ba_partial_exchange(mvo_hip_ba_handle h, int which, void *device_buffer, uint64_t n_doubles,
+                                int direction);
+
 int mvo_hip_ba_set_trace(mvo_hip_ba_handle h, int32_t capacity);
 int mvo_hip_ba_get_trace(mvo_hip_ba_handle h, mvo_hip_ba_iteration *rows, int32_t capacity, int32_t *n_rows);
 int mvo_hip_ba_set_profiling(mvo_hip_ba_handle h, int enabled);

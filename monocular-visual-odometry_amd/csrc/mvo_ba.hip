@@ -797,6 +797,21 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_step(BaParams prm, const BaSt
   if (tid < 4) partT[(size_t)g * 4 + tid] = (red[4 * tid] + red[4 * tid + 1]) + (red[4 * tid + 2] + red[4 * tid + 3]);
 }
 
+// partitioned mode: this rank's four sums in one place, ready for the caller's all-reduce
+__global__ __launch_bounds__(64) void k_ba_sum4(BaParams prm, const BaState* __restrict__ st, int mode,
+                                               const double* __restrict__ partT, double* __restrict__ sums4) {
+  if (st->status != 0) return;
+  const int lane = threadIdx.x;
+  double v[4] = {0, 0, 0, 0};
+  if (mode == 0 || !st->step_bad)
+    for (uint32_t g = lane; g < prm.n_wg_step; g += 64)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] += partT[(size_t)g * 4 + k];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = ba_wave_sum(v[k]);
+  if (lane < 4) sums4[lane] = lane == 0 ? v[0] : (lane == 1 ? v[1] : (lane == 2 ? v[2] : v[3]));
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_ba_decide: the trust-region rules of include/mvo_hip_ba.h on the device-resident state
 // ---------------------------------------------------------------------------------------------
@@ -956,7 +971,7 @@ struct mvo_hip_ba_context {
   hipStream_t stream = nullptr;
   hipError_t last_hip_error = hipSuccess;
   Buf d_poses, d_X, d_lm_off, d_lm_nfree, d_obs_frame, d_obs_uv, d_obs_lm, d_obs_src, d_wg_lm, d_wg_lm_step, d_partS, d_partV,
-      d_redS, d_redV, d_partT, d_delta, d_state, d_trace, d_res;
+      d_redS, d_redV, d_partT, d_delta, d_state, d_trace, d_res, d_sums4;
   bool uploaded = false;
   BaParams prm{};
   uint64_t n_obs = 0;
@@ -1162,16 +1177,93 @@ hipError_t launch_schur(mvo_hip_ba_context* h, double radius_override) {
   return hipGetLastError();
 }
 
-hipError_t launch_step(mvo_hip_ba_context* h, int mode) {
+hipError_t launch_step_only(mvo_hip_ba_context* h, int mode) {
   hipLaunchKernelGGL(k_ba_step, dim3(h->prm.n_wg_step), dim3(BA_THREADS), 0, h->stream, h->prm,
                      h->d_state.as<BaState>(), mode, h->d_poses.as<double>(), h->d_X.as<double>(),
                      h->d_delta.as<double>(), h->d_lm_off.as<uint32_t>(), h->d_obs_frame.as<uint32_t>(),
                      h->d_obs_uv.as<double2>(), h->d_wg_lm_step.as<uint32_t>(), h->d_partT.as<double>());
-  hipError_t e = hipGetLastError();
+  return hipGetLastError();
+}
+
+hipError_t launch_step(mvo_hip_ba_context* h, int mode) {
+  hipError_t e = launch_step_only(h, mode);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_ba_decide, dim3(1), dim3(64), 0, h->stream, h->prm, h->d_state.as<BaState>(), mode,
                      h->d_partT.as<double>(), h->d_trace.as<BaTrace>());
   return hipGetLastError();
+}
+
+// ---- landmark-partitioned mode: every rank holds all poses and a range of the landmarks; the
+// reduced camera system and the step sums are additive over landmarks, so the caller all-reduces
+// them between these calls and every rank takes the identical LM step.  Each call drains the stream.
+int ba_fetch_results(mvo_hip_ba_context* h) {
+  hipStream_t s = h->stream;
+  const uint32_t N = h->prm.N, L = h->prm.L;
+  const int cur = h->h_state.cur;
+  h->h_poses.resize(N);
+  h->h_X.resize(3 * (size_t)L);
+  BA_TRY(hipMemcpyAsync(h->h_poses.data(), h->d_poses.as<double>() + (size_t)cur * 12 * N, sizeof(double) * 12 * N,
+                        hipMemcpyDeviceToHost, s));
+  BA_TRY(hipMemcpyAsync(h->h_X.data(), h->d_X.as<double>() + (size_t)cur * 3 * L, sizeof(double) * 3 * L,
+                        hipMemcpyDeviceToHost, s));
+  BA_TRY(hipStreamSynchronize(s));
+  h->solved = true;
+  return MVO_HIP_OK;
+}
+
+int ba_partial_sum4(mvo_hip_ba_context* h, int mode) {
+  BA_TRY(h->d_sums4.reserve(sizeof(double) * 4));
+  hipLaunchKernelGGL(k_ba_sum4, dim3(1), dim3(64), 0, h->stream, h->prm, h->d_state.as<BaState>(), mode,
+                     h->d_partT.as<double>(), h->d_sums4.as<double>());
+  BA_TRY(hipGetLastError());
+  BA_TRY(hipStreamSynchronize(h->stream));
+  return MVO_HIP_OK;
+}
+
+int ba_partial_begin(mvo_hip_ba_context* h) {
+  if (!h->uploaded) return MVO_HIP_ERR_STATE;
+  BA_TRY(hipSetDevice(h->device));
+  h->prm.trace_cap = (uint32_t)h->trace_cap;
+  if (h->trace_cap > 0) BA_TRY(h->d_trace.reserve(sizeof(BaTrace) * (size_t)h->trace_cap));
+  int rc = ba_reset_point(h);
+  if (rc != MVO_HIP_OK) return rc;
+  h->solved = false;
+  BA_TRY(launch_step_only(h, 0));
+  return ba_partial_sum4(h, 0);
+}
+
+int ba_partial_linearize(mvo_hip_ba_context* h) {
+  if (!h->uploaded) return MVO_HIP_ERR_STATE;
+  BA_TRY(hipSetDevice(h->device));
+  BA_TRY(launch_schur(h, 0.0));
+  BA_TRY(hipStreamSynchronize(h->stream));
+  return MVO_HIP_OK;
+}
+
+int ba_partial_solve(mvo_hip_ba_context* h) {
+  if (!h->uploaded) return MVO_HIP_ERR_STATE;
+  BA_TRY(hipSetDevice(h->device));
+  hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(BA_SOLVE_THREADS), h->solve_lds, h->stream, h->prm,
+                     h->d_state.as<BaState>(), h->d_redS.as<double>(), h->d_redV.as<double>(),
+                     h->d_poses.as<double>(), h->d_delta.as<double>());
+  BA_TRY(hipGetLastError());
+  BA_TRY(launch_step_only(h, 1));
+  return ba_partial_sum4(h, 1);
+}
+
+int ba_partial_decide(mvo_hip_ba_context* h, int mode, int32_t* done) {
+  if (!h->uploaded || !h->d_sums4.p) return MVO_HIP_ERR_STATE;
+  BA_TRY(hipSetDevice(h->device));
+  BaParams one = h->prm;
+  one.n_wg_step = 1;  // the four sums are already complete (this rank's, or all ranks' after the all-reduce)
+  hipLaunchKernelGGL(k_ba_decide, dim3(1), dim3(64), 0, h->stream, one, h->d_state.as<BaState>(), mode,
+                     h->d_sums4.as<double>(), h->d_trace.as<BaTrace>());
+  BA_TRY(hipGetLastError());
+  BA_TRY(hipMemcpyAsync(&h->h_state, h->d_state.p, sizeof(BaState), hipMemcpyDeviceToHost, h->stream));
+  BA_TRY(hipStreamSynchronize(h->stream));
+  const bool fin = h->h_state.status != 0;
+  if (done) *done = fin ? 1 : 0;
+  return fin ? ba_fetch_results(h) : MVO_HIP_OK;
 }
 
 int ba_solve(mvo_hip_ba_context* h) {
@@ -1290,7 +1382,7 @@ void mvo_hip_ba_destroy(mvo_hip_ba_handle h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   Buf* bufs[] = {&h->d_poses, &h->d_X, &h->d_lm_off, &h->d_lm_nfree, &h->d_obs_frame, &h->d_obs_uv, &h->d_obs_lm,
                  &h->d_obs_src, &h->d_wg_lm, &h->d_wg_lm_step, &h->d_partS, &h->d_partV, &h->d_redS, &h->d_redV, &h->d_partT,
-                 &h->d_delta, &h->d_state, &h->d_trace, &h->d_res};
+                 &h->d_delta, &h->d_state, &h->d_trace, &h->d_res, &h->d_sums4};
   for (Buf* b : bufs) b->release();
   if (h->events_ready)
     for (auto& e : h->ev) (void)hipEventDestroy(e);
@@ -1387,6 +1479,43 @@ int mvo_hip_ba_reduced(mvo_hip_ba_handle h, double radius, double* S, double* rh
   }
   if (gradient_max_norm) *gradient_max_norm = gm;
   if (cost) *cost = V[18 * M];
+  return MVO_HIP_OK;
+}
+
+int mvo_hip_ba_partial_begin(mvo_hip_ba_handle h) { return h ? ba_partial_begin(h) : MVO_HIP_ERR_INVALID_ARGUMENT; }
+int mvo_hip_ba_partial_linearize(mvo_hip_ba_handle h) {
+  return h ? ba_partial_linearize(h) : MVO_HIP_ERR_INVALID_ARGUMENT;
+}
+int mvo_hip_ba_partial_solve(mvo_hip_ba_handle h) { return h ? ba_partial_solve(h) : MVO_HIP_ERR_INVALID_ARGUMENT; }
+int mvo_hip_ba_partial_decide(mvo_hip_ba_handle h, int mode, int32_t* done) {
+  if (!h || (mode != 0 && mode != 1)) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  return ba_partial_decide(h, mode, done);
+}
+
+int mvo_hip_ba_partial_exchange(mvo_hip_ba_handle h, int which, void* device_buffer, uint64_t n_doubles,
+                                int direction) {
+  if (!h || !device_buffer || which < 0 || which > 2) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  if (!h->uploaded) return MVO_HIP_ERR_STATE;
+  const uint64_t nS = (uint64_t)h->prm.n_blk * 36, nVs = 18ull * h->prm.M + 1;
+  BA_TRY(hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  double* buf = static_cast<double*>(device_buffer);
+  auto move = [&](double* lib, double* usr, uint64_t n) {
+    return direction == 0 ? hipMemcpyAsync(usr, lib, sizeof(double) * n, hipMemcpyDeviceToDevice, s)
+                          : hipMemcpyAsync(lib, usr, sizeof(double) * n, hipMemcpyDeviceToDevice, s);
+  };
+  if (which == 0) {  // reduced camera system blocks, then rhs | g_c | diag(B) | cost: sums
+    if (n_doubles != nS + nVs) return MVO_HIP_ERR_INVALID_ARGUMENT;
+    BA_TRY(move(h->d_redS.as<double>(), buf, nS));
+    BA_TRY(move(h->d_redV.as<double>(), buf + nS, nVs));
+  } else if (which == 1) {  // largest landmark gradient entry: a maximum
+    if (n_doubles != 1) return MVO_HIP_ERR_INVALID_ARGUMENT;
+    BA_TRY(move(h->d_redV.as<double>() + nVs, buf, 1));
+  } else {  // cost | model-cost-change part | |dl|^2 | |X|^2: sums
+    if (n_doubles != 4 || !h->d_sums4.p) return MVO_HIP_ERR_INVALID_ARGUMENT;
+    BA_TRY(move(h->d_sums4.as<double>(), buf, 4));
+  }
+  BA_TRY(hipStreamSynchronize(s));
   return MVO_HIP_OK;
 }
 

@@ -11,7 +11,9 @@ from . import capi
 EXPORTED_SYMBOLS = [
     "mvo_hip_ba_create", "mvo_hip_ba_destroy", "mvo_hip_ba_refine", "mvo_hip_ba_upload", "mvo_hip_ba_solve",
     "mvo_hip_ba_download", "mvo_hip_ba_eval", "mvo_hip_ba_reduced", "mvo_hip_ba_set_trace",
-    "mvo_hip_ba_get_trace", "mvo_hip_ba_set_profiling", "mvo_hip_ba_get_timing",
+    "mvo_hip_ba_get_trace", "mvo_hip_ba_set_profiling", "mvo_hip_ba_get_timing", "mvo_hip_ba_partial_begin",
+    "mvo_hip_ba_partial_linearize", "mvo_hip_ba_partial_solve", "mvo_hip_ba_partial_decide",
+    "mvo_hip_ba_partial_exchange",
 ]
 
 MAX_FREE_FRAMES = 28
@@ -72,6 +74,11 @@ def load():
         L.mvo_hip_ba_eval.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
         L.mvo_hip_ba_reduced.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.mvo_hip_ba_partial_begin.argtypes = [C.c_void_p]
+        L.mvo_hip_ba_partial_linearize.argtypes = [C.c_void_p]
+        L.mvo_hip_ba_partial_solve.argtypes = [C.c_void_p]
+        L.mvo_hip_ba_partial_decide.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int32)]
+        L.mvo_hip_ba_partial_exchange.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_int]
         L.mvo_hip_ba_set_trace.argtypes = [C.c_void_p, C.c_int32]
         L.mvo_hip_ba_get_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
         L.mvo_hip_ba_set_profiling.argtypes = [C.c_void_p, C.c_int]
@@ -167,6 +174,32 @@ class BaSolver:
         _check(self._lib.mvo_hip_ba_reduced(self._h, float(radius), S.ctypes.data, rhs.ctypes.data, gc.ctypes.data,
                                             C.byref(gm), C.byref(cost)), "mvo_hip_ba_reduced")
         return S, rhs, gc, gm.value, cost.value
+
+    def solve_partitioned(self, allreduce_sum, allreduce_max, buf):
+        """Landmark-partitioned solve: `buf` is a float64 device tensor (torch) of at least
+        18 M (M + 1) + 18 M + 1 elements; allreduce_sum / allreduce_max reduce a tensor in place over
+        the ranks (e.g. torch.distributed.all_reduce on the RCCL backend) and return once it is done."""
+        M = self._shape[1]
+        n0 = 18 * M * (M + 1) + 18 * M + 1
+        assert buf.numel() >= n0 and buf.is_contiguous()
+        ptr = buf.data_ptr()
+
+        def xchg(which, n, op):
+            _check(self._lib.mvo_hip_ba_partial_exchange(self._h, which, ptr, n, 0), "mvo_hip_ba_partial_exchange")
+            op(buf[:n])
+            _check(self._lib.mvo_hip_ba_partial_exchange(self._h, which, ptr, n, 1), "mvo_hip_ba_partial_exchange")
+
+        done = C.c_int32(0)
+        _check(self._lib.mvo_hip_ba_partial_begin(self._h), "mvo_hip_ba_partial_begin")
+        xchg(2, 4, allreduce_sum)
+        _check(self._lib.mvo_hip_ba_partial_decide(self._h, 0, C.byref(done)), "mvo_hip_ba_partial_decide")
+        while not done.value:
+            _check(self._lib.mvo_hip_ba_partial_linearize(self._h), "mvo_hip_ba_partial_linearize")
+            xchg(0, n0, allreduce_sum)
+            xchg(1, 1, allreduce_max)
+            _check(self._lib.mvo_hip_ba_partial_solve(self._h), "mvo_hip_ba_partial_solve")
+            xchg(2, 4, allreduce_sum)
+            _check(self._lib.mvo_hip_ba_partial_decide(self._h, 1, C.byref(done)), "mvo_hip_ba_partial_decide")
 
     def set_trace(self, capacity):
         _check(self._lib.mvo_hip_ba_set_trace(self._h, int(capacity)), "mvo_hip_ba_set_trace")

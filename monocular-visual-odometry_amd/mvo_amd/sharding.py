@@ -39,3 +39,25 @@ def shard_observations(w: "scene.Window", rank: int, world: int) -> "scene.Windo
         true_vec=w.true_vec, true_scale=w.true_scale, bearing_observations=w.bearing_observations,
         meta=dict(w.meta, shard=(rank, world)),
     )
+
+
+def shard_landmarks(sc, rank: int, world: int):
+    """Bundle-adjustment scene (ba_scene.BaScene) restricted to this rank's contiguous range of
+    landmarks, cut so that every rank gets about the same number of observations; all poses stay.
+    Returns (shard, (lo, hi)) with lo/hi the landmark range in the full scene."""
+    from dataclasses import replace
+
+    offs = np.asarray(sc.lm_offsets, dtype=np.uint64)
+    n_obs = int(offs[-1])
+    cuts = [int(np.searchsorted(offs, (n_obs * r) // world, side="left")) for r in range(world + 1)]
+    cuts[0], cuts[-1] = 0, len(offs) - 1
+    for r in range(1, world + 1):
+        cuts[r] = max(cuts[r], cuts[r - 1])
+    lo, hi = cuts[rank], cuts[rank + 1]
+    o0, o1 = int(offs[lo]), int(offs[hi])
+    shard = replace(sc, X=np.ascontiguousarray(sc.X[lo:hi]),
+                    lm_offsets=np.ascontiguousarray(offs[lo:hi + 1] - offs[lo]),
+                    obs_frame=np.ascontiguousarray(sc.obs_frame[o0:o1]),
+                    obs_ray=np.ascontiguousarray(sc.obs_ray[o0:o1]), true_X=sc.true_X[lo:hi],
+                    meta=dict(sc.meta, shard=(rank, world)))
+    return shard, (lo, hi)

@@ -36,7 +36,7 @@ def test_ba_header_symbols_are_exported_and_bound():
     text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "mvo_hip_ba.h")).read(), flags=re.S)
     names = sorted(set(re.findall(r"\b(mvo_hip_ba_[a-z_]+)\s*\(", text)))
     lib = ba_capi.load()
-    assert len(names) == 12 and sorted(ba_capi.EXPORTED_SYMBOLS) == names
+    assert len(names) == 17 and sorted(ba_capi.EXPORTED_SYMBOLS) == names
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/mvo_hip_ba.h but not exported"
     assert C.sizeof(ba_capi.Options) == 48 and C.sizeof(ba_capi.Summary) == 32

@@ -93,3 +93,22 @@ def test_shard_ranges_tile_exactly():
         lo, hi = int(w.pair_offsets[p]), int(w.pair_offsets[p + 1])
         got = np.concatenate([q.m0[int(q.pair_offsets[p]):int(q.pair_offsets[p + 1])] for q in parts])
         assert np.array_equal(got, w.m0[lo:hi])
+
+
+def test_landmark_shards_tile_the_scene():
+    """Bundle-adjustment partition plan (include/mvo_hip_ba.h, partial_*): contiguous landmark ranges,
+    balanced by observations, every observation exactly once, poses replicated."""
+    from mvo_amd import ba_scene
+
+    sc = ba_scene.make_ba_scene(12, 6, 257, seed=4, span=7)
+    for world in (1, 2, 3, 8):
+        parts = [sharding.shard_landmarks(sc, r, world) for r in range(world)]
+        assert parts[0][1][0] == 0 and parts[-1][1][1] == sc.n_landmarks
+        for (a, ra), (b, rb) in zip(parts, parts[1:]):
+            assert ra[1] == rb[0]
+        assert sum(p.n_observations for p, _ in parts) == sc.n_observations
+        assert np.array_equal(np.concatenate([p.obs_ray for p, _ in parts]), sc.obs_ray)
+        assert np.array_equal(np.concatenate([p.X for p, _ in parts]), sc.X)
+        for p, _ in parts:
+            assert p.poses is sc.poses and int(p.lm_offsets[0]) == 0
+            assert abs(p.n_observations - sc.n_observations / world) <= 7
