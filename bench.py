@@ -134,6 +134,64 @@ def cpu_baseline(ws, opt_kw, use_loss):
             "residual_blocks_per_s": round(sample.n_residual_blocks * its / el, 1)}
 
 
+def bench_scaler(args, rank, local_rank, world, barrier, dist, torch):
+    """Closed-form scale stage (include/mvo_hip_scaler.h <- Scaler.cpp:21-68) on 10 M synthetic
+    3-frame tracks per GPU, rays resident in HBM: per-track scales + radix-select median."""
+    import numpy as np
+    from mvo_amd import scaler_capi
+
+    n = int(os.environ.get("MVO_BENCH_TRACKS", "10000000"))
+    t = scaler_capi.synthetic_tracks(n, seed=3000 + rank)
+    inp = scaler_capi.make_input(t["R0"], t["R1"], t["R2"], t["u1"], t["n1"])
+    sc = scaler_capi.Scaler(local_rank)
+    t0 = time.perf_counter()
+    sc.upload(t["v0"], t["v1"], t["v2"])
+    upload_s = time.perf_counter() - t0
+    for _ in range(args.warmup):
+        sc.run(inp)
+    barrier()
+    t0 = time.perf_counter()
+    dev = 0.0
+    for _ in range(args.steps):
+        res, _ = sc.run(inp)
+        secs, nbytes = sc.last_timing()
+        dev += secs
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    gbs = nbytes / (dev / args.steps) / 1e9
+    out = {"metric": "tracks_per_sec", "value": round(n * args.steps * world / elapsed, 1), "unit": "tracks/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"scaler: {n} three-frame tracks per GPU, per-track closed-form scale + median",
+                      "tracks_per_gpu": n, "parallelism": f"{world} x independent windows, no collective"},
+           "median": res.median, "scale": res.scale, "upload_seconds_pcie_inclusive": round(upload_s, 6),
+           "roofline": {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": measured_traffic("scaler", "k_scaler"),
+                        "kernel": "k_scaler_tracks + 6 x k_scaler_hist + k_scaler_next (whole run)",
+                        "bytes_per_launch": int(nbytes), "avg_launch_us": round(dev / args.steps * 1e6, 3),
+                        "launches_timed": args.steps}}
+    if rank == 0 and world == 1 and not args.no_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import mvo_scaler_oracle_py as so
+
+        k = min(n, 2_000_000)
+        t1 = time.perf_counter()
+        so.run(t["R0"], t["R1"], t["R2"], t["u1"], t["n1"], 0.25, 2.0, t["v0"][:k], t["v1"][:k], t["v2"][:k])
+        el = time.perf_counter() - t1
+        out["cpu_baseline"] = {"value": round(k / el, 1), "unit": "tracks/s", "cores": 1, "kind": "port",
+                               "sample": f"the first {k} tracks (scales + qsort median) in {el:.2f} s on one host core"}
+    else:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    sc.close()
+
+
 def bench_ba(args, rank, local_rank, world, barrier, dist, torch):
     """Explicit-landmark window BA.  ba2 = configs[1] shape (30 keyframes, 5 000 landmarks, 100 000
     observations), ba5 = the same with 20 % outliers under a Cauchy loss, ba4 = configs[3] shape
@@ -299,6 +357,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.workload == "scaler":
+        bench_scaler(args, rank, local_rank, world, barrier, dist, torch)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     if args.workload.startswith("ba"):
         bench_ba(args, rank, local_rank, world, barrier, dist, torch)
         if world > 1:

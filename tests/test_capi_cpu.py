@@ -46,6 +46,21 @@ def test_ba_header_symbols_are_exported_and_bound():
     assert e.value.status == capi.ERR_NO_DEVICE
 
 
+def test_scaler_header_symbols_are_exported_and_bound():
+    from mvo_amd import scaler_capi
+
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "mvo_hip_scaler.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(mvo_hip_scaler_[a-z_]+)\s*\(", text)))
+    lib = scaler_capi.load()
+    assert len(names) == 6 and sorted(scaler_capi.EXPORTED_SYMBOLS) == names
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/mvo_hip_scaler.h but not exported"
+    assert C.sizeof(scaler_capi.Input) == 264 and C.sizeof(scaler_capi.Result) == 32
+    with pytest.raises(capi.MvoHipError) as e:
+        scaler_capi.Scaler(0)
+    assert e.value.status == capi.ERR_NO_DEVICE
+
+
 def test_record_layouts():
     # mvo_hip_frame = cv::Matx33d R + cv::Vec3d vec + double scale (IterativeRefinement.hpp:171-175)
     assert scene.make_window(3, 2, 5, 1).frames.shape[1] * 8 == 104
@@ -62,7 +77,7 @@ def test_header_is_plain_c_and_pedantic_cxx11(tmp_path):
 
     for compiler, std, name in (("g++", "-std=c++11", "t.cpp"), ("gcc", "-std=c99", "t.c")):
         src = tmp_path / name
-        src.write_text('#include "mvo_hip.h"\n#include "mvo_hip_ba.h"\n'
+        src.write_text('#include "mvo_hip.h"\n#include "mvo_hip_ba.h"\n#include "mvo_hip_scaler.h"\n'
                        'int main(void){ mvo_hip_options o; mvo_hip_ba_options b; (void)o; (void)b; return 0; }\n')
         subprocess.check_call([compiler, std, "-Wall", "-Werror", "-pedantic", "-Wextra", "-fsyntax-only",
                                "-I", os.path.join(ROOT, "include"), str(src)])
