@@ -134,6 +134,63 @@ def cpu_baseline(ws, opt_kw, use_loss):
             "residual_blocks_per_s": round(sample.n_residual_blocks * its / el, 1)}
 
 
+def bench_epipolar(args, rank, local_rank, world, barrier, dist, torch):
+    """RANSAC baseline-direction stage (include/mvo_hip_epipolar.h <- EpipolarGeometry.cpp:34-176):
+    1024 hypotheses scored against 100 000 correspondences per GPU.  The entry point takes host
+    buffers; `value` counts the device time between the uploads and the read-back (HIP events), i.e.
+    with the inputs resident in HBM; the PCIe-inclusive wall time is reported beside it."""
+    import numpy as np
+    from mvo_amd import epipolar_capi
+
+    n, K = int(os.environ.get("MVO_BENCH_CORRESPONDENCES", "100000")), 1024
+    t = epipolar_capi.synthetic_correspondences(n, seed=4000 + rank, n_samples=K)
+    thr = float(np.cos(np.deg2rad(4.0)))
+    ep = epipolar_capi.Epipolar(local_rank)
+    for _ in range(args.warmup):
+        ep.score(t["mhi"], t["mt"], t["samples"], thr)
+    barrier()
+    t0 = time.perf_counter()
+    dev = 0.0
+    for _ in range(args.steps):
+        hb, hi, hp = ep.score(t["mhi"], t["mt"], t["samples"], thr)
+        secs, ev = ep.last_timing()
+        dev += secs
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dev], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dev = float(tt.item())
+    # pInlier: ~40 fp64 flops per (hypothesis, correspondence); the 4.8 MB of rays stay in L2
+    tf = 40.0 * ev / (dev / args.steps) / 1e12
+    out = {"metric": "hypothesis_correspondence_evaluations_per_sec", "value": round(ev * args.steps * world / dev, 1),
+           "unit": "evaluations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(dev / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"epipolar: {K} RANSAC hypotheses x {n} correspondences per GPU",
+                      "parallelism": f"{world} x independent frames, no collective"},
+           "ms_per_step_pcie_inclusive": round(elapsed / args.steps * 1e3, 5),
+           "roofline": None,
+           "roofline_compute": {"bound": "fp64-valu", "achieved": round(tf, 3), "peak": 78.6, "unit": "TFLOP/s",
+                                "frac": round(tf / 78.6, 4), "flops_per_launch": int(40 * ev)}}
+    if rank == 0 and world == 1 and not args.no_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import mvo_epipolar_oracle_py as eo
+
+        k = 64
+        t1 = time.perf_counter()
+        _, hio, hpo = eo.score(t["mhi"], t["mt"], t["samples"][:k], thr)
+        el = time.perf_counter() - t1
+        assert np.array_equal(hio, hi[:k])
+        out["cpu_baseline"] = {"value": round(k * n / el, 1), "unit": "evaluations/s", "cores": 1, "kind": "port",
+                               "sample": f"the first {k} hypotheses x {n} correspondences in {el:.2f} s on one host core"}
+    else:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    ep.close()
+
+
 def bench_scaler(args, rank, local_rank, world, barrier, dist, torch):
     """Closed-form scale stage (include/mvo_hip_scaler.h <- Scaler.cpp:21-68) on 10 M synthetic
     3-frame tracks per GPU, rays resident in HBM: per-track scales + radix-select median."""
@@ -357,6 +414,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.workload == "epipolar":
+        bench_epipolar(args, rank, local_rank, world, barrier, dist, torch)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     if args.workload == "scaler":
         bench_scaler(args, rank, local_rank, world, barrier, dist, torch)
         if world > 1:

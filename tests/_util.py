@@ -8,7 +8,7 @@ from mvo_amd import scene
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 GOLDEN_CASES = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
-                      if not os.path.basename(p).startswith("scaler_"))  # scaler_*: tests/test_scaler_oracle.py
+                      if not os.path.basename(p).startswith(("scaler_", "epipolar_")))  # those: test_scaler_oracle.py, test_epipolar_oracle.py
 
 FIXED10 = dict(max_num_iterations=10, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
 TIGHT = dict(max_num_iterations=400, function_tolerance=1e-16, gradient_tolerance=1e-14, parameter_tolerance=1e-14)
