@@ -484,14 +484,29 @@ __device__ __forceinline__ void ba_pose_plus(const double* __restrict__ in, cons
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t tri(uint32_t i, uint32_t j) { return (i * (i + 1)) / 2 + j; }  // j <= i
 
+#ifdef MVO_BA_STAMPS  // diagnostic build: cycles of k_ba_solve's phases, thread 0
+__device__ unsigned long long mvo_ba_stamps[8];
+#define BA_STAMP(i)                                                   \
+  do {                                                                \
+    if (threadIdx.x == 0) {                                           \
+      const unsigned long long now_ = __builtin_amdgcn_s_memtime();   \
+      ba_acc_[(i)] += now_ - ba_prev_;                                \
+      ba_prev_ = now_;                                                \
+    }                                                                 \
+  } while (0)
+#else
+#define BA_STAMP(i) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(BA_SOLVE_THREADS) void k_ba_solve(BaParams prm, BaState* __restrict__ st,
                                                               const double* __restrict__ redS,
                                                               const double* __restrict__ redV,
                                                               double* __restrict__ poses2,
                                                               double* __restrict__ delta_c) {
   extern __shared__ double Lf[];  // (M+1)(M+2)/2 blocks x 36: the factor, block (ib, jb) at tri(ib, jb)
-  // X rows are read at a per-lane block index: 37-double rows keep those reads off a common bank
-  __shared__ double pubX[2][BA_MAXF + 1][37], pubW[2][BA_MAXF + 1][36];
+  // W rows are read at a per-lane block index (consecutive ib within a wavefront): 37-double rows
+  // keep those reads off a common bank; X rows are mostly read by whole wavefronts at once
+  __shared__ double pubX[2][BA_MAXF + 1][37], pubW[2][BA_MAXF + 1][37];
   __shared__ double dl[2][36], dinvs[2][6];
   __shared__ double xs[6 * BA_MAXF], dc2[6 * BA_MAXF];
   __shared__ int bad_flag;
@@ -517,13 +532,18 @@ __global__ __launch_bounds__(BA_SOLVE_THREADS) void k_ba_solve(BaParams prm, BaS
     }
     return;
   }
+#ifdef MVO_BA_STAMPS
+  unsigned long long ba_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ba_prev_ = __builtin_amdgcn_s_memtime();
+#endif
   if (tid == 0) bad_flag = 0;
   // thread -> block (ib, jb), jb <= ib <= M
+  // enumerated column by column, so that the panel of a block column (the threads that work in
+  // phase 2) sits in one or two wavefronts instead of being scattered over all eight
   const uint32_t nba = (M + 1) * (M + 2) / 2;
-  uint32_t ib = (uint32_t)((sqrtf(8.0f * (float)tid + 1.0f) - 1.0f) * 0.5f);
-  while ((ib + 1) * (ib + 2) / 2 <= tid) ++ib;
-  while (ib * (ib + 1) / 2 > tid) --ib;
-  const uint32_t jb = tid - ib * (ib + 1) / 2;
+  uint32_t jb = 0;
+  for (uint32_t q = 1; q <= M; ++q)
+    if (tid >= q * (M + 1) - (q * (q - 1)) / 2) jb = q;
+  const uint32_t ib = jb + (tid - (jb * (M + 1) - (jb * (jb - 1)) / 2));
   const bool have = tid < nba;
   double a[36];
 #pragma unroll
@@ -549,6 +569,7 @@ __global__ __launch_bounds__(BA_SOLVE_THREADS) void k_ba_solve(BaParams prm, BaS
     }
   }
   __syncthreads();
+  BA_STAMP(0);
   for (uint32_t kb = 0; kb < M; ++kb) {
     const int buf = kb & 1;
     if (have && ib == kb && jb == kb) {  // (1) l d l^T of the diagonal block (lower part of a)
@@ -579,6 +600,7 @@ __global__ __launch_bounds__(BA_SOLVE_THREADS) void k_ba_solve(BaParams prm, BaS
       if (!ok) bad_flag = 1;
     }
     __syncthreads();
+    BA_STAMP(1);
     if (bad_flag) break;  // uniform
     if (have && jb == kb && ib > kb) {  // (2) X = A l^-T (row by row), W = X d^-1
 #pragma unroll
@@ -601,6 +623,7 @@ __global__ __launch_bounds__(BA_SOLVE_THREADS) void k_ba_solve(BaParams prm, BaS
         }
     }
     __syncthreads();
+    BA_STAMP(2);
     if (have && jb > kb) {  // (3) A_(ib,jb) -= W_ib X_jb^T, both operands read once
       double x[36], wv[36];
 #pragma unroll
@@ -618,36 +641,47 @@ __global__ __launch_bounds__(BA_SOLVE_THREADS) void k_ba_solve(BaParams prm, BaS
           a[6 * r + c] = acc;
         }
     }
+    BA_STAMP(3);
   }
   __syncthreads();
   const bool bad = bad_flag != 0;
   if (have && !bad) {
 #pragma unroll
-    for (int e = 0; e < 36; ++e) Lf[(size_t)tid * 36 + e] = a[e];
+    for (int e = 0; e < 36; ++e) Lf[(size_t)tri(ib, jb) * 36 + e] = a[e];
   }
   __syncthreads();
-  if (tid < 64 && !bad) {
-    // back substitution L^T x = w (w = row 0 of the block row M); lanes own components lane, +64, +128
-    double y[3];
+  if (!bad) {  // uniform: every thread walks the loop (the barriers inside need all of them)
+    // Back substitution L^T x = w (w = row 0 of block row M), block row by block row from the
+    // bottom; thread j < n owns component j.  Per block: the 6 x 6 unit-triangular tail is solved by
+    // one thread from LDS, then every thread above the block subtracts its 6 products.
+    const uint32_t j = tid, jb6 = j / 6, jr = j % 6;
+    double y = j < n ? Lf[(size_t)tri(M, jb6) * 36 + jr] : 0.0;
+    for (int kb = (int)M - 1; kb >= 0; --kb) {
+      if (j < n && (int)jb6 == kb) xs[j] = y;
+      __syncthreads();
+      if (tid == 0) {
+        const double* __restrict__ l = Lf + (size_t)tri(kb, kb) * 36;  // unit lower block: l[6 r + c], r > c
+        double x[6];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const uint32_t i = tid + 64 * c;
-      y[c] = i < n ? Lf[(size_t)tri(M, i / 6) * 36 + i % 6] : 0.0;
-    }
-    for (int k = (int)n - 1; k >= 0; --k) {
-      const int c = k >> 6, src = k & 63;
-      const double yk = c == 0 ? y[0] : (c == 1 ? y[1] : y[2]);
-      const double xk = __shfl(yk, src, 64);
-      if ((int)tid == src) xs[k] = xk;
-      const uint32_t kb6 = (uint32_t)k / 6, kr = (uint32_t)k % 6;
+        for (int r = 5; r >= 0; --r) {
+          double v = xs[6 * kb + r];
 #pragma unroll
-      for (int cc = 0; cc < 3; ++cc) {
-        const uint32_t j = tid + 64 * cc;
-        if ((int)j < k) y[cc] -= Lf[(size_t)tri(kb6, j / 6) * 36 + 6 * kr + j % 6] * xk;
+          for (int r2 = r + 1; r2 < 6; ++r2) v -= l[6 * r2 + r] * x[r2];
+          x[r] = v;
+        }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) xs[6 * kb + r] = x[r];
+      }
+      __syncthreads();
+      if (j < n && (int)jb6 < kb) {
+        const double* __restrict__ l = Lf + (size_t)tri(kb, jb6) * 36 + jr;  // L[6 kb + r][j] = l[6 r]
+#pragma unroll
+        for (int r = 0; r < 6; ++r) y -= l[6 * r] * xs[6 * kb + r];
       }
     }
   }
   __syncthreads();
+  BA_STAMP(4);
   if (tid < 64) {
     double mcc = 0.0, s2 = 0.0, xn2 = 0.0;
     bool nonfinite = false;
@@ -682,6 +716,11 @@ __global__ __launch_bounds__(BA_SOLVE_THREADS) void k_ba_solve(BaParams prm, BaS
       st->xnorm2_c = xn2;
     }
   }
+#ifdef MVO_BA_STAMPS
+  BA_STAMP(5);
+  if (tid == 0)
+    for (int q = 0; q < 8; ++q) mvo_ba_stamps[q] += ba_acc_[q];
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1518,6 +1557,16 @@ int mvo_hip_ba_partial_exchange(mvo_hip_ba_handle h, int which, void* device_buf
   BA_TRY(hipStreamSynchronize(s));
   return MVO_HIP_OK;
 }
+
+#ifdef MVO_BA_STAMPS
+int mvo_hip_ba_debug_stamps(unsigned long long* out8, int reset) {
+  if (reset) {
+    unsigned long long z[8] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(mvo_ba_stamps), z, sizeof z) == hipSuccess ? 0 : 4;
+  }
+  return hipMemcpyFromSymbol(out8, HIP_SYMBOL(mvo_ba_stamps), 64) == hipSuccess ? 0 : 4;
+}
+#endif
 
 int mvo_hip_ba_set_trace(mvo_hip_ba_handle h, int32_t capacity) {
   if (!h || capacity < 0) return MVO_HIP_ERR_INVALID_ARGUMENT;

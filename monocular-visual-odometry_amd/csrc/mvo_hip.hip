@@ -103,6 +103,7 @@ struct mvo_hip_context {
   std::vector<uint32_t> v_wave_tiles;
   std::vector<double> v_initx;
   bool lm_started = false;  // false until the first k_lm launch of the current solve
+  size_t lm_dyn_configured[2] = {0, 0};  // dynamic LDS already granted to k_lm<64> / k_lm<256> on this device
   bool profiling = false;  // record HIP events around the launches (mvo_hip_set_profiling)
   // problem description of the last upload
   bool uploaded = false;
@@ -465,7 +466,9 @@ hipError_t launch_pass(mvo_hip_context* h) {
 template <int NT>
 hipError_t launch_lm(mvo_hip_context* h, const SolveParams& prm, bool from_pair_sums = false) {
   const size_t dyn = sizeof(double) * 10 * (size_t)h->P;
-  static size_t configured = 0;
+  // the attribute is per device: remembered per handle (a handle is bound to one device), not per
+  // process -- two handles on two GPUs must each configure their own device
+  size_t& configured = h->lm_dyn_configured[NT == 64 ? 0 : 1];
   if (dyn > configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lm<NT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);

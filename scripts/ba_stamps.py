@@ -1,0 +1,19 @@
+"""Diagnostic: cycles of k_ba_solve's phases (needs libmvo_hip_stamps.so)."""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "monocular-visual-odometry_amd"))
+from mvo_amd import capi
+capi.LIB_PATH = os.path.join(ROOT, "monocular-visual-odometry_amd", "libmvo_hip_stamps.so")
+from mvo_amd import ba_capi, ba_scene
+lib = ba_capi.load()
+lib.mvo_hip_ba_debug_stamps.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+names = ["load", "diag", "panel", "update", "dump+backsub", "tail"]
+sc = ba_scene.ba_config2()
+with ba_capi.BaSolver(0) as s:
+    s.upload(sc, ba_capi.make_options(max_num_iterations=10, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0))
+    s.solve()
+    buf = (C.c_ulonglong * 8)()
+    lib.mvo_hip_ba_debug_stamps(buf, 1)
+    s.solve()
+    lib.mvo_hip_ba_debug_stamps(buf, 0)
+    print({n: buf[i] // 10 for i, n in enumerate(names)}, "cycles per solve call; total", sum(buf[:6]) // 10)
