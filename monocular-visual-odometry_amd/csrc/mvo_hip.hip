@@ -103,6 +103,10 @@ struct mvo_hip_context {
   std::vector<uint32_t> v_wave_tiles;
   std::vector<double> v_initx;
   bool lm_started = false;  // false until the first k_lm launch of the current solve
+  // The done counter is never cleared between solves: a solve is complete when it has advanced by W
+  // past done_base (one fill less per solve).  done_ready = the counter holds done_base.
+  uint32_t done_base = 0;
+  bool done_ready = false;
   size_t lm_dyn_configured[2] = {0, 0};  // dynamic LDS already granted to k_lm<64> / k_lm<256> on this device
   bool profiling = false;  // record HIP events around the launches (mvo_hip_set_profiling)
   // problem description of the last upload
@@ -366,8 +370,11 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
   {
     const size_t status_bytes = (sizeof(int32_t) * W + 15) & ~(size_t)15;
     const size_t mirror_bytes = 16 + sizeof(LmResult) * W;
+    const void* ctl_before = h->d_ctl.p;
     HIP_TRY(h->d_ctl.reserve(status_bytes + mirror_bytes));
+    if (h->d_ctl.p != ctl_before) h->done_ready = false;  // fresh memory: the counter is garbage
     char* base = h->d_ctl.as<char>();
+    if (reinterpret_cast<int32_t*>(base + status_bytes) != h->d_done) h->done_ready = false;  // W changed: it moved
     h->d_status = reinterpret_cast<int32_t*>(base);
     h->d_done = reinterpret_cast<int32_t*>(base + status_bytes);
     h->d_results = reinterpret_cast<LmResult*>(base + status_bytes + 16);
@@ -511,6 +518,8 @@ int partial_begin(mvo_hip_context* h) {
   h->lm_started = false;
   // window status words and the done counter are adjacent: one fill
   HIP_TRY(hipMemsetAsync(h->d_status, 0, (size_t)((char*)h->d_done - (char*)h->d_status) + 16, s));
+  h->done_base = 0;
+  h->done_ready = true;
   HIP_TRY(hipMemsetAsync(h->d_pairsum.p, 0, sizeof(double) * 8 * (size_t)n, s));
   if (!h->pass_mode) {
     HIP_TRY(launch_fold(h, false));
@@ -544,8 +553,9 @@ int partial_advance(mvo_hip_context* h, int32_t* done) {
   HIP_TRY(launch_lm_any(h, prm, true));
   HIP_TRY(hipMemcpyAsync(h->h_done, h->d_done, sizeof(int32_t), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
-  const bool all = (uint32_t)h->h_done[0] >= h->W;
+  const bool all = (uint32_t)h->h_done[0] - h->done_base >= h->W;
   if (all) {
+    h->done_base = (uint32_t)h->h_done[0];
     HIP_TRY(hipMemcpyAsync(h->h_results, h->d_results, sizeof(LmResult) * h->W, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
   }
@@ -567,9 +577,14 @@ int do_solve(mvo_hip_context* h) {
   if (h->trace_cap > 0) HIP_TRY(h->d_trace.reserve(sizeof(TraceRec) * (size_t)h->trace_cap));
 
   h->lm_started = false;
-  // window status words and the done counter are adjacent: one fill.  The LM states need none:
-  // the first k_lm launch starts from zeros of its own (SolveParams::fresh).
-  HIP_TRY(hipMemsetAsync(h->d_status, 0, (size_t)((char*)h->d_done - (char*)h->d_status) + 16, s));
+  // No per-solve fills: the first k_lm launch starts from a zero state of its own and clears its
+  // window's status word (SolveParams::fresh); the done counter only ever counts up (done_base).
+  if (!h->done_ready) {
+    HIP_TRY(hipMemsetAsync(h->d_status, 0, (size_t)((char*)h->d_done - (char*)h->d_status) + 16, s));
+    h->done_base = 0;
+  }
+  h->done_ready = false;  // until this solve has been seen to complete
+  const uint32_t done_base = h->done_base;
 
   const uint32_t fold_blocks = pass_blocks(h);
   int n_timed = 0;
@@ -596,10 +611,15 @@ int do_solve(mvo_hip_context* h) {
       HIP_TRY(timed_end());
       ++asm_launches;
     }
-    // S_p never changes without a loss: sum the slots once, then the whole LM loop runs in one
-    // launch on 8 doubles per pair
-    HIP_TRY(launch_reduce_slots(h));
-    HIP_TRY(launch_lm_any(h, prm, true));
+    // S_p never changes without a loss.  Up to 256 pairs every k_lm thread owns one pair for the
+    // whole launch: it sums the pair's slots once itself and keeps them in registers.  Beyond that
+    // the slots are summed once by a launch of their own and the LM loop reads 8 doubles per pair.
+    if (h->P <= 256) {
+      HIP_TRY(launch_lm_any(h, prm, false));
+    } else {
+      HIP_TRY(launch_reduce_slots(h));
+      HIP_TRY(launch_lm_any(h, prm, true));
+    }
     ++lm_launches;
   } else {
     if (fold_blocks) {
@@ -631,7 +651,7 @@ int do_solve(mvo_hip_context* h) {
       if (issued < total_evals) {
         HIP_TRY(hipMemcpyAsync(h->h_done, h->d_done, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
-        if ((uint32_t)h->h_done[0] >= h->W) break;
+        if ((uint32_t)h->h_done[0] - done_base >= h->W) break;
       }
     }
   }
@@ -640,7 +660,9 @@ int do_solve(mvo_hip_context* h) {
   HIP_TRY(hipMemcpyAsync(h->h_ctl, h->d_done, 16 + sizeof(LmResult) * h->W, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   h->copy_pending = false;
-  if ((uint32_t)h->h_done[0] != h->W) return MVO_HIP_ERR_DEVICE;  // every window must have terminated
+  if ((uint32_t)h->h_done[0] - done_base != h->W) return MVO_HIP_ERR_DEVICE;  // every window must have terminated
+  h->done_base = (uint32_t)h->h_done[0];
+  h->done_ready = true;
 
   mvo_hip_timing& tm = h->timing;
   tm.solve_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();

@@ -699,6 +699,7 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
   LmState* __restrict__ gst = states + w;
   const bool fresh = prm.fresh != 0;
   if (!fresh && gst->status != 0) return;  // uniform: every thread reads the same word
+  if (fresh && tid == 0) win_status[w] = 0;  // read by k_pass: set again when this window terminates
   const WinDev win = wins[w];
   const int M = win.M, N = win.N, P = win.P;
   const int fix = prm.fix_length;
