@@ -54,6 +54,15 @@ __device__ unsigned long long mvo_lm_stamps[16];
 #endif
 
 // ---- wave-level helpers -----------------------------------------------------------------
+// Ordering point between two phases that only wavefront 0 executes: LDS operations of one
+// wavefront complete in order, so no s_barrier is needed -- only the compiler must not move LDS
+// accesses across it.
+__device__ __forceinline__ void wave0_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ double bcast_lane(double v, int src_lane /* compile-time uniform */) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
@@ -845,7 +854,7 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
           sh.C1[a * MCX + j][v] = acc;
         }
     }
-    __syncthreads();
+    wave0_sync();  // phases (3a), (3b), (4) and the LM step all run in wavefront 0: no workgroup barrier
     // (3b) suffix over j:  W_kl = sum_{j >= l} C1[k][j] (l > k).  The pair (k,k) is kept apart:
     // its baseline is s_k v_k alone, so r does not depend on t_k at all (IR.cpp:466-471 normalises
     // the scale away) and its scale row/column is exactly zero instead of rounding noise of the
@@ -877,7 +886,7 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
         sh.cost_z = c;
       }
     }
-    __syncthreads();
+    wave0_sync();  // phases (3a), (3b), (4) and the LM step all run in wavefront 0: no workgroup barrier
     MVO_STAMP(3);
     // (4) 3x3 blocks G_k^T W_kl G_l, one ROW of a block per thread (all of it fits one wavefront
     // round: 45 rows + 15 gradient entries), and gradient entries G_k^T y_k
@@ -930,7 +939,7 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
         }
       }
     }
-    __syncthreads();
+    wave0_sync();  // phases (3a), (3b), (4) and the LM step all run in wavefront 0: no workgroup barrier
     MVO_STAMP(4);
     // ---------------- wavefront 0: accept/reject, damping, next candidate ----------------
     if (wave0) {
