@@ -167,6 +167,20 @@ __device__ __forceinline__ double ba_wave_max(double v) {
 // No atomics of any kind, no LDS read-modify-write, fixed summation order => bitwise reproducible.
 // partS[g][n_blk * 36], partV[g][18 M + 2] = rhs(6M) | g_c(6M) | diag(B)(6M) | cost | gmax(landmarks)
 // ---------------------------------------------------------------------------------------------
+#ifdef MVO_BA_STAMPS  // diagnostic build: cycles of the phases of k_ba_solve ([0..5]) and k_ba_schur ([8..11]), thread 0
+__device__ unsigned long long mvo_ba_stamps[16];
+#define BA_STAMP(i)                                                   \
+  do {                                                                \
+    if (threadIdx.x == 0) {                                           \
+      const unsigned long long now_ = __builtin_amdgcn_s_memtime();   \
+      ba_acc_[(i)] += now_ - ba_prev_;                                \
+      ba_prev_ = now_;                                                \
+    }                                                                 \
+  } while (0)
+#else
+#define BA_STAMP(i) do { } while (0)
+#endif
+
 struct SchurHdr {  // per staged landmark
   double gl[3];
   int32_t n_free, pad;
@@ -244,6 +258,9 @@ __global__ __launch_bounds__(BA_SCHUR_THREADS) void k_ba_schur(BaParams prm, con
       p.uv = obs_uv[p.o0 + lane];
     }
   };
+#ifdef MVO_BA_STAMPS
+  unsigned long long ba_acc_[16] = {0}, ba_prev_ = __builtin_amdgcn_s_memtime();
+#endif
   LmPre pa, pb;
   fetch_hdr(lm_begin + wave, pa);
   fetch_obs(pa);
@@ -330,7 +347,9 @@ __global__ __launch_bounds__(BA_SCHUR_THREADS) void k_ba_schur(BaParams prm, con
       }
     }
     if (lane == 0) hdr[wave].n_free = (int32_t)Tf;
+    BA_STAMP(8);
     __syncthreads();
+    BA_STAMP(9);
     // ---------------- phase B ----------------
     if (owner) {
 #pragma unroll 1
@@ -370,8 +389,14 @@ __global__ __launch_bounds__(BA_SCHUR_THREADS) void k_ba_schur(BaParams prm, con
         }
       }
     }
+    BA_STAMP(10);
     __syncthreads();
+    BA_STAMP(11);
   }
+#ifdef MVO_BA_STAMPS
+  if (tid == 0 && blockIdx.x == 0)
+    for (int q = 8; q < 12; ++q) mvo_ba_stamps[q] += ba_acc_[q];
+#endif
   // workgroup totals
   cost_acc = ba_wave_sum(cost_acc);
   gmax_acc = ba_wave_max(gmax_acc);
@@ -484,19 +509,6 @@ __device__ __forceinline__ void ba_pose_plus(const double* __restrict__ in, cons
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t tri(uint32_t i, uint32_t j) { return (i * (i + 1)) / 2 + j; }  // j <= i
 
-#ifdef MVO_BA_STAMPS  // diagnostic build: cycles of k_ba_solve's phases, thread 0
-__device__ unsigned long long mvo_ba_stamps[8];
-#define BA_STAMP(i)                                                   \
-  do {                                                                \
-    if (threadIdx.x == 0) {                                           \
-      const unsigned long long now_ = __builtin_amdgcn_s_memtime();   \
-      ba_acc_[(i)] += now_ - ba_prev_;                                \
-      ba_prev_ = now_;                                                \
-    }                                                                 \
-  } while (0)
-#else
-#define BA_STAMP(i) do { } while (0)
-#endif
 
 __global__ __launch_bounds__(BA_SOLVE_THREADS) void k_ba_solve(BaParams prm, BaState* __restrict__ st,
                                                               const double* __restrict__ redS,
@@ -533,7 +545,7 @@ __global__ __launch_bounds__(BA_SOLVE_THREADS) void k_ba_solve(BaParams prm, BaS
     return;
   }
 #ifdef MVO_BA_STAMPS
-  unsigned long long ba_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ba_prev_ = __builtin_amdgcn_s_memtime();
+  unsigned long long ba_acc_[16] = {0}, ba_prev_ = __builtin_amdgcn_s_memtime();
 #endif
   if (tid == 0) bad_flag = 0;
   // thread -> block (ib, jb), jb <= ib <= M
@@ -1561,10 +1573,10 @@ int mvo_hip_ba_partial_exchange(mvo_hip_ba_handle h, int which, void* device_buf
 #ifdef MVO_BA_STAMPS
 int mvo_hip_ba_debug_stamps(unsigned long long* out8, int reset) {
   if (reset) {
-    unsigned long long z[8] = {0};
+    unsigned long long z[16] = {0};
     return hipMemcpyToSymbol(HIP_SYMBOL(mvo_ba_stamps), z, sizeof z) == hipSuccess ? 0 : 4;
   }
-  return hipMemcpyFromSymbol(out8, HIP_SYMBOL(mvo_ba_stamps), 64) == hipSuccess ? 0 : 4;
+  return hipMemcpyFromSymbol(out8, HIP_SYMBOL(mvo_ba_stamps), 128) == hipSuccess ? 0 : 4;
 }
 #endif
 

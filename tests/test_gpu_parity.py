@@ -258,3 +258,43 @@ def test_split_phase_is_repeatable(solver):
     assert np.array_equal(f1, f2) and s1[0].final_cost == s2[0].final_cost
     t = solver.timing()
     assert t["assembly_launches"] == 11 and t["residual_blocks"] == w.n_residual_blocks
+
+
+def test_handle_reuse_across_shapes_and_modes(oracle):
+    """One handle through a sequence of different problems (window counts, sizes, assembly paths,
+    the partitioned entry points in between): every result must equal a fresh handle's bit for bit --
+    nothing may leak from one solve into the next (done counter, status words, staging block)."""
+    import torch
+
+    seq = [
+        (lambda: [scene.config1()], dict(**FIXED10)),
+        (lambda: [scene.reference_defaults_window()], dict()),
+        (lambda: [scene.config3_window(i) for i in range(7)], dict(**FIXED10)),
+        (lambda: [scene.make_window(30, 5, 800, seed=41, span=("sliding", 18))], dict(use_loss_function=True, **FIXED10)),
+        (lambda: [scene.reference_defaults_window(seed=9)], dict(use_loss_function=True)),
+        (lambda: [scene.make_window(12, 4, 200, seed=5)], dict(assembly_mode=capi.ASSEMBLY_TILED, **FIXED10)),
+        (lambda: [scene.config3_window(i) for i in range(3)], dict(assembly_mode=capi.ASSEMBLY_PASSES, **FIXED10)),
+    ]
+    with capi.Solver(0) as shared:
+        for k, (make, kw) in enumerate(seq):
+            ws = make()
+            opt = capi.make_options(**kw)
+            if k == 3:  # a partitioned solve on the same handle in between
+                shared.upload(ws, opt)
+                sums = torch.zeros(8 * ws[0].n_pairs, dtype=torch.float64, device="cuda")
+                shared.solve_partitioned(lambda t: torch.cuda.synchronize(), sums)
+                part_frames, part_summ = shared.download()
+            shared.upload(ws, opt)
+            shared.solve()
+            fa, sa = shared.download()
+            shared.solve()                      # and again without a new upload
+            fb, sb = shared.download()
+            with capi.Solver(0) as fresh:
+                fresh.upload(ws, opt)
+                fresh.solve()
+                fc, sc = fresh.download()
+            assert np.array_equal(fa, fc) and np.array_equal(fa, fb), k
+            for x, y, z in zip(sa, sb, sc):
+                assert x.iterations == y.iterations == z.iterations and x.final_cost == y.final_cost == z.final_cost
+            if k == 3:
+                assert np.abs(np.asarray(part_frames) - np.asarray(fa)).max() < 1e-9
