@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of libmvo_hip's sliding-window refinement on MI355X.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload config2|config3|config4|config4r|config5|ba2|ba4|ba5]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload config2|config3|config4|config4r|config5|scaler|epipolar|tracks2|tracks4|ba2|ba4|ba5]
 
 (ba*: the explicit-landmark bundle adjustment of include/mvo_hip_ba.h -- SURVEY.md 8f rank 1, no
 reference counterpart -- on BASELINE.json's config shapes; see bench_ba below.)
@@ -380,6 +380,127 @@ def bench_ba(args, rank, local_rank, world, barrier, dist, torch):
     solver.close()
 
 
+def bench_tracks(args, rank, local_rank, world, barrier, dist, torch):
+    """--workload tracks2 | tracks4: the refinement of config 2 / config 4 with the feature tracks
+    RESIDENT in HBM (include/mvo_hip_tracks.h).  A step is one complete
+    mvo_hip_tracks_refine: count + fill kernels gather every frame pair's residual blocks on the
+    device, the N frame records go up, the LM loop runs, results come back.  The tables were pushed
+    before the timed region (a tracker pushes one keyframe per refine; the push is not the path).
+    `roofline` is k_tracks_fill (HBM-bound scattered ray gather); the same window refined from
+    host-gathered blocks through mvo_hip_refine (PCIe-inclusive) is timed beside it."""
+    import numpy as np
+    from mvo_amd import capi, scene, tracks_capi
+
+    fixed10 = dict(max_num_iterations=10, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
+    if args.workload == "tracks2":
+        w = scene.make_window(30, 5, 5000, 1002 + rank, span=("sliding", 20), keep_tracks=True)
+        desc = "config2 from device-resident tracks: N=30 M=5, 5000 landmarks, fixed 10 LM iterations"
+    elif args.workload == "tracks4":
+        w = scene.make_window(200, 5, 20000, 1004 + rank, span=("anchored", 2, 200), keep_tracks=True)
+        desc = "config4 (one GPU's worth) from device-resident tracks: N=200 M=5, ~9.7M residual blocks, fixed 10 LM iterations"
+    else:
+        raise SystemExit(f"unknown workload {args.workload}")
+    opt = capi.make_options(**fixed10)
+    frames = scene.track_frames(w)
+    solver = capi.Solver(local_rank)
+    table = tracks_capi.TrackTable(solver, max_frames=w.N, max_features=max(len(p) for _, p in frames))
+    table.set_profiling(True)
+    for rays, pre in frames:
+        table.push(rays, pre)
+
+    for _ in range(args.warmup):
+        table.refine(w.frames, w.M, opt)
+    barrier()
+    t0 = time.perf_counter()
+    fill_s = count_s = lm_dev_s = 0.0
+    for _ in range(args.steps):
+        out_frames, summ = table.refine(w.frames, w.M, opt)
+        tt = table.timing()
+        fill_s += tt["fill_seconds"]
+        count_s += tt["count_seconds"]
+        lm_dev_s += solver.timing()["device_seconds"]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # the same window through the host-gathered entry point (rays cross PCIe on every call)
+    host_ms = None
+    if rank == 0:
+        offs, m0, m1 = table.gather(w.M, w.N)
+        hw = scene.Window(**{**w.__dict__, "pair_offsets": offs, "m0": m0, "m1": m1, "meta": {}})
+        for _ in range(2):
+            exp, es = solver.refine(hw, opt)
+        k = max(3, min(args.steps, 20))
+        t1 = time.perf_counter()
+        for _ in range(k):
+            exp, es = solver.refine(hw, opt)
+        host_ms = (time.perf_counter() - t1) / k * 1e3
+        assert np.array_equal(exp, out_frames), "device-gathered and host-gathered refinement differ"
+
+    dur = fill_s / args.steps
+    gbs = tt["fill_bytes"] / dur / 1e9 if dur > 0 else 0.0
+    out = {
+        "metric": "lm_iterations_per_sec", "value": round(summ.iterations * args.steps * world / elapsed, 3),
+        "unit": "LM iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": desc, "residual_blocks_per_gpu": int(tt["residual_blocks"]),
+                   "pairs_per_window": w.n_pairs, "lm_iterations_per_window": summ.iterations,
+                   "features_per_frame_max": max(len(p) for _, p in frames),
+                   "parallelism": f"{world} x independent windows, no collective"},
+        "gathered_blocks_per_sec": round(tt["residual_blocks"] * args.steps * world / elapsed, 1),
+        "count_kernel_us": round(count_s / args.steps * 1e6, 3),
+        "fill_kernel_us": round(dur * 1e6, 3),
+        "solver_device_ms_per_step": round(lm_dev_s / args.steps * 1e3, 5),
+        "host_gathered_refine_ms_pcie_inclusive": None if host_ms is None else round(host_ms, 5),
+        "roofline": {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.workload, "k_tracks_fill"),
+                     "kernel": "k_tracks_fill", "bytes_per_launch": int(tt["fill_bytes"]),
+                     "avg_launch_us": round(dur * 1e6, 3), "launches_timed": args.steps},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu:
+        # CPU leg: the host-side chain walk the device gather replaces (numpy restatement, one core)
+        t1 = time.perf_counter()
+        reps = 0
+        while True:
+            scene.gather_tracks_numpy(frames, w.M)
+            reps += 1
+            if time.perf_counter() - t1 > 5.0 or reps >= 20:
+                break
+        g_s = (time.perf_counter() - t1) / reps
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import mvo_oracle_py as orc
+
+        sample, note = hw, "the whole window"
+        if hw.n_residual_blocks > 600_000:
+            o2, a0, a1 = [0], [], []
+            for p in range(hw.n_pairs):
+                lo, hi = int(hw.pair_offsets[p]), int(hw.pair_offsets[p + 1])
+                a0.append(hw.m0[lo:hi:16])
+                a1.append(hw.m1[lo:hi:16])
+                o2.append(o2[-1] + len(a0[-1]))
+            sample = scene.Window(**{**hw.__dict__, "m0": np.ascontiguousarray(np.concatenate(a0)),
+                                     "m1": np.ascontiguousarray(np.concatenate(a1)),
+                                     "pair_offsets": np.array(o2, dtype=np.uint64)})
+            note = "every 16th residual block of each pair, time scaled by 16"
+        t1 = time.perf_counter()
+        _, so, _ = orc.refine(sample, orc.make_options(**fixed10))
+        s_s = (time.perf_counter() - t1) * (hw.n_residual_blocks / max(1, sample.n_residual_blocks))
+        out["cpu_baseline"] = {"value": round(so.iterations / (g_s + s_s), 3), "unit": "LM iterations/s", "cores": 1,
+                               "kind": "port",
+                               "sample": f"numpy chain-walk gather of the whole window ({g_s * 1e3:.1f} ms, mean of {reps}) + "
+                                         f"one oracle solve of {note} ({s_s:.2f} s) on one host core"}
+    else:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    table.close()
+    solver.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -421,6 +542,11 @@ def main():
         return
     if args.workload == "scaler":
         bench_scaler(args, rank, local_rank, world, barrier, dist, torch)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    if args.workload.startswith("tracks"):
+        bench_tracks(args, rank, local_rank, world, barrier, dist, torch)
         if world > 1:
             dist.destroy_process_group()
         return

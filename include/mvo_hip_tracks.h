@@ -1,0 +1,68 @@
+/* mvo_hip_tracks.h -- device-resident feature-track tables and on-device observation gathering
+ * (SURVEY.md section 8f, rank 2).
+ *
+ * The reference keeps, per keyframe, a vector of Feature {_positionProjected, _preFeature,
+ * _preFeatureCounter} (/root/reference/mvo/src/sliding_window/Feature.hpp:6-22) chained frame to
+ * frame, and IterativeRefinement::refine walks those chains on the host for every frame pair
+ * (IterativeRefinement.cpp:116-165 through Frame::getCorrespondingFeatures,
+ * sliding_window/Frame.hpp:258-302, and FeatureOperations::normFeatures,
+ * operations/FeatureOperations.cpp:117-122).  Here the same table lives in HBM: each new keyframe
+ * is pushed ONCE (its rays and predecessor indices); a refine call gathers the residual blocks of
+ * all frame pairs on the device, straight into the solver's buffers, and uploads only the N frame
+ * records.  _preFeatureCounter is derived on the device exactly as
+ * Frame::calculateFeaturePreCounter does (sliding_window/Frame.cpp:132-148).
+ */
+#ifndef MVO_HIP_TRACKS_H
+#define MVO_HIP_TRACKS_H
+#include <stdint.h>
+
+#include "mvo_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mvo_hip_tracks_context *mvo_hip_tracks_handle;
+
+/* The table is a ring of max_frames keyframes with at most max_features features each, bound to
+ * `solver` (its device and stream; the solver must outlive the table). */
+int mvo_hip_tracks_create(mvo_hip_handle solver, uint32_t max_frames, uint32_t max_features,
+                          mvo_hip_tracks_handle *out);
+void mvo_hip_tracks_destroy(mvo_hip_tracks_handle t);
+
+/* Appends the newest keyframe.  rays: 3 doubles per feature as Feature::_positionProjected holds
+ * them (any norm); pre_feature: Feature::_preFeature, the index of the same track in the
+ * previously pushed frame, or negative.  The first frame ever pushed has no predecessor. */
+int mvo_hip_tracks_push(mvo_hip_tracks_handle t, uint32_t n_features, const double *rays, const int32_t *pre_feature);
+
+/* Forget everything (a new sequence). */
+int mvo_hip_tracks_reset(mvo_hip_tracks_handle t);
+
+/* IterativeRefinement::refine on the newest N pushed keyframes: `frames` as in mvo_hip_refine
+ * (index 0 = newest), observations gathered on the device.  Same status codes, same results as
+ * mvo_hip_refine on the host-gathered observations. */
+int mvo_hip_tracks_refine(mvo_hip_tracks_handle t, mvo_hip_frame *frames, uint32_t M, uint32_t N,
+                          const mvo_hip_options *options, mvo_hip_summary *summary);
+
+/* parity/debug: the gathered residual blocks of the newest N frames in the reference's pair order.
+ * pair_offsets: n_pairs + 1 entries; m0 / m1 (3 doubles per block, capacity `capacity` blocks) may
+ * be NULL to query the total = pair_offsets[n_pairs] first. */
+int mvo_hip_tracks_gather(mvo_hip_tracks_handle t, uint32_t M, uint32_t N, uint64_t *pair_offsets, double *m0,
+                          double *m1, uint64_t capacity);
+
+/* Measurement (off by default): HIP events on the solver's stream around the two gather kernels of
+ * the last refine / gather call. */
+typedef struct {
+  double count_seconds;      /* k_tracks_count */
+  double fill_seconds;       /* k_tracks_fill */
+  uint64_t residual_blocks;  /* gathered by the last call */
+  uint64_t fill_bytes;       /* algorithmic bytes of that k_tracks_fill launch: per pair 4 B per feature of
+                              * frame a (its counter); per gathered block 4 B per chain step, 2 x 24 B of
+                              * rays read, 2 x 24 B written */
+} mvo_hip_tracks_timing; /* 32 bytes */
+int mvo_hip_tracks_set_profiling(mvo_hip_tracks_handle t, int enabled);
+int mvo_hip_tracks_get_timing(mvo_hip_tracks_handle t, mvo_hip_tracks_timing *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVO_HIP_TRACKS_H */

@@ -194,8 +194,10 @@ int ensure_events(mvo_hip_context* h) {
   return MVO_HIP_OK;
 }
 
+// rays_on_device: obs[w].m0 / m1 are not read; the caller fills h->t.m0 / m1 itself with work it queues
+// on h->stream after this call (the device-side gather of mvo_tracks.hip); pair_offsets are host memory.
 int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint32_t M, uint32_t N,
-              const mvo_hip_options* opt, const mvo_hip_observations* obs) {
+              const mvo_hip_options* opt, const mvo_hip_observations* obs, bool rays_on_device = false) {
   const auto t_begin = std::chrono::steady_clock::now();
   int rc = validate(W, frames, M, N, opt, obs);
   if (rc != MVO_HIP_OK) return rc;
@@ -410,7 +412,7 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
   uint64_t pos = 0;
   for (uint32_t w = 0; w < W; ++w) {
     const uint64_t cnt = obs[w].pair_offsets[P];
-    if (cnt) {
+    if (cnt && !rays_on_device) {
       if (rays_in_arena) {
         std::memcpy(ha + o_m0 + sizeof(double) * 3 * pos, obs[w].m0, sizeof(double) * 3 * cnt);
         std::memcpy(ha + o_m1 + sizeof(double) * 3 * pos, obs[w].m1, sizeof(double) * 3 * cnt);
@@ -421,8 +423,8 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
     }
     pos += cnt;
   }
-  HIP_TRY(hipMemcpyAsync(da, ha, arena_bytes, hipMemcpyHostToDevice, s));
-  if (rays_in_arena) {
+  HIP_TRY(hipMemcpyAsync(da, ha, rays_on_device && rays_in_arena ? o_m0 : arena_bytes, hipMemcpyHostToDevice, s));
+  if (rays_in_arena || rays_on_device) {
     h->copy_pending = true;  // pinned source: the copy is asynchronous and the solve is queued behind it
   } else {
     HIP_TRY(hipStreamSynchronize(s));  // the caller's ray arrays may change once this call returns
@@ -783,6 +785,21 @@ int mvo_hip_upload(mvo_hip_handle h, uint32_t n_windows, const mvo_hip_frame* fr
                    const mvo_hip_options* options, const mvo_hip_observations* observations) {
   if (!h) return MVO_HIP_ERR_INVALID_ARGUMENT;
   return do_upload(h, n_windows, frames, M, N, options, observations);
+}
+
+// library-internal (csrc/mvo_internal.h): the device-side gather queues its kernels on the solver's
+// stream and hands over device-resident rays
+void* mvo_hip_internal_stream(mvo_hip_handle h) { return h ? (void*)h->stream : nullptr; }
+int mvo_hip_internal_device(mvo_hip_handle h) { return h ? h->device : -1; }
+int mvo_hip_internal_upload_device_rays(mvo_hip_handle h, const mvo_hip_frame* frames, uint32_t M, uint32_t N,
+                                        const mvo_hip_options* options, const mvo_hip_observations* observations,
+                                        double** m0_device, double** m1_device) {
+  if (!h || !m0_device || !m1_device) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  const int rc = do_upload(h, 1, frames, M, N, options, observations, true);
+  if (rc != MVO_HIP_OK) return rc;
+  *m0_device = h->t.m0;
+  *m1_device = h->t.m1;
+  return MVO_HIP_OK;
 }
 
 int mvo_hip_solve(mvo_hip_handle h) {

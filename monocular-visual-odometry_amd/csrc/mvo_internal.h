@@ -1,0 +1,16 @@
+// mvo_internal.h -- entry points shared between the translation units of libmvo_hip.so only (not
+// part of the public C ABI in include/).
+#pragma once
+#include "../../include/mvo_hip.h"
+
+extern "C" {
+void* mvo_hip_internal_stream(mvo_hip_handle h);  // hipStream_t of the handle
+int mvo_hip_internal_device(mvo_hip_handle h);
+// mvo_hip_upload for ONE window whose rays the caller writes on the device: observations->m0 / m1 are
+// not read (non-NULL placeholders), pair_offsets is host memory.  Returns where the 3-double rays of
+// residual block k go (m0_device + 3 k); the caller fills them with work queued on the handle's
+// stream before mvo_hip_solve.
+int mvo_hip_internal_upload_device_rays(mvo_hip_handle h, const mvo_hip_frame* frames, uint32_t M, uint32_t N,
+                                        const mvo_hip_options* options, const mvo_hip_observations* observations,
+                                        double** m0_device, double** m1_device);
+}

@@ -192,6 +192,63 @@ def make_window(
     )
 
 
+def track_frames(w: Window, unnormalised: bool = True):
+    """The window (built with keep_tracks=True) as the reference's per-frame Feature tables
+    (sliding_window/Feature.hpp:6-22), OLDEST FRAME FIRST, as a tracker would hand them over:
+    [(rays[n,3], pre_feature[n] int32)], features in landmark order, pre_feature = index of the same
+    landmark in the next older frame or -1.  unnormalised: rays as projectPixelTo3dRay returns them,
+    (x, y, 1) (FeatureOperations.cpp:31-33), otherwise the unit rays."""
+    tr = w.meta["tracks"]
+    lo, hi, rays = tr["lo"], tr["hi"], tr["rays"]
+    N = w.N
+    ids = [np.nonzero((lo <= i) & (hi >= i))[0] for i in range(N)]
+    out = []
+    for i in range(N - 1, -1, -1):
+        r = rays[i, ids[i]]
+        if unnormalised:
+            r = r / r[:, 2:3]
+        pre = -np.ones(len(ids[i]), dtype=np.int32)
+        if i + 1 < N:
+            index = -np.ones(len(lo), dtype=np.int64)
+            index[ids[i + 1]] = np.arange(len(ids[i + 1]))
+            pre = index[ids[i]].astype(np.int32)
+        out.append((np.ascontiguousarray(r), pre))
+    return out
+
+
+def gather_tracks_numpy(frames_oldest_first, M: int):
+    """Numpy restatement of the reference's host-side gather for test comparison (chain walk of
+    Frame.hpp:277-291 per pair of IterativeRefinement.cpp:116-152, normFeatures
+    FeatureOperations.cpp:117-122) -> (pair_offsets, m0, m1)."""
+    fr = frames_oldest_first[::-1]  # index 0 = newest
+    N = len(fr)
+    counter = [None] * N
+    for i in range(N - 1, -1, -1):  # Frame.cpp:132-148
+        pre = fr[i][1]
+        if i == N - 1:
+            counter[i] = np.zeros(len(pre), dtype=np.int64)
+        else:
+            ok = (pre >= 0) & (pre < len(fr[i + 1][1]))
+            older = np.concatenate([counter[i + 1], [0]])  # one pad entry: indexable when empty
+            counter[i] = np.where(ok, older[np.where(ok, pre, 0)] + 1, 0)
+    offs = [0]
+    m0s, m1s = [], []
+    for a, b in pair_list(M, N):
+        past = b - a + 1
+        sel = np.nonzero(counter[a] >= past)[0]
+        idx = sel.copy()
+        for s in range(past):
+            idx = fr[a + s][1][idx]
+        v0 = fr[a][0][sel]
+        v1 = fr[b + 1][0][idx]
+        for v, dst in ((v0, m0s), (v1, m1s)):
+            scale = 1.0 / np.sqrt((v[:, 0] * v[:, 0] + v[:, 1] * v[:, 1]) + v[:, 2] * v[:, 2])
+            dst.append(v * scale[:, None])
+        offs.append(offs[-1] + len(sel))
+    cat = lambda parts: np.ascontiguousarray(np.concatenate(parts, axis=0)) if parts else np.zeros((0, 3))
+    return np.array(offs, dtype=np.uint64), cat(m0s), cat(m1s)
+
+
 def write_track_file(w: Window, path: str, max_num_iterations=10, function_tolerance=0.0,
                      gradient_tolerance=0.0, parameter_tolerance=0.0, use_loss_function=False,
                      fix_length=False, lowest_length=LOWEST_LENGTH, highest_length=HIGHEST_LENGTH):

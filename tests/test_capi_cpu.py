@@ -76,6 +76,21 @@ def test_epipolar_header_symbols_are_exported_and_bound():
     assert e.value.status == capi.ERR_NO_DEVICE
 
 
+def test_tracks_header_symbols_are_exported_and_bound():
+    from mvo_amd import tracks_capi
+
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "mvo_hip_tracks.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(mvo_hip_tracks_[a-z_]+)\s*\(", text)))
+    lib = tracks_capi.load()
+    assert len(names) == 8 and sorted(tracks_capi.EXPORTED_SYMBOLS) == names
+    assert C.sizeof(tracks_capi.Timing) == 32
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/mvo_hip_tracks.h but not exported"
+    # a table lives on a solver's GPU: without one there is nothing to bind to (and no CPU path)
+    h = C.c_void_p()
+    assert lib.mvo_hip_tracks_create(None, 8, 100, C.byref(h)) == capi.ERR_INVALID_ARGUMENT and not h.value
+
+
 def test_record_layouts():
     # mvo_hip_frame = cv::Matx33d R + cv::Vec3d vec + double scale (IterativeRefinement.hpp:171-175)
     assert scene.make_window(3, 2, 5, 1).frames.shape[1] * 8 == 104
@@ -92,7 +107,7 @@ def test_header_is_plain_c_and_pedantic_cxx11(tmp_path):
 
     for compiler, std, name in (("g++", "-std=c++11", "t.cpp"), ("gcc", "-std=c99", "t.c")):
         src = tmp_path / name
-        src.write_text('#include "mvo_hip.h"\n#include "mvo_hip_ba.h"\n#include "mvo_hip_scaler.h"\n#include "mvo_hip_epipolar.h"\n'
+        src.write_text('#include "mvo_hip.h"\n#include "mvo_hip_ba.h"\n#include "mvo_hip_scaler.h"\n#include "mvo_hip_epipolar.h"\n#include "mvo_hip_tracks.h"\n'
                        'int main(void){ mvo_hip_options o; mvo_hip_ba_options b; (void)o; (void)b; return 0; }\n')
         subprocess.check_call([compiler, std, "-Wall", "-Werror", "-pedantic", "-Wextra", "-fsyntax-only",
                                "-I", os.path.join(ROOT, "include"), str(src)])

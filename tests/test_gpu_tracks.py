@@ -1,0 +1,158 @@
+"""GPU parity of the device-resident track tables (include/mvo_hip_tracks.h) through the C ABI.
+
+The on-device gather replaces the host-side chain walk of IterativeRefinement::refine
+(/root/reference/mvo/src/algorithms/IterativeRefinement.cpp:116-165, sliding_window/Frame.hpp:258-302,
+operations/FeatureOperations.cpp:117-122).  It is index and copy work plus one normalisation, so the
+bar is BIT-EXACT against the numpy restatement scene.gather_tracks_numpy (offsets, block order and
+ray values), and mvo_hip_tracks_refine must return exactly what mvo_hip_refine returns on the
+host-gathered blocks (same kernels, same inputs: array_equal)."""
+import numpy as np
+import pytest
+
+from mvo_amd import capi, scene, tracks_capi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def solver():
+    s = capi.Solver(0)
+    yield s
+    s.close()
+
+
+def _push_all(table, frames):
+    for rays, pre in frames:
+        table.push(rays, pre)
+
+
+CASES = [
+    # N, M, landmarks, span
+    (3, 1, 40, "full"),
+    (10, 5, 300, "full"),                  # BASELINE.json configs[0]
+    (8, 3, 500, ("sliding", 4)),
+    (12, 5, 2000, ("anchored", 2, 12)),
+    (30, 5, 5000, ("sliding", 8)),        # the shape of configs[1], fewer landmarks
+    (6, 2, 1, "full"),                     # a single track
+    (20, 4, 777, ("anchored", 1, 3)),     # many tracks too short for any pair
+]
+
+
+@pytest.mark.parametrize("N,M,L,span", CASES, ids=lambda v: str(v).replace(" ", ""))
+def test_gather_bit_exact(solver, N, M, L, span):
+    w = scene.make_window(N, M, L, seed=4100 + N, span=span, keep_tracks=True)
+    frames = scene.track_frames(w)
+    width = max(len(p) for _, p in frames)
+    with tracks_capi.TrackTable(solver, max_frames=N, max_features=max(width, 1)) as table:
+        _push_all(table, frames)
+        offs, m0, m1 = table.gather(M, N)
+    eo, e0, e1 = scene.gather_tracks_numpy(frames, M)
+    assert np.array_equal(offs, eo)
+    assert np.array_equal(offs, w.pair_offsets)  # the window builder's own count
+    assert np.array_equal(m0, e0) and np.array_equal(m1, e1)
+    if len(e0):  # and they are the window's unit rays to rounding (those were normalised before /z)
+        assert np.abs(m0 - w.m0).max() <= 4e-16 and np.abs(m1 - w.m1).max() <= 4e-16
+
+
+@pytest.mark.parametrize("use_loss", [False, True])
+@pytest.mark.parametrize("N,M,L,span", [(10, 5, 300, "full"), (30, 5, 5000, ("sliding", 8)), (8, 3, 500, ("sliding", 4))],
+                         ids=["config1", "config2-shape", "small"])
+def test_refine_equals_host_gathered_refine(solver, N, M, L, span, use_loss):
+    w = scene.make_window(N, M, L, seed=4200 + N, span=span, keep_tracks=True)
+    frames = scene.track_frames(w)
+    opt = capi.make_options(max_num_iterations=15, function_tolerance=0.0, gradient_tolerance=0.0,
+                            parameter_tolerance=0.0, use_loss_function=use_loss)
+    with tracks_capi.TrackTable(solver, max_frames=N + 3, max_features=max(len(p) for _, p in frames)) as table:
+        _push_all(table, frames)
+        got, gs = table.refine(w.frames, M, opt)
+        offs, m0, m1 = table.gather(M, N)
+    w2 = scene.Window(N=N, M=M, frames=w.frames, pair_offsets=offs, m0=m0, m1=m1, true_vec=w.true_vec,
+                      true_scale=w.true_scale, bearing_observations=w.bearing_observations, meta={})
+    exp, es = solver.refine(w2, opt)
+    assert np.array_equal(got, exp)
+    assert gs.iterations == es.iterations and gs.final_cost == es.final_cost and gs.termination == es.termination
+    # and the refinement did its job on the clean scene
+    assert gs.final_cost < gs.initial_cost
+
+
+def test_ring_slides_over_a_sequence(solver):
+    """A 14-frame sequence through an 8-slot ring: after every push beyond the 6th, the newest 6
+    keyframes must gather exactly as a fresh table holding only those 6 would (older slots are
+    overwritten; counters that reach beyond the ring are still right)."""
+    w = scene.make_window(14, 3, 400, seed=4301, span=("sliding", 9), keep_tracks=True)
+    frames = scene.track_frames(w)  # oldest first
+    width = max(len(p) for _, p in frames)
+    N, M = 6, 3
+    with tracks_capi.TrackTable(solver, max_frames=8, max_features=width) as ring:
+        for k, (rays, pre) in enumerate(frames):
+            ring.push(rays, pre)
+            if k + 1 < N:
+                with pytest.raises(capi.MvoHipError) as e:
+                    ring.gather(M, N)
+                assert e.value.status == capi.ERR_STATE
+                continue
+            offs, m0, m1 = ring.gather(M, N)
+            window = list(frames[k + 1 - N:k + 1])
+            # the oldest frame of the sub-window keeps its predecessor indices; the numpy
+            # restatement ignores them for the last frame exactly as the chain walk never follows them
+            eo, e0, e1 = scene.gather_tracks_numpy(window, M)
+            # counters in the ring count frames beyond the window too; only >= past matters
+            assert np.array_equal(offs, eo), k
+            assert np.array_equal(m0, e0) and np.array_equal(m1, e1), k
+        ring.reset()
+        with pytest.raises(capi.MvoHipError):
+            ring.gather(M, N)
+
+
+def test_invalid_predecessors_start_new_tracks(solver):
+    """Frame.cpp:138-144: a negative (or out-of-range) predecessor index starts a new track."""
+    rng = np.random.default_rng(5)
+    n = 300
+    f_old = (rng.normal(size=(n, 3)) + [0, 0, 4.0], -np.ones(n, dtype=np.int32))
+    pre = np.arange(n, dtype=np.int32)
+    pre[::3] = -1
+    pre[1::7] = n + 5  # out of range: treated as "no predecessor"
+    f_new = (rng.normal(size=(n, 3)) + [0, 0, 4.0], pre)
+    with tracks_capi.TrackTable(solver, max_frames=2, max_features=n) as table:
+        _push_all(table, [f_old, f_new])
+        offs, m0, m1 = table.gather(1, 2)
+    eo, e0, e1 = scene.gather_tracks_numpy([f_old, f_new], 1)
+    keep = (pre >= 0) & (pre < n)
+    assert int(offs[-1]) == int(keep.sum()) == int(eo[-1])
+    assert np.array_equal(m0, e0) and np.array_equal(m1, e1)
+
+
+def test_argument_errors(solver):
+    with pytest.raises(capi.MvoHipError) as e:
+        tracks_capi.TrackTable(solver, max_frames=1, max_features=10)
+    assert e.value.status == capi.ERR_INVALID_ARGUMENT
+    with tracks_capi.TrackTable(solver, max_frames=4, max_features=10) as table:
+        with pytest.raises(capi.MvoHipError) as e:
+            table.push(np.ones((11, 3)), np.zeros(11, dtype=np.int32))
+        assert e.value.status == capi.ERR_UNSUPPORTED
+        table.push(np.ones((10, 3)), -np.ones(10, dtype=np.int32))
+        table.push(np.ones((10, 3)), np.arange(10, dtype=np.int32))
+        for M, N, status in [(0, 2, capi.ERR_INVALID_ARGUMENT), (2, 2, capi.ERR_INVALID_ARGUMENT),
+                             (6, 7, capi.ERR_UNSUPPORTED), (1, 3, capi.ERR_STATE)]:
+            with pytest.raises(capi.MvoHipError) as e:
+                table.gather(M, N)
+            assert e.value.status == status
+        offs, m0, m1 = table.gather(1, 2)
+        assert int(offs[-1]) == 10
+
+
+def test_refine_on_empty_gather(solver):
+    """No track spans two frames: zero residual blocks, the solver reports what mvo_hip_refine
+    reports for an empty window (frames unchanged)."""
+    N, M = 4, 2
+    with tracks_capi.TrackTable(solver, max_frames=N, max_features=16) as table:
+        for _ in range(N):
+            table.push(np.tile([0.1, 0.2, 1.0], (16, 1)), -np.ones(16, dtype=np.int32))
+        offs, m0, m1 = table.gather(M, N)
+        assert int(offs[-1]) == 0 and len(m0) == 0
+        w = scene.make_window(N, M, 10, seed=1, span="full")
+        got, gs = table.refine(w.frames, M)
+    empty = scene.Window(N=N, M=M, frames=w.frames, pair_offsets=offs, m0=m0, m1=m1, true_vec=w.true_vec,
+                         true_scale=w.true_scale, bearing_observations=0, meta={})
+    exp, es = solver.refine(empty)
+    assert np.array_equal(got, exp) and gs.termination == es.termination
