@@ -34,6 +34,12 @@ void mvo_hip_tracks_destroy(mvo_hip_tracks_handle t);
  * previously pushed frame, or negative.  The first frame ever pushed has no predecessor. */
 int mvo_hip_tracks_push(mvo_hip_tracks_handle t, uint32_t n_features, const double *rays, const int32_t *pre_feature);
 
+/* Appends features WITHOUT predecessor to the newest pushed keyframe, behind its existing ones: what
+ * Frame::mergeFrame does to the previous keyframe when a later image is merged onto it
+ * (sliding_window/Frame.cpp:103-119, called from pipeline/Merger.cpp:105-110).  Features of the
+ * next pushed keyframe may name them as predecessors. */
+int mvo_hip_tracks_append(mvo_hip_tracks_handle t, uint32_t n_features, const double *rays);
+
 /* Forget everything (a new sequence). */
 int mvo_hip_tracks_reset(mvo_hip_tracks_handle t);
 
@@ -52,12 +58,12 @@ int mvo_hip_tracks_gather(mvo_hip_tracks_handle t, uint32_t M, uint32_t N, uint6
 /* Measurement (off by default): HIP events on the solver's stream around the two gather kernels of
  * the last refine / gather call. */
 typedef struct {
-  double count_seconds;      /* k_tracks_count */
+  double count_seconds;      /* k_tracks_count + k_tracks_scan */
   double fill_seconds;       /* k_tracks_fill */
   uint64_t residual_blocks;  /* gathered by the last call */
-  uint64_t fill_bytes;       /* algorithmic bytes of that k_tracks_fill launch: per pair 4 B per feature of
-                              * frame a (its counter); per gathered block 4 B per chain step, 2 x 24 B of
-                              * rays read, 2 x 24 B written */
+  uint64_t fill_bytes;       /* algorithmic bytes of that k_tracks_fill launch: 32 B per feature of the M
+                              * newest frames (counter, predecessor, ray); per gathered block 4 B of
+                              * predecessor index, 24 B of ray read, 2 x 24 B written */
 } mvo_hip_tracks_timing; /* 32 bytes */
 int mvo_hip_tracks_set_profiling(mvo_hip_tracks_handle t, int enabled);
 int mvo_hip_tracks_get_timing(mvo_hip_tracks_handle t, mvo_hip_tracks_timing *out);

@@ -4,17 +4,29 @@
 // Frame::getCorrespondingFeatures sliding_window/Frame.hpp:258-302, normFeatures
 // operations/FeatureOperations.cpp:117-122).  No CPU fallback.
 //
-//   k_tracks_counter  on push: _preFeatureCounter of the new frame (Frame.cpp:132-148)
-//   k_tracks_count    one workgroup per frame pair (a, b): how many features of frame a reach back
-//                     b - a + 1 frames (Frame.hpp:277-279)
-//   k_tracks_fill     one workgroup per frame pair: ordered compaction (feature order of frame a,
-//                     as the reference's loop pushes them), chain walk to frame b + 1
-//                     (Frame.hpp:283-289), both rays normalised, written at the pair's offset
+// The reference walks the predecessor chain of a feature again for every frame pair it takes part
+// in (b - a + 1 steps for pair (a, b): quadratic in the track length).  Here a feature of frame a
+// walks its chain ONCE and drops one residual block per step -- step s is pair (a, a + s - 1) --
+// at the position the reference's loop would have pushed it: pair offset + number of features
+// with a smaller index in frame a that also reach back s frames (Frame.hpp:277-291 keeps feature
+// order).  Those ranks come from a count + scan over 64-feature groups:
+//
+//   k_tracks_counter  on push: _preFeatureCounter of the new frame (Frame.cpp:132-148) and the unit
+//                     ray of every feature (normFeatures is a pure function of the stored ray, so
+//                     normalising once at push returns the very same doubles)
+//   k_tracks_count    wavefront per (64-feature group g, frame a): cnt[a][g][s] = features of the
+//                     group that reach back s frames
+//   k_tracks_scan     per frame a and step s: exclusive scan of cnt over the groups (-> the group's
+//                     base rank, in place) and the pair's block count
+//   (host: prefix sum of the P pair counts -> CSR offsets, needed by the solver's tiling anyway)
+//   k_tracks_fill     wavefront per (group, frame a): the chain walk; ranks inside the group by
+//                     ballot; m0 / m1 written straight into the solver's ray buffers
 // All kernels run on the solver's stream; the solve is queued right behind the gather.
 #include "../../include/mvo_hip_tracks.h"
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -22,9 +34,10 @@
 #include "mvo_internal.h"
 
 #define TR_THREADS 256
+#define TR_SCAN_GROUPS 16  // k_tracks_scan: 16 wavefronts share the feature groups of one (a, 64 steps)
 
 struct TracksDev {
-  const double* rays;     // [max_frames][max_features][3]
+  const double* rays;     // [max_frames][max_features][3], unit length
   const int32_t* pre;     // [max_frames][max_features]
   const uint32_t* counter;
   const uint32_t* n_feat; // [max_frames]
@@ -35,38 +48,30 @@ __device__ __forceinline__ uint32_t tr_slot(const TracksDev& t, uint32_t age) { 
   return (t.head + t.max_frames - age) % t.max_frames;
 }
 
+// index of pair (a, a) in the reference's loop order: for a < M: for b in [a, N-1)
+__host__ __device__ __forceinline__ uint32_t tr_pair_start(uint32_t N, uint32_t a) {
+  return a * (N - 1) - (a * (a - 1)) / 2;
+}
+
 // FeatureOperations.cpp:119: scale = 1.0 / cv::norm(v).  Contraction is switched off here: a fused
 // multiply-add in the sum of squares rounds differently from the host's separate multiply and add
 // (the _rn intrinsics are plain operators to the compiler and would be fused all the same).
-__device__ __forceinline__ double tr_inv_norm(const double* __restrict__ v) {
+__device__ __forceinline__ double tr_inv_norm(double x, double y, double z) {
 #pragma clang fp contract(off)
-  const double xx = v[0] * v[0], yy = v[1] * v[1], zz = v[2] * v[2];
+  const double xx = x * x, yy = y * y, zz = z * z;
   const double ss = (xx + yy) + zz;
   return 1.0 / __builtin_sqrt(ss);
 }
 
-// (a, b) of pair p in the reference's loop order: for a < M: for b in [a, N-1)
-__device__ __forceinline__ void tr_pair(uint32_t M, uint32_t N, uint32_t p, uint32_t& a, uint32_t& b) {
-  a = 0;
-  uint32_t start = 0;
-  for (uint32_t k = 0; k < M; ++k) {
-    const uint32_t len = N - 1 - k;
-    if (p >= start + len) start += len;
-    else {
-      a = k;
-      break;
-    }
-  }
-  b = a + (p - start);
-}
-
-__global__ __launch_bounds__(TR_THREADS) void k_tracks_counter(uint32_t n, const int32_t* __restrict__ pre,
+__global__ __launch_bounds__(TR_THREADS) void k_tracks_counter(uint32_t n, const double* __restrict__ rays_in,
+                                                              const int32_t* __restrict__ pre,
                                                               const uint32_t* __restrict__ prev_counter,
-                                                              uint32_t prev_n, int32_t* __restrict__ pre_out,
+                                                              uint32_t prev_n, double* __restrict__ rays_out,
+                                                              int32_t* __restrict__ pre_out,
                                                               uint32_t* __restrict__ counter_out) {
   const uint32_t i = blockIdx.x * TR_THREADS + threadIdx.x;
   if (i >= n) return;
-  const int32_t p = pre[i];
+  const int32_t p = pre ? pre[i] : -1;  // no predecessor array: features appended to a frame (all new tracks)
   if (p >= 0 && (uint32_t)p < prev_n) {  // Frame.cpp:138-139
     counter_out[i] = prev_counter[p] + 1;
     pre_out[i] = p;
@@ -74,63 +79,102 @@ __global__ __launch_bounds__(TR_THREADS) void k_tracks_counter(uint32_t n, const
     counter_out[i] = 0;
     pre_out[i] = -1;
   }
+  const double x = rays_in[3 * i], y = rays_in[3 * i + 1], z = rays_in[3 * i + 2];
+  const double sc = tr_inv_norm(x, y, z);  // FeatureOperations.cpp:119-120
+  rays_out[3 * i] = x * sc;
+  rays_out[3 * i + 1] = y * sc;
+  rays_out[3 * i + 2] = z * sc;
 }
 
-__global__ __launch_bounds__(TR_THREADS) void k_tracks_count(TracksDev t, uint32_t M, uint32_t N,
-                                                            uint32_t* __restrict__ counts) {
-  __shared__ uint32_t wsum[TR_THREADS / 64];
-  uint32_t a, b;
-  tr_pair(M, N, blockIdx.x, a, b);
-  const uint32_t slot = tr_slot(t, a), n = t.n_feat[slot], past = b - a + 1;
-  const uint32_t* __restrict__ cnt = t.counter + (size_t)slot * t.max_features;
-  uint32_t c = 0;
-  for (uint32_t i = threadIdx.x; i < n; i += TR_THREADS) c += cnt[i] >= past ? 1u : 0u;
-  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
-  __syncthreads();
-  if (threadIdx.x == 0) counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-}
-
-__global__ __launch_bounds__(TR_THREADS) void k_tracks_fill(TracksDev t, uint32_t M, uint32_t N,
-                                                           const uint64_t* __restrict__ offsets,
-                                                           double* __restrict__ m0, double* __restrict__ m1) {
-  __shared__ uint32_t wsum[TR_THREADS / 64];
-  __shared__ uint32_t base_sh;
-  uint32_t a, b;
-  tr_pair(M, N, blockIdx.x, a, b);
-  const uint32_t slot_a = tr_slot(t, a), n = t.n_feat[slot_a], past = b - a + 1;
-  const uint32_t* __restrict__ cnt = t.counter + (size_t)slot_a * t.max_features;
-  const uint64_t off = offsets[blockIdx.x];
-  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (threadIdx.x == 0) base_sh = 0;
-  __syncthreads();
-  for (uint32_t i0 = 0; i0 < n; i0 += TR_THREADS) {
-    const uint32_t i = i0 + threadIdx.x;
-    const bool take = i < n && cnt[i] >= past;
-    // rank of this feature among the taken ones of the chunk, in feature order
-    const unsigned long long ballot = __ballot(take);
-    const uint32_t in_wave = __popcll(ballot & ((1ull << lane) - 1ull));
-    if (lane == 0) wsum[wave] = __popcll(ballot);
-    __syncthreads();
-    uint32_t before = base_sh;
-    for (uint32_t w = 0; w < wave; ++w) before += wsum[w];
-    if (take) {
-      uint32_t idx = i;  // Frame.hpp:283-289: follow _preFeature `past` frames back
-      for (uint32_t s = 0; s < past; ++s) idx = (uint32_t)t.pre[(size_t)tr_slot(t, a + s) * t.max_features + idx];
-      const double* __restrict__ r0 = t.rays + ((size_t)slot_a * t.max_features + i) * 3;
-      const double* __restrict__ r1 = t.rays + ((size_t)tr_slot(t, b + 1) * t.max_features + idx) * 3;
-      const double s0 = tr_inv_norm(r0), s1 = tr_inv_norm(r1);
-      const size_t o = 3 * (size_t)(off + before + in_wave);
-      m0[o] = r0[0] * s0;
-      m0[o + 1] = r0[1] * s0;
-      m0[o + 2] = r0[2] * s0;
-      m1[o] = r1[0] * s1;
-      m1[o + 1] = r1[1] * s1;
-      m1[o + 2] = r1[2] * s1;
+// cnt[(a * n_groups + g) * SP + (s - 1)], SP = N - 1 rounded up to 64 (steps beyond N - 1 - a count 0)
+__global__ __launch_bounds__(64) void k_tracks_count(TracksDev t, uint32_t N, uint32_t n_groups, uint32_t SP,
+                                                    uint32_t* __restrict__ cnt) {
+  const uint32_t g = blockIdx.x, a = blockIdx.y, lane = threadIdx.x;
+  const uint32_t slot = tr_slot(t, a), n = t.n_feat[slot];
+  if (g * 64 >= n) return;  // k_tracks_scan never reads the groups past the frame's last feature
+  const uint32_t i = g * 64 + lane;
+  const uint32_t c = i < n ? min(t.counter[(size_t)slot * t.max_features + i], N - 1 - a) : 0u;
+  uint32_t* __restrict__ row = cnt + (size_t)(a * n_groups + g) * SP;
+  for (uint32_t s0 = 0; s0 < SP; s0 += 64) {
+    uint32_t mine = 0;
+    for (uint32_t j = 0; j < 64; ++j) {
+      const uint32_t k = (uint32_t)__popcll(__ballot(c >= s0 + j + 1));
+      if (lane == j) mine = k;
     }
-    __syncthreads();
-    if (threadIdx.x == 0) base_sh += wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    __syncthreads();
+    row[s0 + lane] = mine;
+  }
+}
+
+// grid (SP / 64, M), TR_SCAN_GROUPS wavefronts: lane <-> step, the wavefronts split the feature groups
+__global__ __launch_bounds__(64 * TR_SCAN_GROUPS) void k_tracks_scan(TracksDev t, uint32_t N, uint32_t n_groups,
+                                                                    uint32_t SP, uint32_t* __restrict__ cnt,
+                                                                    uint32_t* __restrict__ counts) {
+  __shared__ uint32_t part[TR_SCAN_GROUPS][64];
+  const uint32_t a = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint32_t s1 = blockIdx.x * 64 + lane;  // s - 1
+  const uint32_t ng = (t.n_feat[tr_slot(t, a)] + 63) / 64;
+  const uint32_t per = (ng + TR_SCAN_GROUPS - 1) / TR_SCAN_GROUPS;
+  const uint32_t lo = min(w * per, ng), hi = min(lo + per, ng);
+  uint32_t* __restrict__ col = cnt + (size_t)a * n_groups * SP + s1;
+  uint32_t sum = 0;
+  for (uint32_t g = lo; g < hi; ++g) sum += col[(size_t)g * SP];
+  part[w][lane] = sum;
+  __syncthreads();
+  uint32_t run = 0, total = 0;
+  for (uint32_t k = 0; k < TR_SCAN_GROUPS; ++k) {
+    const uint32_t v = part[k][lane];
+    run += k < w ? v : 0u;
+    total += v;
+  }
+  for (uint32_t g = lo; g < hi; ++g) {
+    const uint32_t v = col[(size_t)g * SP];
+    col[(size_t)g * SP] = run;
+    run += v;
+  }
+  if (w == 0 && s1 < N - 1 - a) counts[tr_pair_start(N, a) + s1] = total;
+}
+
+__global__ __launch_bounds__(64) void k_tracks_fill(TracksDev t, uint32_t N, uint32_t n_groups, uint32_t SP,
+                                                   const uint32_t* __restrict__ base,
+                                                   const uint64_t* __restrict__ offsets, double* __restrict__ m0,
+                                                   double* __restrict__ m1) {
+  const uint32_t g = blockIdx.x, a = blockIdx.y, lane = threadIdx.x;
+  const uint32_t slot_a = tr_slot(t, a), n = t.n_feat[slot_a];
+  if (g * 64 >= n) return;
+  const uint32_t i = g * 64 + lane;
+  const bool have = i < n;
+  const uint32_t c = have ? min(t.counter[(size_t)slot_a * t.max_features + i], N - 1 - a) : 0u;
+  double r0x = 0.0, r0y = 0.0, r0z = 0.0;
+  if (c) {
+    const double* __restrict__ r0 = t.rays + ((size_t)slot_a * t.max_features + i) * 3;
+    r0x = r0[0];
+    r0y = r0[1];
+    r0z = r0[2];
+  }
+  const uint32_t* __restrict__ brow = base + (size_t)(a * n_groups + g) * SP;
+  const uint64_t* __restrict__ orow = offsets + tr_pair_start(N, a);
+  const unsigned long long below = (1ull << lane) - 1ull;
+  // Frame.hpp:283-289: follow _preFeature; idx is the feature's index in frame a + s - 1
+  uint32_t idx = i;
+  int32_t nxt = c ? t.pre[(size_t)slot_a * t.max_features + i] : -1;
+  for (uint32_t s = 1;; ++s) {
+    const bool alive = c >= s;
+    const unsigned long long bal = __ballot(alive);
+    if (!bal) break;
+    if (alive) {
+      idx = (uint32_t)nxt;
+      const size_t cell = (size_t)tr_slot(t, a + s) * t.max_features + idx;
+      const double* __restrict__ r1 = t.rays + cell * 3;
+      const double x = r1[0], y = r1[1], z = r1[2];
+      if (c > s) nxt = t.pre[cell];  // in flight together with the ray
+      const size_t o = 3 * (size_t)(orow[s - 1] + brow[s - 1] + (uint32_t)__popcll(bal & below));
+      m0[o] = r0x;
+      m0[o + 1] = r0y;
+      m0[o + 2] = r0z;
+      m1[o] = x;
+      m1[o + 1] = y;
+      m1[o + 2] = z;
+    }
   }
 }
 
@@ -143,6 +187,10 @@ struct mvo_hip_tracks_context {
   double* d_rays = nullptr;
   int32_t* d_pre = nullptr;
   uint32_t *d_counter = nullptr, *d_nfeat = nullptr, *d_counts = nullptr;
+  uint32_t* d_cnt = nullptr;  // [M][n_groups][SP]: per-group counts, then base ranks
+  size_t cap_cnt = 0;
+  double* d_rays_in = nullptr;  // staging of the caller's rays
+  uint32_t g_groups = 0, g_sp = 0;  // shape of d_cnt at the last count
   int32_t* d_pre_in = nullptr;  // staging of the caller's predecessor indices
   uint64_t* d_offsets = nullptr;
   double *d_m0 = nullptr, *d_m1 = nullptr;
@@ -210,9 +258,31 @@ int count_pairs(mvo_hip_tracks_context* t, uint32_t M, uint32_t N) {
     for (auto& e : t->ev) TR_TRY(hipEventCreate(&e));
     t->events_ready = true;
   }
+  // feature groups of the widest of the M newest frames; d_cnt holds [M][groups][SP] counts
+  uint32_t groups = 0;
+  for (uint32_t a = 0; a < M; ++a)
+    groups = std::max(groups, (t->h_nfeat[(t->head + t->max_frames - a) % t->max_frames] + 63) / 64);
+  const uint32_t SP = (N - 1 + 63) / 64 * 64;
+  t->g_groups = groups;
+  t->g_sp = SP;
+  const size_t cnt_elems = (size_t)M * groups * SP;
+  if (cnt_elems > t->cap_cnt) {
+    if (t->d_cnt) (void)hipFree(t->d_cnt);
+    t->d_cnt = nullptr;
+    t->cap_cnt = 0;
+    TR_TRY(hipMalloc((void**)&t->d_cnt, sizeof(uint32_t) * cnt_elems));
+    t->cap_cnt = cnt_elems;
+  }
   if (t->profiling) TR_TRY(hipEventRecord(t->ev[0], s));
-  hipLaunchKernelGGL(k_tracks_count, dim3(P), dim3(TR_THREADS), 0, s, dev_view(t), M, N, t->d_counts);
-  TR_TRY(hipGetLastError());
+  if (groups) {
+    hipLaunchKernelGGL(k_tracks_count, dim3(groups, M), dim3(64), 0, s, dev_view(t), N, groups, SP, t->d_cnt);
+    TR_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_tracks_scan, dim3(SP / 64, M), dim3(64 * TR_SCAN_GROUPS), 0, s, dev_view(t), N, groups, SP,
+                       t->d_cnt, t->d_counts);
+    TR_TRY(hipGetLastError());
+  } else {
+    TR_TRY(hipMemsetAsync(t->d_counts, 0, sizeof(uint32_t) * P, s));
+  }
   if (t->profiling) {
     TR_TRY(hipEventRecord(t->ev[1], s));
     t->count_timed = true;
@@ -223,12 +293,9 @@ int count_pairs(mvo_hip_tracks_context* t, uint32_t M, uint32_t N) {
   for (uint32_t p = 0; p < P; ++p) t->h_offsets[p + 1] = t->h_offsets[p] + t->h_counts[p];
   {  // algorithmic bytes of the fill that follows (include/mvo_hip_tracks.h)
     uint64_t bytes = 0;
-    uint32_t p = 0;
-    for (uint32_t a = 0; a < M; ++a)
-      for (uint32_t b = a; b + 1 < N; ++b, ++p)
-        bytes += 4ull * t->h_nfeat[(t->head + t->max_frames - a) % t->max_frames] + (uint64_t)t->h_counts[p] * (96 + 4 * (b - a + 1));
-    t->last_fill_bytes = bytes;
+    for (uint32_t a = 0; a < M; ++a) bytes += 32ull * t->h_nfeat[(t->head + t->max_frames - a) % t->max_frames];
     t->last_blocks = t->h_offsets[P];
+    t->last_fill_bytes = bytes + 76ull * t->last_blocks;
   }
   TR_TRY(hipMemcpyAsync(t->d_offsets, t->h_offsets, sizeof(uint64_t) * (P + 1), hipMemcpyHostToDevice, s));
   return MVO_HIP_OK;
@@ -239,7 +306,8 @@ int fill_pairs(mvo_hip_tracks_context* t, uint32_t M, uint32_t N, double* m0, do
   const uint32_t P = num_pairs(M, N);
   if (t->h_offsets[P] == 0) return MVO_HIP_OK;
   if (t->profiling) TR_TRY(hipEventRecord(t->ev[2], t->stream));
-  hipLaunchKernelGGL(k_tracks_fill, dim3(P), dim3(TR_THREADS), 0, t->stream, dev_view(t), M, N, t->d_offsets, m0, m1);
+  hipLaunchKernelGGL(k_tracks_fill, dim3(t->g_groups, M), dim3(64), 0, t->stream, dev_view(t), N, t->g_groups, t->g_sp,
+                     t->d_cnt, t->d_offsets, m0, m1);
   TR_TRY(hipGetLastError());
   if (t->profiling) {
     TR_TRY(hipEventRecord(t->ev[3], t->stream));
@@ -272,6 +340,7 @@ int mvo_hip_tracks_create(mvo_hip_handle solver, uint32_t max_frames, uint32_t m
                   hipMalloc((void**)&t->d_pre, sizeof(int32_t) * cells) == hipSuccess &&
                   hipMalloc((void**)&t->d_counter, sizeof(uint32_t) * cells) == hipSuccess &&
                   hipMalloc((void**)&t->d_pre_in, sizeof(int32_t) * max_features) == hipSuccess &&
+                  hipMalloc((void**)&t->d_rays_in, sizeof(double) * 3 * max_features) == hipSuccess &&
                   hipMalloc((void**)&t->d_nfeat, sizeof(uint32_t) * max_frames) == hipSuccess &&
                   hipMemset(t->d_nfeat, 0, sizeof(uint32_t) * max_frames) == hipSuccess;
   if (!ok) {
@@ -286,7 +355,8 @@ void mvo_hip_tracks_destroy(mvo_hip_tracks_handle t) {
   if (!t) return;
   (void)hipSetDevice(t->device);
   if (t->stream) (void)hipStreamSynchronize(t->stream);
-  void* bufs[] = {t->d_rays, t->d_pre, t->d_counter, t->d_nfeat, t->d_counts, t->d_pre_in, t->d_offsets, t->d_m0, t->d_m1};
+  void* bufs[] = {t->d_rays, t->d_pre, t->d_counter, t->d_nfeat, t->d_counts, t->d_pre_in, t->d_offsets, t->d_m0, t->d_m1,
+                  t->d_cnt, t->d_rays_in};
   for (void* p : bufs)
     if (p) (void)hipFree(p);
   if (t->h_counts) (void)hipHostFree(t->h_counts);
@@ -314,12 +384,12 @@ int mvo_hip_tracks_push(mvo_hip_tracks_handle t, uint32_t n_features, const doub
   const uint32_t slot = t->n_pushed == 0 ? 0 : (t->head + 1) % t->max_frames;
   const uint32_t prev_n = t->n_pushed == 0 ? 0 : t->h_nfeat[prev];
   if (n_features) {
-    TR_TRY(hipMemcpyAsync(t->d_rays + (size_t)slot * t->max_features * 3, rays, sizeof(double) * 3 * n_features,
-                          hipMemcpyHostToDevice, s));
+    TR_TRY(hipMemcpyAsync(t->d_rays_in, rays, sizeof(double) * 3 * n_features, hipMemcpyHostToDevice, s));
     TR_TRY(hipMemcpyAsync(t->d_pre_in, pre_feature, sizeof(int32_t) * n_features, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_tracks_counter, dim3((n_features + TR_THREADS - 1) / TR_THREADS), dim3(TR_THREADS), 0, s,
-                       n_features, t->d_pre_in, t->d_counter + (size_t)prev * t->max_features, prev_n,
-                       t->d_pre + (size_t)slot * t->max_features, t->d_counter + (size_t)slot * t->max_features);
+                       n_features, t->d_rays_in, t->d_pre_in, t->d_counter + (size_t)prev * t->max_features, prev_n,
+                       t->d_rays + (size_t)slot * t->max_features * 3, t->d_pre + (size_t)slot * t->max_features,
+                       t->d_counter + (size_t)slot * t->max_features);
     TR_TRY(hipGetLastError());
   }
   TR_TRY(hipMemcpyAsync(t->d_nfeat + slot, &n_features, sizeof(uint32_t), hipMemcpyHostToDevice, s));
@@ -327,6 +397,27 @@ int mvo_hip_tracks_push(mvo_hip_tracks_handle t, uint32_t n_features, const doub
   t->h_nfeat[slot] = n_features;
   t->head = slot;
   if (t->n_pushed < 0xFFFFFFFFu) ++t->n_pushed;
+  return MVO_HIP_OK;
+}
+
+int mvo_hip_tracks_append(mvo_hip_tracks_handle t, uint32_t n_features, const double* rays) {
+  if (!t || (n_features && !rays)) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  if (t->n_pushed == 0) return MVO_HIP_ERR_STATE;
+  const uint32_t slot = t->head, n_old = t->h_nfeat[slot];
+  if (n_features > t->max_features - n_old) return MVO_HIP_ERR_UNSUPPORTED;
+  if (n_features == 0) return MVO_HIP_OK;
+  TR_TRY(hipSetDevice(t->device));
+  hipStream_t s = t->stream;
+  const uint32_t n_new = n_old + n_features;
+  const size_t cell = (size_t)slot * t->max_features + n_old;
+  TR_TRY(hipMemcpyAsync(t->d_rays_in, rays, sizeof(double) * 3 * n_features, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_tracks_counter, dim3((n_features + TR_THREADS - 1) / TR_THREADS), dim3(TR_THREADS), 0, s,
+                     n_features, t->d_rays_in, (const int32_t*)nullptr, (const uint32_t*)nullptr, 0u,
+                     t->d_rays + cell * 3, t->d_pre + cell, t->d_counter + cell);
+  TR_TRY(hipGetLastError());
+  TR_TRY(hipMemcpyAsync(t->d_nfeat + slot, &n_new, sizeof(uint32_t), hipMemcpyHostToDevice, s));
+  TR_TRY(hipStreamSynchronize(s));
+  t->h_nfeat[slot] = n_new;
   return MVO_HIP_OK;
 }
 

@@ -9,7 +9,8 @@ import numpy as np
 from . import capi
 
 EXPORTED_SYMBOLS = [
-    "mvo_hip_tracks_create", "mvo_hip_tracks_destroy", "mvo_hip_tracks_push", "mvo_hip_tracks_reset",
+    "mvo_hip_tracks_create", "mvo_hip_tracks_destroy", "mvo_hip_tracks_push", "mvo_hip_tracks_append",
+    "mvo_hip_tracks_reset",
     "mvo_hip_tracks_refine", "mvo_hip_tracks_gather", "mvo_hip_tracks_set_profiling", "mvo_hip_tracks_get_timing",
 ]
 
@@ -29,6 +30,7 @@ def load():
         L.mvo_hip_tracks_destroy.argtypes = [C.c_void_p]
         L.mvo_hip_tracks_destroy.restype = None
         L.mvo_hip_tracks_push.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.mvo_hip_tracks_append.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         L.mvo_hip_tracks_reset.argtypes = [C.c_void_p]
         L.mvo_hip_tracks_refine.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                             C.POINTER(capi.Options), C.POINTER(capi.Summary)]
@@ -78,6 +80,13 @@ class TrackTable:
         rc = self._lib.mvo_hip_tracks_push(self._h, len(rays), rays.ctypes.data, pre.ctypes.data)
         if rc != capi.OK:
             raise capi.MvoHipError(rc, "mvo_hip_tracks_push")
+
+    def append(self, rays):
+        """Features without predecessor appended to the newest keyframe (Frame::mergeFrame)."""
+        rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 3)
+        rc = self._lib.mvo_hip_tracks_append(self._h, len(rays), rays.ctypes.data)
+        if rc != capi.OK:
+            raise capi.MvoHipError(rc, "mvo_hip_tracks_append")
 
     def reset(self):
         rc = self._lib.mvo_hip_tracks_reset(self._h)

@@ -122,6 +122,34 @@ def test_invalid_predecessors_start_new_tracks(solver):
     assert np.array_equal(m0, e0) and np.array_equal(m1, e1)
 
 
+def test_append_to_newest_keyframe(solver):
+    """Frame::mergeFrame (Frame.cpp:103-119) appends features without predecessor to a keyframe that
+    is already in the window; the next keyframe may continue them.  The table after push / append /
+    push must gather exactly as one that received the grown frames in one piece."""
+    rng = np.random.default_rng(11)
+    ray = lambda n: rng.normal(size=(n, 3)) * 0.2 + [0, 0, 1.0]
+    f0 = (ray(100), -np.ones(100, dtype=np.int32))
+    f1a = (ray(90), np.arange(90, dtype=np.int32))           # 90 of the 100 continue
+    extra = ray(37)                                            # appended to frame 1 later
+    f1 = (np.concatenate([f1a[0], extra]), np.concatenate([f1a[1], -np.ones(37, dtype=np.int32)]))
+    pre2 = np.concatenate([np.arange(0, 90, 2), np.arange(90, 127)]).astype(np.int32)  # old and appended tracks
+    f2 = (ray(len(pre2)), pre2)
+    f3 = (ray(len(pre2)), np.arange(len(pre2), dtype=np.int32))
+    with tracks_capi.TrackTable(solver, max_frames=4, max_features=128) as table:
+        table.push(*f0)
+        table.push(*f1a)
+        table.append(extra)
+        with pytest.raises(capi.MvoHipError) as e:
+            table.append(ray(2))  # 127 + 2 > 128
+        assert e.value.status == capi.ERR_UNSUPPORTED
+        table.push(*f2)
+        table.push(*f3)
+        offs, m0, m1 = table.gather(3, 4)
+    eo, e0, e1 = scene.gather_tracks_numpy([f0, f1, f2, f3], 3)
+    assert int(eo[-1]) > 0 and np.array_equal(offs, eo)
+    assert np.array_equal(m0, e0) and np.array_equal(m1, e1)
+
+
 def test_argument_errors(solver):
     with pytest.raises(capi.MvoHipError) as e:
         tracks_capi.TrackTable(solver, max_frames=1, max_features=10)
