@@ -1,7 +1,9 @@
 // IterativeRefinementHip.hpp -- the reference-side adapter: same signature as
 // IterativeRefinement::refine (mvo/src/algorithms/IterativeRefinement.hpp:181-192), body replaced
 // by one call into libmvo_hip.  C++11, warning-clean under -Wall -Werror -pedantic -Wextra
-// (mvo/CMakeLists.txt:4,71).  Header-only; depends on include/mvo_hip.h only.
+// (mvo/CMakeLists.txt:4,71).  Header-only; depends on include/mvo_hip.h and include/mvo_hip_tracks.h
+// only.  Second half: TrackMirror, which keeps the Frame/Feature tables on the GPU so that the
+// gathering loop runs there as well (include/mvo_hip_tracks.h).
 //
 // What stays on this side of the boundary (exactly the reference's own statements):
 //   * packing refinementData -> plain records            (IterativeRefinement.cpp:36-43)
@@ -26,6 +28,7 @@
 #include <vector>
 
 #include "mvo_hip.h"
+#include "mvo_hip_tracks.h"
 
 namespace mvo_hip_adapter {
 
@@ -120,6 +123,90 @@ inline int refine(mvo_hip_handle handle, std::vector<RefinementFrameT> &refineme
   }
   return MVO_HIP_OK;
 }
+
+// The Refiner's mirror of the sliding window on the GPU.  Every keyframe reaches Refiner::stage once
+// (pipeline/Refiner.cpp:27), after the Merger fixed its connections (Merger.cpp:115-124) and the
+// BaselineEstimator disbanded the outliers (BaselineEstimator.cpp:32): keyframe() pushes it then.
+// Frame::mergeFrame (Frame.cpp:103-119) may append new features to a keyframe afterwards; they are
+// picked up when the next keyframe arrives, before it is pushed.
+// FrameT additionally needs
+//   void getFeatureTable(std::size_t from, std::vector<RayT> &rays, std::vector<int> &preFeature) const
+// returning _positionProjected and _preFeature of the features [from, size()) under the frame's lock.
+template <class RayT, class FrameT>
+class TrackMirror {
+ public:
+  TrackMirror() : _solver(0), _tracks(0), _pushedOfNewest(0) {}
+  ~TrackMirror() {
+    if (_tracks) mvo_hip_tracks_destroy(_tracks);
+  }
+  int create(mvo_hip_handle solver, unsigned int ringFrames, unsigned int maxFeatures) {
+    _solver = solver;
+    return mvo_hip_tracks_create(solver, ringFrames, maxFeatures, &_tracks);
+  }
+  mvo_hip_tracks_handle handle() const { return _tracks; }
+
+  // newest keyframe; `previous` = the keyframe handed over by the call before (0 for the first)
+  int keyframe(const FrameT &frame, const FrameT *previous) {
+    std::vector<RayT> rays;
+    std::vector<int> pre;
+    if (previous) {
+      previous->getFeatureTable(_pushedOfNewest, rays, pre);
+      const int rc = mvo_hip_tracks_append(_tracks, static_cast<uint32_t>(rays.size()), flat(rays));
+      if (rc != MVO_HIP_OK) return rc;
+    }
+    frame.getFeatureTable(0, rays, pre);
+    std::vector<int32_t> pre32(pre.begin(), pre.end());
+    _pushedOfNewest = rays.size();
+    return mvo_hip_tracks_push(_tracks, static_cast<uint32_t>(rays.size()), flat(rays), pre32.data());
+  }
+
+  // IterativeRefinement::refine with the gathering loop on the device; same arguments, the window is
+  // the newest numberToNote keyframes handed to keyframe()
+  template <class RefinementFrameT>
+  int refine(std::vector<RefinementFrameT> &refinementData, unsigned int numberToRefine, unsigned int numberToNote,
+             int maxNumthreads, int maxNumIterations, double functionTolerance, double gradientTolerance,
+             double parameterTolerance, bool useLossFunction, double lowestLength, double highestLength,
+             bool fixLength, mvo_hip_summary *summary = 0) {
+    assert(refinementData.size() == numberToNote);  // IterativeRefinement.cpp:28-30
+    std::vector<mvo_hip_frame> frames(refinementData.size());
+    for (std::size_t i = 0; i < refinementData.size(); i++) {  // IterativeRefinement.cpp:36-43
+      for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) frames[i].R[3 * r + c] = refinementData[i].R(r, c);
+      for (int c = 0; c < 3; c++) frames[i].vec[c] = refinementData[i].vec[c];
+      frames[i].scale = refinementData[i].scale;
+    }
+    mvo_hip_options opt;
+    opt.max_num_iterations = maxNumIterations;
+    opt.num_threads = maxNumthreads;
+    opt.function_tolerance = functionTolerance;
+    opt.gradient_tolerance = gradientTolerance;
+    opt.parameter_tolerance = parameterTolerance;
+    opt.use_loss_function = useLossFunction ? 1 : 0;
+    opt.fix_length = fixLength ? 1 : 0;  // IterativeRefinement.cpp:105
+    opt.lowest_length = lowestLength;
+    opt.highest_length = highestLength;
+    opt.assembly_mode = MVO_HIP_ASSEMBLY_AUTO;
+    opt.reserved = 0;
+    const int status = mvo_hip_tracks_refine(_tracks, frames.data(), numberToRefine, numberToNote, &opt, summary);
+    if (status != MVO_HIP_OK) return status;
+    for (unsigned int i = 0; i < numberToRefine; i++) {  // IterativeRefinement.cpp:240-246
+      refinementData[i].scale = frames[i].scale;
+      for (int c = 0; c < 3; c++) refinementData[i].vec[c] = frames[i].vec[c];
+    }
+    return MVO_HIP_OK;
+  }
+
+ private:
+  TrackMirror(const TrackMirror &);
+  TrackMirror &operator=(const TrackMirror &);
+  static const double *flat(const std::vector<RayT> &rays) {
+    // cv::Vec3d is three contiguous doubles (cv::Matx<double, 3, 1>::val); so is the stand-in
+    return rays.empty() ? 0 : &rays[0][0];
+  }
+  mvo_hip_handle _solver;
+  mvo_hip_tracks_handle _tracks;
+  std::size_t _pushedOfNewest;
+};
 
 }  // namespace mvo_hip_adapter
 

@@ -4,6 +4,9 @@
 //
 //   adapter_check gather <tracks.bin> <csr.bin>     CPU only: dumps the CSR buffers the adapter builds
 //   adapter_check refine <tracks.bin> <out.bin>     GPU: runs refine() through libmvo_hip
+//   adapter_check tracks <tracks.bin> <out.bin>     GPU: keyframes mirrored into the device-resident
+//                                                   track table (TrackMirror), refine from there; the
+//                                                   device-gathered CSR buffers follow the results
 //
 // tracks.bin (little endian): int32 N, M, maxNumIterations, useLoss, fixLength; double ftol, gtol,
 //   ptol, lowest, highest; per frame: double R[9], vec[3], scale; int32 nfeat; per feature:
@@ -54,6 +57,15 @@ class Frame {
     for (unsigned int i = 0; i < past; i++) f = f->preFrame;
     return *f;
   }
+  // what TrackMirror reads: _positionProjected and _preFeature of the features [from, size())
+  void getFeatureTable(std::size_t from, std::vector<Vec3> &rays, std::vector<int> &pre) const {
+    rays.clear();
+    pre.clear();
+    for (std::size_t i = from; i < features.size(); i++) {
+      rays.push_back(features[i].ray);
+      pre.push_back(features[i].preFeature);
+    }
+  }
   // Frame.hpp:258-302: features of THIS frame whose track reaches `past` frames back
   void getCorrespondingFeatures(unsigned int past, std::vector<Vec3> &oldFeatures,
                                 std::vector<Vec3> &newFeatures) const {
@@ -78,7 +90,7 @@ bool rd(FILE *f, void *p, std::size_t n) { return std::fread(p, 1, n, f) == n; }
 
 int main(int argc, char **argv) {
   if (argc != 4) {
-    std::fprintf(stderr, "usage: adapter_check gather|refine <tracks.bin> <out.bin>\n");
+    std::fprintf(stderr, "usage: adapter_check gather|refine|tracks <tracks.bin> <out.bin>\n");
     return 2;
   }
   const std::string mode = argv[1];
@@ -118,6 +130,52 @@ int main(int argc, char **argv) {
     std::fwrite(g.pair_offsets.data(), 8, g.pair_offsets.size(), o);
     std::fwrite(g.m0.data(), 8, g.m0.size(), o);
     std::fwrite(g.m1.data(), 8, g.m1.size(), o);
+  } else if (mode == "tracks") {
+    mvo_hip_handle h = 0;
+    int rc = mvo_hip_create(0, 1, N, 0, &h);
+    if (rc != MVO_HIP_OK) {
+      std::fprintf(stderr, "mvo_hip_create: %s\n", mvo_hip_status_string(rc));
+      return 10 + rc;
+    }
+    std::size_t widest = 1;
+    for (unsigned int i = 0; i < N; i++) widest = frames[i].features.size() > widest ? frames[i].features.size() : widest;
+    mvo_hip_summary s;
+    std::memset(&s, 0, sizeof s);
+    std::vector<uint64_t> offs;
+    std::vector<double> m0, m1;
+    {
+      mvo_hip_adapter::TrackMirror<Vec3, Frame> mirror;
+      rc = mirror.create(h, N + 1, static_cast<unsigned int>(widest));
+      for (unsigned int k = N; rc == MVO_HIP_OK && k-- > 0;)  // oldest keyframe first, as the pipeline delivers them
+        rc = mirror.keyframe(frames[k], k + 1 < N ? &frames[k + 1] : 0);
+      if (rc == MVO_HIP_OK)
+        rc = mirror.refine(data, M, N, 4, hdr[2], tol[0], tol[1], tol[2], hdr[3] != 0, tol[3], tol[4], hdr[4] != 0, &s);
+      if (rc == MVO_HIP_OK) {
+        offs.resize(mvo_hip_num_pairs(M, N) + 1);
+        rc = mvo_hip_tracks_gather(mirror.handle(), M, N, offs.data(), 0, 0, 0);
+      }
+      if (rc == MVO_HIP_OK) {
+        m0.resize(3 * offs.back() + 3);
+        m1.resize(3 * offs.back() + 3);
+        rc = mvo_hip_tracks_gather(mirror.handle(), M, N, offs.data(), m0.data(), m1.data(), offs.back());
+      }
+    }
+    mvo_hip_destroy(h);
+    if (rc != MVO_HIP_OK) {
+      std::fprintf(stderr, "tracks: %s\n", mvo_hip_status_string(rc));
+      return 10 + rc;
+    }
+    for (unsigned int i = 0; i < N; i++) {
+      std::fwrite(data[i].vec.v, 8, 3, o);
+      std::fwrite(&data[i].scale, 8, 1, o);
+    }
+    std::fwrite(&s, sizeof s, 1, o);
+    const uint64_t np = offs.size() - 1, nb = offs.back();
+    std::fwrite(&np, 8, 1, o);
+    std::fwrite(&nb, 8, 1, o);
+    std::fwrite(offs.data(), 8, offs.size(), o);
+    std::fwrite(m0.data(), 8, 3 * nb, o);
+    std::fwrite(m1.data(), 8, 3 * nb, o);
   } else {
     mvo_hip_handle h = 0;
     int rc = mvo_hip_create(0, 1, N, 0, &h);

@@ -68,3 +68,38 @@ def test_adapter_refine_matches_oracle(tmp_path, oracle, c, use_loss, fix):
     # rounding dependent, so only runs that hit the cap are compared on the iteration count
     if so.reason == 1 and reason == 1:
         assert (term, iters) == (so.termination, so.iterations)
+
+
+def _read_csr(raw, base):
+    n_pairs, n_blocks = struct.unpack_from("<2Q", raw, base)
+    offs = np.frombuffer(raw, dtype="<u8", count=n_pairs + 1, offset=base + 16)
+    b = base + 16 + 8 * (n_pairs + 1)
+    m0 = np.frombuffer(raw, dtype="<f8", count=3 * n_blocks, offset=b).reshape(-1, 3)
+    m1 = np.frombuffer(raw, dtype="<f8", count=3 * n_blocks, offset=b + 24 * n_blocks).reshape(-1, 3)
+    return offs, m0, m1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c", CASES, ids=lambda c: f"n{c['N']}m{c['M']}")
+@pytest.mark.parametrize("use_loss", [False, True])
+def test_track_mirror_equals_host_gathering_adapter(tmp_path, c, use_loss):
+    """TrackMirror (keyframes mirrored into include/mvo_hip_tracks.h's table, gathering loop on the
+    device) against the adapter that runs the reference's own loops on the host (`gather` / `refine`
+    modes: Frame::getCorrespondingFeatures + normFeatures as C++): the CSR buffers and the refined
+    baselines must be bit-identical."""
+    _need_exe()
+    w = _window(c)
+    tracks = str(tmp_path / "tracks.bin")
+    scene.write_track_file(w, tracks, use_loss_function=use_loss, **FIXED10)
+    outs = {}
+    for mode in ("gather", "refine", "tracks"):
+        outs[mode] = str(tmp_path / f"{mode}.bin")
+        subprocess.check_call([EXE, mode, tracks, outs[mode]])
+    host_csr = _read_csr(open(outs["gather"], "rb").read(), 0)
+    host = open(outs["refine"], "rb").read()
+    dev = open(outs["tracks"], "rb").read()
+    n_res = 32 * w.N + 40  # N x (vec, scale) + mvo_hip_summary
+    assert dev[:n_res] == host[:n_res]
+    dev_csr = _read_csr(dev, n_res)
+    for got, exp in zip(dev_csr, host_csr):
+        assert np.array_equal(got, exp)
