@@ -128,10 +128,31 @@ def cpu_baseline(ws, opt_kw, use_loss):
         if el > 10.0 or reps >= 50:
             break
     its = s.iterations * reps
-    return {"value": round(its / el, 3), "unit": "LM iterations/s", "cores": 1, "kind": "port",
-            "sample": f"{reps} solve(s) of {note} ({sample.n_residual_blocks} residual blocks, "
-                      f"{s.iterations} LM iterations each) in {el:.2f} s on one host core",
-            "residual_blocks_per_s": round(sample.n_residual_blocks * its / el, 1)}
+    out = {"value": round(its / el, 3), "unit": "LM iterations/s", "cores": 1, "kind": "port",
+           "sample": f"{reps} solve(s) of {note} ({sample.n_residual_blocks} residual blocks, "
+                     f"{s.iterations} LM iterations each) in {el:.2f} s on one host core",
+           "residual_blocks_per_s": round(sample.n_residual_blocks * its / el, 1)}
+    # also the reference's default of 4 threads (mvo.cfg:47) and this box's CPU share
+    # (OMP_NUM_THREADS on the GPU box, else the visible cores, at most 16); ~3 s each
+    share = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    legs = {}
+    for th in sorted({4, share}):
+        if th <= 1:
+            continue
+        orc.set_threads(th)
+        try:
+            k, t1 = 0, time.perf_counter()
+            while True:
+                _, st, _ = orc.refine(sample, opt)
+                k += 1
+                e2 = time.perf_counter() - t1
+                if e2 > 3.0 or k >= 50:
+                    break
+            legs[str(th)] = round(st.iterations * k / e2, 3)
+        finally:
+            orc.set_threads(1)
+    out["threads"] = legs  # LM iterations/s with that many threads (evaluation and QR both parallel)
+    return out
 
 
 def bench_epipolar(args, rank, local_rank, world, barrier, dist, torch):

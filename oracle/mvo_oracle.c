@@ -16,6 +16,15 @@
 #define MAXC (3 * MAXM)   /* local columns: per refined frame (da, db, dt) */
 #define MAXG (4 * MAXM)   /* global parameters: per refined frame vec(3) + t(1) */
 
+/* Threads for the timing legs of bench.py's cpu_baseline (1 thread, the reference's
+ * default of 4 = maxNumThreads, mvo/cfg/mvo.cfg:47, all cores).  Ceres 1.14 evaluates residual blocks
+ * on num_threads threads; the dense QR is parallelised here as well (row ranges reduced separately,
+ * then combined), which is more than Ceres does -- a generous baseline.  Default 1: every parity test
+ * runs the serial path, whose summation order never changes. */
+static int g_threads = 1;
+void mvo_oracle_set_threads(int32_t n) { g_threads = n < 1 ? 1 : (n > 256 ? 256 : n); }
+int32_t mvo_oracle_get_threads(void) { return g_threads; }
+
 /* ------------------------------------------------------------------------------------ */
 /* scalar helpers                                                                        */
 /* ------------------------------------------------------------------------------------ */
@@ -176,6 +185,82 @@ static void cauchy(double s, double rho[3]) {
  *               rho'' < 0 for Cauchy the Corrector scales residual and Jacobian row by
  *               sqrt(rho'); only active columns are emitted (jac is n_obs x ncol).
  */
+/* one frame pair (a, b) = pair index p: adds to *cost_acc and grad_acc (may be NULL) */
+static void evaluate_pair(const ctx_t *c, const double vecs[][3], const double *s, const double *sp, int raw,
+                          int use_loss, int ncol, uint32_t p, uint32_t a, uint32_t b, double *res, double *jac,
+                          double *cost_acc, double *grad_acc) {
+  const uint32_t M = c->M;
+  double cost = *cost_acc;
+  const uint32_t kmax = b < M - 1 ? b : M - 1;
+  /* IR.cpp:137-144: fresh zero offset per pair; only frame b itself is added if b >= M */
+  double offset[3] = {0.0, 0.0, 0.0};
+  if (b >= M)
+    for (int j = 0; j < 3; j++) offset[j] = c->frames[b].scale * c->frames[b].vec[j];
+  /* IR.cpp:466-577: s0*v0 + s1*v1 + ... summed left to right */
+  double u[3] = {0.0, 0.0, 0.0};
+  for (uint32_t k = a; k <= kmax; k++)
+    for (int j = 0; j < 3; j++) {
+      double term = s[k] * vecs[k][j];
+      u[j] = (k == a) ? term : u[j] + term;
+    }
+  /* IR.cpp:254-255 */
+  for (int j = 0; j < 3; j++) u[j] = u[j] + offset[j];
+  const double nb = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+  for (int j = 0; j < 3; j++) u[j] /= nb;
+
+  const double *R0 = c->frames[a].R;      /* IR.cpp:172 */
+  const double *R1 = c->frames[b + 1].R;  /* IR.cpp:171 */
+
+  for (uint64_t i = c->off[p]; i < c->off[p + 1]; i++) {
+    const double *m0 = c->m0 + 3 * i, *m1 = c->m1 + 3 * i;
+    double p0[3], x[3], y[3];
+    mat3_vec(R0, m0, p0);
+    cross3(u, p0, x);
+    mat3t_vec(R1, x, y);
+    double r = dot3(m1, y); /* IR.cpp:257-258 */
+    double sr = 1.0;
+    if (use_loss) {
+      double rho[3];
+      cauchy(r * r, rho);
+      cost += 0.5 * rho[0];
+      sr = sqrt(rho[1]);
+    } else {
+      cost += 0.5 * (r * r);
+    }
+    if (jac || grad_acc) {
+      double row[MAXC];
+      for (int j = 0; j < ncol; j++) row[j] = 0.0;
+      double p1[3], cc[3], g[3];
+      mat3_vec(R1, m1, p1);
+      cross3(p0, p1, cc);
+      const double uc = dot3(u, cc);
+      for (int j = 0; j < 3; j++) g[j] = (cc[j] - u[j] * uc) / nb;
+      for (uint32_t k = a; k <= kmax; k++) {
+        const double *v = vecs[k];
+        const double jl0[3] = {-2.0 * v[1], 2.0 * v[0], 0.0};
+        const double jl1[3] = {2.0 * v[2], 0.0, -2.0 * v[0]};
+        const double d0 = s[k] * dot3(g, jl0);
+        const double d1 = s[k] * dot3(g, jl1);
+        const double dt = sp[k] * dot3(v, g);
+        if (raw) {
+          row[3 * k + 0] = d0;
+          row[3 * k + 1] = d1;
+          row[3 * k + 2] = dt;
+        } else {
+          row[c->colmap[3 * k + 0]] = d0 * sr;
+          row[c->colmap[3 * k + 1]] = d1 * sr;
+          if (c->colmap[3 * k + 2] >= 0) row[c->colmap[3 * k + 2]] = dt * sr;
+        }
+      }
+      if (jac) memcpy(jac + (size_t)i * ncol, row, sizeof(double) * ncol);
+      if (grad_acc)
+        for (int j = 0; j < ncol; j++) grad_acc[j] += row[j] * (r * sr);
+    }
+    if (res) res[i] = r * sr;
+  }
+  *cost_acc = cost;
+}
+
 static double evaluate(const ctx_t *c, const double vecs[][3], const double *t, int raw,
                        double *res, double *jac, double *grad) {
   const uint32_t M = c->M, N = c->N;
@@ -192,78 +277,31 @@ static double evaluate(const ctx_t *c, const double vecs[][3], const double *t, 
     sp[k] = mvo_oracle_scale_derivative(t[k], MAX, MIN);
   }
 
-  uint32_t p = 0;
-  for (uint32_t a = 0; a < M; a++) {
-    for (uint32_t b = a; b < N - 1; b++, p++) {
-      const uint32_t kmax = b < M - 1 ? b : M - 1;
-      /* IR.cpp:137-144: fresh zero offset per pair; only frame b itself is added if b >= M */
-      double offset[3] = {0.0, 0.0, 0.0};
-      if (b >= M)
-        for (int j = 0; j < 3; j++) offset[j] = c->frames[b].scale * c->frames[b].vec[j];
-      /* IR.cpp:466-577: s0*v0 + s1*v1 + ... summed left to right */
-      double u[3] = {0.0, 0.0, 0.0};
-      for (uint32_t k = a; k <= kmax; k++)
-        for (int j = 0; j < 3; j++) {
-          double term = s[k] * vecs[k][j];
-          u[j] = (k == a) ? term : u[j] + term;
-        }
-      /* IR.cpp:254-255 */
-      for (int j = 0; j < 3; j++) u[j] = u[j] + offset[j];
-      const double nb = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
-      for (int j = 0; j < 3; j++) u[j] /= nb;
-
-      const double *R0 = c->frames[a].R;      /* IR.cpp:172 */
-      const double *R1 = c->frames[b + 1].R;  /* IR.cpp:171 */
-
-      for (uint64_t i = c->off[p]; i < c->off[p + 1]; i++) {
-        const double *m0 = c->m0 + 3 * i, *m1 = c->m1 + 3 * i;
-        double p0[3], x[3], y[3];
-        mat3_vec(R0, m0, p0);
-        cross3(u, p0, x);
-        mat3t_vec(R1, x, y);
-        double r = dot3(m1, y); /* IR.cpp:257-258 */
-        double sr = 1.0;
-        if (use_loss) {
-          double rho[3];
-          cauchy(r * r, rho);
-          cost += 0.5 * rho[0];
-          sr = sqrt(rho[1]);
-        } else {
-          cost += 0.5 * (r * r);
-        }
-        if (jac || grad) {
-          double row[MAXC];
-          for (int j = 0; j < ncol; j++) row[j] = 0.0;
-          double p1[3], cc[3], g[3];
-          mat3_vec(R1, m1, p1);
-          cross3(p0, p1, cc);
-          const double uc = dot3(u, cc);
-          for (int j = 0; j < 3; j++) g[j] = (cc[j] - u[j] * uc) / nb;
-          for (uint32_t k = a; k <= kmax; k++) {
-            const double *v = vecs[k];
-            const double jl0[3] = {-2.0 * v[1], 2.0 * v[0], 0.0};
-            const double jl1[3] = {2.0 * v[2], 0.0, -2.0 * v[0]};
-            const double d0 = s[k] * dot3(g, jl0);
-            const double d1 = s[k] * dot3(g, jl1);
-            const double dt = sp[k] * dot3(v, g);
-            if (raw) {
-              row[3 * k + 0] = d0;
-              row[3 * k + 1] = d1;
-              row[3 * k + 2] = dt;
-            } else {
-              row[c->colmap[3 * k + 0]] = d0 * sr;
-              row[c->colmap[3 * k + 1]] = d1 * sr;
-              if (c->colmap[3 * k + 2] >= 0) row[c->colmap[3 * k + 2]] = dt * sr;
-            }
-          }
-          if (jac) memcpy(jac + (size_t)i * ncol, row, sizeof(double) * ncol);
-          if (grad)
-            for (int j = 0; j < ncol; j++) grad[j] += row[j] * (r * sr);
-        }
-        if (res) res[i] = r * sr;
-      }
-    }
+  if (g_threads <= 1) { /* the parity path: one running sum over all residual blocks, pair-major */
+    uint32_t p = 0;
+    for (uint32_t a = 0; a < M; a++)
+      for (uint32_t b = a; b < N - 1; b++, p++)
+        evaluate_pair(c, vecs, s, sp, raw, use_loss, ncol, p, a, b, res, jac, &cost, grad);
+    return cost;
   }
+
+  /* timing legs: pairs in parallel, per-pair sums added up in pair order afterwards */
+  const int P = (int)c->n_pairs;
+  double *pc = (double *)calloc((size_t)P * (MAXC + 1), sizeof(double));
+  if (!pc) return NAN;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(g_threads)
+  for (int p = 0; p < P; p++) {
+    uint32_t a, b;
+    mvo_oracle_pair(M, N, (uint32_t)p, &a, &b);
+    evaluate_pair(c, vecs, s, sp, raw, use_loss, ncol, (uint32_t)p, a, b, res, jac, pc + (size_t)p * (MAXC + 1),
+                  grad ? pc + (size_t)p * (MAXC + 1) + 1 : NULL);
+  }
+  for (int p = 0; p < P; p++) {
+    cost += pc[(size_t)p * (MAXC + 1)];
+    if (grad)
+      for (int j = 0; j < ncol; j++) grad[j] += pc[(size_t)p * (MAXC + 1) + 1 + j];
+  }
+  free(pc);
   return cost;
 }
 
@@ -520,22 +558,42 @@ static void householder_rows(double *W, int m, int n) {
   }
 }
 
-/* returns 0 ok, 1 = non-finite / singular (=> LINEAR_SOLVER_FAILURE) */
-static int lsq_qr(const double *J, const double *r, uint64_t m, int n, const double *D, double *y) {
+/* folds rows [lo, hi) of [J | r] into the running triangle held in the top n rows of W */
+static void qr_fold_rows(double *W, const double *J, const double *r, uint64_t lo, uint64_t hi, int n) {
   const int ld = n + 1;
-  double *W = (double *)calloc((size_t)(n + QR_BLOCK) * ld, sizeof(double));
-  if (!W) return 1;
-  uint64_t done = 0;
-  /* top n rows of W hold the running [R | Q^T r]; start with the LM rows [D | 0] */
-  for (int i = 0; i < n; i++) W[i * ld + i] = D[i];
-  while (done < m) {
-    uint64_t nb = m - done < QR_BLOCK ? m - done : QR_BLOCK;
+  uint64_t done = lo;
+  while (done < hi) {
+    uint64_t nb = hi - done < QR_BLOCK ? hi - done : QR_BLOCK;
     for (uint64_t i = 0; i < nb; i++) {
       memcpy(W + (size_t)(n + i) * ld, J + (size_t)(done + i) * n, sizeof(double) * n);
       W[(size_t)(n + i) * ld + n] = r[done + i];
     }
     householder_rows(W, (int)(n + nb), n);
     done += nb;
+  }
+}
+
+/* returns 0 ok, 1 = non-finite / singular (=> LINEAR_SOLVER_FAILURE) */
+static int lsq_qr(const double *J, const double *r, uint64_t m, int n, const double *D, double *y) {
+  const int ld = n + 1;
+  int T = g_threads;
+  if ((uint64_t)T * QR_BLOCK > m) T = 1;
+  double *W = (double *)calloc((size_t)(n + QR_BLOCK) * ld * (size_t)T, sizeof(double));
+  if (!W) return 1;
+  /* top n rows of W hold the running [R | Q^T r]; start with the LM rows [D | 0] */
+  for (int i = 0; i < n; i++) W[i * ld + i] = D[i];
+  if (T == 1) {
+    qr_fold_rows(W, J, r, 0, m, n);
+  } else {
+    /* timing legs: every thread reduces its own row range to a triangle; the T triangles are
+     * stacked under the first and reduced once more */
+    const size_t stride = (size_t)(n + QR_BLOCK) * ld;
+#pragma omp parallel for schedule(static, 1) num_threads(T)
+    for (int k = 0; k < T; k++) qr_fold_rows(W + stride * k, J, r, m * k / T, m * (k + 1) / T, n);
+    for (int k = 1; k < T; k++) {
+      memcpy(W + (size_t)n * ld, W + stride * k, sizeof(double) * (size_t)n * ld);
+      householder_rows(W, 2 * n, n);
+    }
   }
   int bad = 0;
   for (int i = n - 1; i >= 0; i--) {

@@ -101,6 +101,12 @@ typedef struct {
   int32_t step_is_successful;
 } mvo_oracle_iteration;
 
+/* Threads used by mvo_oracle_refine / mvo_oracle_eval (default 1 = the serial parity path; > 1 is for
+ * bench.py's cpu_baseline timing legs only: sums are formed per pair and per row range, so results
+ * differ from the serial ones in the last bits). */
+void mvo_oracle_set_threads(int32_t n);
+int32_t mvo_oracle_get_threads(void);
+
 /* |P| = M(N-1) - M(M-1)/2 and the idx-th pair (a,b) in the reference's loop order
  * (IterativeRefinement.cpp:116,134). */
 int32_t mvo_oracle_num_pairs(uint32_t M, uint32_t N);

@@ -72,6 +72,9 @@ def lib():
         L.mvo_oracle_scale.argtypes = [C.c_double] * 3
         L.mvo_oracle_scale_derivative.restype = C.c_double
         L.mvo_oracle_scale_derivative.argtypes = [C.c_double] * 3
+        L.mvo_oracle_set_threads.argtypes = [C.c_int32]
+        L.mvo_oracle_set_threads.restype = None
+        L.mvo_oracle_get_threads.restype = C.c_int32
         L.mvo_oracle_num_pairs.restype = C.c_int32
         L.mvo_oracle_num_pairs.argtypes = [C.c_uint32, C.c_uint32]
         _LIB = L
@@ -97,6 +100,15 @@ def _prep(w):
     m0 = np.ascontiguousarray(w.m0, dtype=np.float64)
     m1 = np.ascontiguousarray(w.m1, dtype=np.float64)
     return frames, offs, m0, m1
+
+
+def set_threads(n):
+    """Threads of refine()/evaluate(); 1 (default) is the serial parity path, more is for timing only."""
+    lib().mvo_oracle_set_threads(int(n))
+
+
+def get_threads():
+    return lib().mvo_oracle_get_threads()
 
 
 def reverse_scale(length, max_len=2.0, min_len=0.25):

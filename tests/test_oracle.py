@@ -213,3 +213,25 @@ def test_rejects_bad_shapes(oracle):
     w.M, w.N = 6, 8  # the reference asserts false beyond 5 refined frames (IR.cpp:450)
     with pytest.raises(RuntimeError):
         oracle.refine(w)
+
+
+@pytest.mark.parametrize("use_loss", [False, True])
+def test_threaded_timing_path_agrees_with_the_serial_path(oracle, use_loss):
+    """set_threads(n > 1) exists for bench.py's cpu_baseline legs only (pairs evaluated in parallel,
+    QR by row ranges): same algorithm, different summation order -- results must agree with the
+    serial parity path to rounding, and the default must stay 1."""
+    assert oracle.get_threads() == 1
+    w = scene.make_window(12, 5, 1500, 77, span=("sliding", 8), outlier_fraction=0.1 if use_loss else 0.0)
+    opt = oracle.make_options(use_loss_function=use_loss, **FIXED10)
+    f1, s1, _ = oracle.refine(w, opt)
+    r1, j1, c1 = oracle.evaluate(w, opt)
+    oracle.set_threads(3)
+    try:
+        f3, s3, _ = oracle.refine(w, opt)
+        r3, j3, c3 = oracle.evaluate(w, opt)
+    finally:
+        oracle.set_threads(1)
+    assert np.array_equal(r1, r3) and np.array_equal(j1, j3)  # per-row values do not depend on threads
+    assert abs(c1 - c3) <= 1e-13 * abs(c1)
+    assert np.abs(refined(f1, w.M) - refined(f3, w.M)).max() < 1e-9
+    assert s1.iterations == s3.iterations and abs(s1.final_cost - s3.final_cost) <= 1e-11 * abs(s1.final_cost)
