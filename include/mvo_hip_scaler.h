@@ -58,8 +58,13 @@ int mvo_hip_scaler_upload(mvo_hip_scaler_handle h, uint64_t n_tracks, const doub
                           const double *v2);
 int mvo_hip_scaler_run(mvo_hip_scaler_handle h, const mvo_hip_scaler_input *in, double *per_track,
                        mvo_hip_scaler_result *result);
-/* seconds the device spent in the last run (HIP events), and its algorithmic bytes */
+/* seconds the device spent in the last run (HIP events), and its algorithmic bytes: 72 B of rays in,
+ * 8 B of scale out, and for more than 2048 tracks one more pass over the 8-byte scales for the median
+ * (two when the first 64 tracks are not representative of the rest) */
 int mvo_hip_scaler_last_timing(mvo_hip_scaler_handle h, double *device_seconds, uint64_t *bytes);
+/* the same for the dominant kernel of that run alone, k_scaler_tracks (80 B per track); zeros for a
+ * run of at most 2048 tracks, which is one fused launch */
+int mvo_hip_scaler_tracks_timing(mvo_hip_scaler_handle h, double *device_seconds, uint64_t *bytes);
 
 #ifdef __cplusplus
 }

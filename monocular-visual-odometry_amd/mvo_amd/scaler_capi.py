@@ -10,7 +10,8 @@ import numpy as np
 from . import capi
 
 EXPORTED_SYMBOLS = ["mvo_hip_scaler_create", "mvo_hip_scaler_destroy", "mvo_hip_scaler_scale",
-                    "mvo_hip_scaler_upload", "mvo_hip_scaler_run", "mvo_hip_scaler_last_timing"]
+                    "mvo_hip_scaler_upload", "mvo_hip_scaler_run", "mvo_hip_scaler_last_timing",
+                    "mvo_hip_scaler_tracks_timing"]
 
 
 class Input(C.Structure):
@@ -47,6 +48,7 @@ def load():
         L.mvo_hip_scaler_upload.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mvo_hip_scaler_run.argtypes = [C.c_void_p, C.POINTER(Input), C.c_void_p, C.POINTER(Result)]
         L.mvo_hip_scaler_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+        L.mvo_hip_scaler_tracks_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
         _READY = True
     return L
 
@@ -111,6 +113,12 @@ class Scaler:
     def last_timing(self):
         s, b = C.c_double(), C.c_uint64()
         self._lib.mvo_hip_scaler_last_timing(self._h, C.byref(s), C.byref(b))
+        return s.value, b.value
+
+    def tracks_timing(self):
+        """(seconds, algorithmic bytes) of k_scaler_tracks in the last run."""
+        s, b = C.c_double(), C.c_uint64()
+        self._lib.mvo_hip_scaler_tracks_timing(self._h, C.byref(s), C.byref(b))
         return s.value, b.value
 
 

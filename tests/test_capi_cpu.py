@@ -52,7 +52,7 @@ def test_scaler_header_symbols_are_exported_and_bound():
     text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "mvo_hip_scaler.h")).read(), flags=re.S)
     names = sorted(set(re.findall(r"\b(mvo_hip_scaler_[a-z_]+)\s*\(", text)))
     lib = scaler_capi.load()
-    assert len(names) == 6 and sorted(scaler_capi.EXPORTED_SYMBOLS) == names
+    assert len(names) == 7 and sorted(scaler_capi.EXPORTED_SYMBOLS) == names
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/mvo_hip_scaler.h but not exported"
     assert C.sizeof(scaler_capi.Input) == 264 and C.sizeof(scaler_capi.Result) == 32

@@ -67,6 +67,34 @@ def test_duplicates_nans_and_clamping(sc):
         assert abs(res.median - med) <= 1e-8 * abs(med) and res.clamped == cl and abs(res.scale - scl) <= 1e-8 * abs(scl)
 
 
+@pytest.mark.parametrize("n", [30_001, 200_000])
+@pytest.mark.parametrize("order", ["largest_first", "smallest_first", "two_binades"])
+def test_select_when_the_first_tracks_are_unlike_the_rest(sc, n, order):
+    """k_scaler_tracks guesses the median's top digit from the first 64 tracks to save one pass over
+    the keys.  Here the guess is wrong on purpose (the first tracks hold the extreme scales) or the
+    scales straddle two binades: the select must take its separate pass and return the same median."""
+    t = scaler_capi.synthetic_tracks(n, seed=700 + n % 13, noise_sigma=2e-2)
+    pero = so.run(t["R0"], t["R1"], t["R2"], t["u1"], t["n1"], 0.25, 2.0, t["v0"], t["v1"], t["v2"])[0]
+    key = np.where(np.isnan(pero), np.inf, pero)
+    if order == "two_binades":
+        perm = np.argsort(np.abs(key - 1.0), kind="stable")  # 0.99.., 1.00.. alternate around 1.0
+        n1 = t["n1"] / np.median(key)                        # median scale ~ 1.0: digit 1 splits it
+    else:
+        perm = np.argsort(key if order == "smallest_first" else -key, kind="stable")
+        n1 = t["n1"]
+    v0, v1, v2 = (np.ascontiguousarray(t[k][perm]) for k in ("v0", "v1", "v2"))
+    inp = scaler_capi.make_input(t["R0"], t["R1"], t["R2"], t["u1"], n1, 0.25, 2.0)
+    res, per = sc.scale(inp, v0, v1, v2)
+    pero2, med, scl, cl, _ = so.run(t["R0"], t["R1"], t["R2"], t["u1"], n1, 0.25, 2.0, v0, v1, v2)
+    if order != "two_binades":  # the premise: the first 64 scales sit in another binade than the median
+        first = np.median(pero2[:64])
+        assert not (0.5 <= first / med < 2.0) or np.floor(np.log2(first)) != np.floor(np.log2(med))
+    srt = np.sort(per)
+    k = (n - 1) // 2
+    assert res.median == ((srt[k] + srt[k + 1]) / 2 if n % 2 == 0 else srt[k])
+    assert abs(res.median - med) <= 1e-8 * abs(med) and res.clamped == cl
+
+
 def test_empty_window_and_split_form(sc):
     t = scaler_capi.synthetic_tracks(10, seed=1)
     inp = scaler_capi.make_input(t["R0"], t["R1"], t["R2"], t["u1"], t["n1"])
