@@ -4,9 +4,9 @@
 //
 //   k_epi_hypotheses  one thread per draw: A = sum of the three rows a a^T, det test, null
 //                     direction by Jacobi rotations
-//   k_epi_score       one workgroup per hypothesis, threads over the correspondences (read through
-//                     L2: 48 B each, shared by all hypotheses): pInlier, count and summed
-//                     probability, fixed-order reduction (wave shuffles, then LDS)
+//   k_epi_score_tiled workgroup per (2048 correspondences, 8 hypotheses): every loaded correspondence
+//                     is scored against 8 hypotheses held in scalar registers (pInlier, count and summed
+//                     probability), partial sums per tile; k_epi_score_reduce adds the tiles in order
 //   k_epi_final       the best direction again: inlier flags and per-workgroup partial sums of
 //                     a a^T over the inliers (calculateBaseLine over the inlier set)
 // The adaptive-iteration bookkeeping of the reference's loop is replayed on the host over the
@@ -49,36 +49,119 @@ __global__ __launch_bounds__(256) void k_epi_hypotheses(uint32_t K, const double
   hyp_b[3 * (size_t)k + 2] = b[2];
 }
 
-__global__ __launch_bounds__(256) void k_epi_score(uint32_t N, const double* __restrict__ mhi,
-                                                  const double* __restrict__ mt, const double* __restrict__ hyp_b,
-                                                  double threshold, uint32_t* __restrict__ hyp_inl,
-                                                  double* __restrict__ hyp_prob) {
-  __shared__ double wp[4];
-  __shared__ uint32_t wc[4];
-  const uint32_t k = blockIdx.x;
-  const double b[3] = {hyp_b[3 * (size_t)k], hyp_b[3 * (size_t)k + 1], hyp_b[3 * (size_t)k + 2]};
-  double prob = 0.0;
-  uint32_t cnt = 0;
-  for (uint32_t i = threadIdx.x; i < N; i += 256) {
-    const double p = mvo_epi_pinlier(mhi + 3 * (size_t)i, mt + 3 * (size_t)i, b);
-    if (p > threshold) {
-      ++cnt;
-      prob += p;
+#define EP_HB 8   // hypotheses per workgroup: every loaded correspondence is scored against all of them;
+                  // their 24 doubles stay in scalar registers for the whole kernel
+#define EP_CPT 8  // correspondences per thread
+
+// 1 / sqrt(a) for a normal, positive a: hardware estimate + two Newton steps (full double precision
+// to a couple of ulps; the reference's own two square roots and division round no better)
+__device__ __forceinline__ double ep_rsqrt(double a) {
+  double y = __builtin_amdgcn_rsq(a);
+  const double h = 0.5 * a;
+  y = y * fma(-h * y, y, 1.5);
+  y = y * fma(-h * y, y, 1.5);
+  return y;
+}
+
+// Workgroup (tile, group): 256 * EP_CPT correspondences x EP_HB hypotheses.  The three dot products
+// that do not depend on the hypothesis (m1.m2, |m1|^2, |m2|^2 of EpipolarGeometry.cpp:90-94) are
+// formed once per correspondence; per hypothesis two dot products, three fused multiply-adds and one
+// reciprocal square root of the PRODUCT of the two radicands remain.  Radicands that are not
+// comfortably positive (a ray along the baseline) take the reference's expression literally, NaN
+// and infinity included.  Partial sums per (tile, hypothesis); k_epi_score_reduce adds the tiles in
+// order, so the result does not depend on scheduling.
+__global__ __launch_bounds__(256) void k_epi_score_tiled(uint32_t N, uint32_t K, const double* __restrict__ mhi,
+                                                        const double* __restrict__ mt,
+                                                        const double* __restrict__ hyp_b, double threshold,
+                                                        double* __restrict__ part_prob,
+                                                        uint32_t* __restrict__ part_cnt) {
+  __shared__ double wp[4][EP_HB];
+  __shared__ uint32_t wc[4][EP_HB];
+  const uint32_t tile = blockIdx.x, k0 = blockIdx.y * EP_HB;
+  double prob[EP_HB];
+  uint32_t cnt[EP_HB];
+#pragma unroll
+  for (int h = 0; h < EP_HB; ++h) {
+    prob[h] = 0.0;
+    cnt[h] = 0;
+  }
+  double hb[EP_HB][3];  // wavefront-uniform
+#pragma unroll
+  for (int h = 0; h < EP_HB; ++h) {
+    const uint32_t k = min(k0 + h, K - 1);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) hb[h][j] = hyp_b[3 * (size_t)k + j];
+  }
+  for (uint32_t c = 0; c < EP_CPT; ++c) {
+    const uint32_t i = (tile * EP_CPT + c) * 256 + threadIdx.x;
+    if (i >= N) break;
+    const double* __restrict__ m1 = mhi + 3 * (size_t)i;
+    const double* __restrict__ m2 = mt + 3 * (size_t)i;
+    const double a0 = m1[0], a1 = m1[1], a2 = m1[2], c0 = m2[0], c1 = m2[1], c2 = m2[2];
+    const double m12 = a0 * c0 + a1 * c1 + a2 * c2;
+    const double n1 = a0 * a0 + a1 * a1 + a2 * a2;
+    const double n2 = c0 * c0 + c1 * c1 + c2 * c2;
+    uint32_t odd = 0;  // hypotheses whose radicands are not comfortably positive for this correspondence
+#pragma unroll
+    for (int h = 0; h < EP_HB; ++h) {  // branch-free: sixteen independent chains for the scheduler
+      const double b0 = hb[h][0], b1 = hb[h][1], b2 = hb[h][2];
+      const double m1b = a0 * b0 + a1 * b1 + a2 * b2;
+      const double m2b = c0 * b0 + c1 * b1 + c2 * b2;
+      const double x = fma(-m1b, m1b, n1), y = fma(-m2b, m2b, n2), num = fma(-m2b, m1b, m12);
+      const bool ok = fmin(x, y) > 1e-140 && fmax(x, y) < 1e140;
+      const double p = num * ep_rsqrt(x * y);
+      const bool in = ok && p > threshold;
+      cnt[h] += in ? 1u : 0u;
+      prob[h] += in ? p : 0.0;
+      odd |= ok ? 0u : (1u << h);
+    }
+    if (odd) {  // rare: the reference's expression literally, NaN and infinity included
+#pragma unroll
+      for (int h = 0; h < EP_HB; ++h)
+        if ((odd >> h) & 1u) {
+          const double p = mvo_epi_pinlier(m1, m2, hb[h]);
+          if (p > threshold) {
+            ++cnt[h];
+            prob[h] += p;
+          }
+        }
     }
   }
-  for (int o = 32; o > 0; o >>= 1) {
-    prob += __shfl_xor(prob, o, 64);
-    cnt += __shfl_xor(cnt, o, 64);
-  }
-  if ((threadIdx.x & 63) == 0) {
-    wp[threadIdx.x >> 6] = prob;
-    wc[threadIdx.x >> 6] = cnt;
+#pragma unroll
+  for (int h = 0; h < EP_HB; ++h) {
+    for (int o = 32; o > 0; o >>= 1) {
+      prob[h] += __shfl_xor(prob[h], o, 64);
+      cnt[h] += __shfl_xor(cnt[h], o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+      wp[threadIdx.x >> 6][h] = prob[h];
+      wc[threadIdx.x >> 6][h] = cnt[h];
+    }
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    hyp_prob[k] = (wp[0] + wp[1]) + (wp[2] + wp[3]);
-    hyp_inl[k] = wc[0] + wc[1] + wc[2] + wc[3];
+  if (threadIdx.x < EP_HB && k0 + threadIdx.x < K) {
+    const uint32_t h = threadIdx.x;
+    part_prob[(size_t)tile * K + k0 + h] = (wp[0][h] + wp[1][h]) + (wp[2][h] + wp[3][h]);
+    part_cnt[(size_t)tile * K + k0 + h] = wc[0][h] + wc[1][h] + wc[2][h] + wc[3][h];
   }
+}
+
+__global__ __launch_bounds__(256) void k_epi_score_reduce(uint32_t K, uint32_t tiles,
+                                                         const double* __restrict__ part_prob,
+                                                         const uint32_t* __restrict__ part_cnt,
+                                                         uint32_t* __restrict__ hyp_inl,
+                                                         double* __restrict__ hyp_prob) {
+  const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= K) return;
+  double prob = 0.0;
+  uint32_t cnt = 0;
+#pragma unroll 8
+  for (uint32_t t = 0; t < tiles; ++t) {  // loads of eight tiles in flight; the sum itself stays in tile order
+    prob += part_prob[(size_t)t * K + k];
+    cnt += part_cnt[(size_t)t * K + k];
+  }
+  hyp_prob[k] = prob;
+  hyp_inl[k] = cnt;
 }
 
 // inlier flags of direction b and per-workgroup sums of the 6 distinct entries of a a^T over them
@@ -121,7 +204,9 @@ struct mvo_hip_epipolar_context {
   hipStream_t stream = nullptr;
   hipError_t last_hip_error = hipSuccess;
   double *d_mhi = nullptr, *d_mt = nullptr, *d_hb = nullptr, *d_hp = nullptr, *d_part = nullptr;
-  uint32_t *d_samples = nullptr, *d_hi = nullptr;
+  uint32_t *d_samples = nullptr, *d_hi = nullptr, *d_part_cnt = nullptr;
+  double* d_part_prob = nullptr;
+  size_t cap_part = 0;
   uint8_t* d_flags = nullptr;
   size_t cap_n = 0, cap_k = 0;
   hipEvent_t ev[2] = {};
@@ -184,6 +269,13 @@ int ep_score(mvo_hip_epipolar_context* h, uint32_t n, const double* mhi, const d
     EP_TRY(regrow(h->d_hi, want));
     h->cap_k = want;
   }
+  const uint32_t tiles = (n + 256 * EP_CPT - 1) / (256 * EP_CPT);
+  if ((size_t)tiles * K > h->cap_part) {
+    const size_t want = (size_t)tiles * K + 1024;
+    EP_TRY(regrow(h->d_part_prob, want));
+    EP_TRY(regrow(h->d_part_cnt, want));
+    h->cap_part = want;
+  }
   hipStream_t s = h->stream;
   EP_TRY(hipMemcpyAsync(h->d_mhi, mhi, sizeof(double) * 3 * n, hipMemcpyHostToDevice, s));
   EP_TRY(hipMemcpyAsync(h->d_mt, mt, sizeof(double) * 3 * n, hipMemcpyHostToDevice, s));
@@ -192,8 +284,10 @@ int ep_score(mvo_hip_epipolar_context* h, uint32_t n, const double* mhi, const d
   if (K) {
     hipLaunchKernelGGL(k_epi_hypotheses, dim3((K + 255) / 256), dim3(256), 0, s, K, h->d_mhi, h->d_mt, h->d_samples,
                        h->d_hb);
-    hipLaunchKernelGGL(k_epi_score, dim3(K), dim3(256), 0, s, n, h->d_mhi, h->d_mt, h->d_hb, threshold, h->d_hi,
-                       h->d_hp);
+    hipLaunchKernelGGL(k_epi_score_tiled, dim3(tiles, (K + EP_HB - 1) / EP_HB), dim3(256), 0, s, n, K, h->d_mhi, h->d_mt,
+                       h->d_hb, threshold, h->d_part_prob, h->d_part_cnt);
+    hipLaunchKernelGGL(k_epi_score_reduce, dim3((K + 255) / 256), dim3(256), 0, s, K, tiles, h->d_part_prob,
+                       h->d_part_cnt, h->d_hi, h->d_hp);
     EP_TRY(hipGetLastError());
   }
   EP_TRY(hipEventRecord(h->ev[1], s));
@@ -230,7 +324,8 @@ void mvo_hip_epipolar_destroy(mvo_hip_epipolar_handle h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  void* bufs[] = {h->d_mhi, h->d_mt, h->d_hb, h->d_hp, h->d_part, h->d_samples, h->d_hi, h->d_flags};
+  void* bufs[] = {h->d_mhi, h->d_mt, h->d_hb, h->d_hp, h->d_part, h->d_samples, h->d_hi, h->d_flags,
+                  h->d_part_prob, h->d_part_cnt};
   for (void* p : bufs)
     if (p) (void)hipFree(p);
   for (auto& e : h->ev)
