@@ -23,6 +23,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -204,7 +205,8 @@ __global__ __launch_bounds__(BA_SCHUR_THREADS) void k_ba_schur(BaParams prm, con
                                                               const double2* __restrict__ obs_uv,
                                                               const uint32_t* __restrict__ wg_lm,
                                                               double* __restrict__ partS,
-                                                              double* __restrict__ partV) {
+                                                              double* __restrict__ partV,
+                                                              double* __restrict__ lmC) {
   extern __shared__ double lds_poses[];  // 12 N doubles when POSES_IN_LDS
   __shared__ double stage[BA_SCHUR_WAVES][BA_MAXF * BA_STAGE];
   __shared__ SchurHdr hdr[BA_SCHUR_WAVES];
@@ -322,12 +324,25 @@ __global__ __launch_bounds__(BA_SCHUR_THREADS) void k_ba_schur(BaParams prm, con
       wave_reduce8_all(a8, lane, tot);
       const double gl2 = ba_wave_sum(a9);
       gmax_acc = fmax(gmax_acc, fmax(fabs(tot[6]), fmax(fabs(tot[7]), fabs(gl2))));
+      double C[6] = {tot[0], tot[1], tot[2], tot[3], tot[4], tot[5]}, Ci[6];
+      const double D0 = ba_clamp_diag(C[0]) * inv_radius, D1 = ba_clamp_diag(C[3]) * inv_radius,
+                   D2 = ba_clamp_diag(C[5]) * inv_radius;
+      C[0] += D0;
+      C[3] += D1;
+      C[5] += D2;
+      ba_inv3(C, Ci);
+      if (lane == 0) {  // (C + D)^-1 | g_l | D: k_ba_step's back substitution reads them instead of
+        double* __restrict__ o = lmC + 12 * (size_t)lm;  // evaluating every observation once more
+#pragma unroll
+        for (int q = 0; q < 6; ++q) o[q] = Ci[q];
+        o[6] = tot[6];
+        o[7] = tot[7];
+        o[8] = gl2;
+        o[9] = D0;
+        o[10] = D1;
+        o[11] = D2;
+      }
       if (Tf) {
-        double C[6] = {tot[0], tot[1], tot[2], tot[3], tot[4], tot[5]}, Ci[6];
-        C[0] += ba_clamp_diag(C[0]) * inv_radius;
-        C[3] += ba_clamp_diag(C[3]) * inv_radius;
-        C[5] += ba_clamp_diag(C[5]) * inv_radius;
-        ba_inv3(C, Ci);
         __builtin_amdgcn_wave_barrier();
         if ((uint32_t)lane < Tf) {  // Y = E C^-1
           double* sg = my + lane * BA_STAGE;
@@ -744,6 +759,8 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_step(BaParams prm, const BaSt
                                                        const double* __restrict__ poses2, double* __restrict__ X2,
                                                        const double* __restrict__ delta_c,
                                                        const uint32_t* __restrict__ lm_off,
+                                                       const uint32_t* __restrict__ lm_nfree,
+                                                       const double* __restrict__ lmC,
                                                        const uint32_t* __restrict__ obs_frame,
                                                        const double2* __restrict__ obs_uv,
                                                        const uint32_t* __restrict__ wg_lm,
@@ -753,8 +770,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_step(BaParams prm, const BaSt
   if (mode == 1 && st->step_bad) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int cur = st->cur, M = prm.M;
-  const double inv_radius = 1.0 / st->radius;
+  const int cur = st->cur;
   const double* __restrict__ poses = poses2 + (size_t)cur * 12 * prm.N;
   const double* __restrict__ posesc = poses2 + (size_t)(1 - cur) * 12 * prm.N;
   const double* __restrict__ Xs = X2 + (size_t)cur * 3 * prm.L;
@@ -766,52 +782,36 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_step(BaParams prm, const BaSt
     const double X[3] = {Xs[3 * lm], Xs[3 * lm + 1], Xs[3 * lm + 2]};
     double Xn[3] = {X[0], X[1], X[2]};
     if (mode == 1) {
-      double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, acc2[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // C(6) gl(2) | gl[2] t(3)
-      for (uint32_t base = 0; base < T; base += 64) {
-        const uint32_t t = base + lane;
-        if (t < T) {
-          const uint32_t word = obs_frame[o0 + t], f = word & 0xFFFFu;
-          const double2 uv = obs_uv[o0 + t];
-          BaObs e;
-          ba_obs_eval(poses + 12 * f, X, uv.x, uv.y, prm.loss, prm.loss_scale, e);
-          const double w = e.w;
-          acc[0] += w * (e.jx[0] * e.jx[0] + e.jx[3] * e.jx[3]);
-          acc[1] += w * (e.jx[0] * e.jx[1] + e.jx[3] * e.jx[4]);
-          acc[2] += w * (e.jx[0] * e.jx[2] + e.jx[3] * e.jx[5]);
-          acc[3] += w * (e.jx[1] * e.jx[1] + e.jx[4] * e.jx[4]);
-          acc[4] += w * (e.jx[1] * e.jx[2] + e.jx[4] * e.jx[5]);
-          acc[5] += w * (e.jx[2] * e.jx[2] + e.jx[5] * e.jx[5]);
-          acc[6] += w * (e.jx[0] * e.r0 + e.jx[3] * e.r1);
-          acc[7] += w * (e.jx[1] * e.r0 + e.jx[4] * e.r1);
-          acc2[0] += w * (e.jx[2] * e.r0 + e.jx[5] * e.r1);
-          if ((int)f < M) {  // E^T dc = w J_X^T (J_c dc)
-            double jd0 = 0.0, jd1 = 0.0;
+      // E^T dc over the landmark's observations in FREE frames (they come first, at most 28);
+      // (C + D)^-1, g_l and D are k_ba_schur's, computed at this point with this radius
+      const uint32_t Tf = lm_nfree[lm];
+      double e0 = 0.0, e1 = 0.0, e2 = 0.0;
+      if ((uint32_t)lane < Tf) {
+        const uint32_t f = obs_frame[o0 + lane] & 0xFFFFu;
+        const double2 uv = obs_uv[o0 + lane];
+        BaObs e;
+        ba_obs_eval(poses + 12 * f, X, uv.x, uv.y, prm.loss, prm.loss_scale, e);
+        double jd0 = 0.0, jd1 = 0.0;  // E^T dc = w J_X^T (J_c dc)
 #pragma unroll
-            for (int p = 0; p < 6; ++p) {
-              const double dcp = delta_c[6 * f + p];
-              jd0 += e.jc[p] * dcp;
-              jd1 += e.jc[6 + p] * dcp;
-            }
-            acc2[1] += w * (e.jx[0] * jd0 + e.jx[3] * jd1);
-            acc2[2] += w * (e.jx[1] * jd0 + e.jx[4] * jd1);
-            acc2[3] += w * (e.jx[2] * jd0 + e.jx[5] * jd1);
-          }
+        for (int p = 0; p < 6; ++p) {
+          const double dcp = delta_c[6 * f + p];
+          jd0 += e.jc[p] * dcp;
+          jd1 += e.jc[6 + p] * dcp;
         }
+        e0 = e.w * (e.jx[0] * jd0 + e.jx[3] * jd1);
+        e1 = e.w * (e.jx[1] * jd0 + e.jx[4] * jd1);
+        e2 = e.w * (e.jx[2] * jd0 + e.jx[5] * jd1);
       }
-      double tot[8], tot2[8];
-      wave_reduce8_all(acc, lane, tot);
-      wave_reduce8_all(acc2, lane, tot2);
-      const double gl[3] = {tot[6], tot[7], tot2[0]};
-      double C[6] = {tot[0], tot[1], tot[2], tot[3], tot[4], tot[5]}, Ci[6];
-      const double D[3] = {ba_clamp_diag(C[0]) * inv_radius, ba_clamp_diag(C[3]) * inv_radius,
-                           ba_clamp_diag(C[5]) * inv_radius};
-      C[0] += D[0];
-      C[3] += D[1];
-      C[5] += D[2];
-      ba_inv3(C, Ci);
-      const double t0 = gl[0] + tot2[1], t1 = gl[1] + tot2[2], t2 = gl[2] + tot2[3];
-      const double dl[3] = {-(Ci[0] * t0 + Ci[1] * t1 + Ci[2] * t2), -(Ci[1] * t0 + Ci[3] * t1 + Ci[4] * t2),
-                            -(Ci[2] * t0 + Ci[4] * t1 + Ci[5] * t2)};
+      if (Tf) {
+        e0 = ba_wave_sum(e0);
+        e1 = ba_wave_sum(e1);
+        e2 = ba_wave_sum(e2);
+      }
+      const double* __restrict__ c = lmC + 12 * (size_t)lm;
+      const double gl[3] = {c[6], c[7], c[8]}, D[3] = {c[9], c[10], c[11]};
+      const double t0 = gl[0] + e0, t1 = gl[1] + e1, t2 = gl[2] + e2;
+      const double dl[3] = {-(c[0] * t0 + c[1] * t1 + c[2] * t2), -(c[1] * t0 + c[3] * t1 + c[4] * t2),
+                            -(c[2] * t0 + c[4] * t1 + c[5] * t2)};
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
         Xn[q] = X[q] + dl[q];
@@ -838,6 +838,150 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_step(BaParams prm, const BaSt
     }
   }
   cost_acc = ba_wave_sum(cost_acc);
+  if (lane == 0) {
+    red[wave] = cost_acc;
+    red[BA_WAVES + wave] = mcc_acc;
+    red[2 * BA_WAVES + wave] = s2_acc;
+    red[3 * BA_WAVES + wave] = xn2_acc;
+  }
+  __syncthreads();
+  if (tid < 4) partT[(size_t)g * 4 + tid] = (red[4 * tid] + red[4 * tid + 1]) + (red[4 * tid + 2] + red[4 * tid + 3]);
+}
+
+// The same for SHORT tracks: a group of G = 8 or 16 lanes per landmark instead of a whole wavefront,
+// 256 / G landmarks in flight per workgroup.  With some tens of observations per landmark the
+// per-landmark work of the wavefront version (two 64-lane reductions, the 3 x 3 inverse) outweighs
+// the per-observation work; here the reduction is 3 or 4 DPP steps shared by all groups of the
+// wavefront.  Same sums per landmark; the order of the additions differs (fixed, reproducible).
+template <int G>
+__device__ __forceinline__ double ba_group_sum(double v) {
+  v += dpp_mov_f64<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov_f64<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov_f64<0x141>(v);  // row_half_mirror: the two quads of 8 lanes
+  if (G >= 16) v += dpp_mov_f64<0x128>(v);  // row_ror:8
+  return v;
+}
+
+template <int G, bool POSES_IN_LDS>
+__global__ __launch_bounds__(BA_THREADS) void k_ba_step_g(BaParams prm, const BaState* __restrict__ st, int mode,
+                                                         const double* __restrict__ poses2, double* __restrict__ X2,
+                                                         const double* __restrict__ delta_c,
+                                                         const uint32_t* __restrict__ lm_off,
+                                                         const uint32_t* __restrict__ lm_nfree,
+                                                         const double* __restrict__ lmC,
+                                                         const uint32_t* __restrict__ obs_frame,
+                                                         const double2* __restrict__ obs_uv,
+                                                         const uint32_t* __restrict__ wg_lm,
+                                                         double* __restrict__ partT) {
+  constexpr uint32_t GROUPS = BA_THREADS / G;
+  extern __shared__ double lds_poses2[];  // both pose sets (24 N doubles) when POSES_IN_LDS
+  __shared__ double red[4 * BA_WAVES];
+  if (st->status != 0) return;
+  if (mode == 1 && st->step_bad) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t sub = tid & (G - 1), grp = tid / G;
+  const int cur = st->cur;
+  if (POSES_IN_LDS) {  // the pose of an observation's frame is then one LDS read behind the frame index
+    for (uint32_t i = tid; i < 24 * (uint32_t)prm.N; i += BA_THREADS) lds_poses2[i] = poses2[i];
+    __syncthreads();
+  }
+  const double* pbase = POSES_IN_LDS ? lds_poses2 : poses2;
+  const double* poses = pbase + (size_t)cur * 12 * prm.N;
+  const double* posesc = pbase + (size_t)(1 - cur) * 12 * prm.N;
+  const double* __restrict__ Xs = X2 + (size_t)cur * 3 * prm.L;
+  double* __restrict__ Xc = X2 + (size_t)(1 - cur) * 3 * prm.L;
+  const uint32_t g = blockIdx.x, lm_end = wg_lm[g + 1];
+  double cost_acc = 0.0, mcc_acc = 0.0, s2_acc = 0.0, xn2_acc = 0.0;
+  for (uint32_t lm0 = wg_lm[g]; lm0 < lm_end; lm0 += GROUPS) {  // workgroup-uniform
+    const uint32_t lm = lm0 + grp;
+    const bool live = lm < lm_end;
+    uint32_t o0 = 0, T = 0;
+    double X[3] = {0.0, 0.0, 1.0};
+    if (live) {
+      o0 = lm_off[lm];
+      T = lm_off[lm + 1] - o0;
+      X[0] = Xs[3 * lm];
+      X[1] = Xs[3 * lm + 1];
+      X[2] = Xs[3 * lm + 2];
+    }
+    double Xn[3] = {X[0], X[1], X[2]};
+    if (mode == 1) {
+      // E^T dc over the landmark's observations in FREE frames (they come first, at most 28);
+      // (C + D)^-1, g_l and D are k_ba_schur's, computed at this point with this radius
+      const uint32_t Tf = live ? lm_nfree[lm] : 0u;
+      double e0 = 0.0, e1 = 0.0, e2 = 0.0;
+      for (uint32_t t = sub; __ballot(t < Tf) != 0ull; t += G) {  // wavefront-uniform trip count
+        if (t < Tf) {
+          const uint32_t f = obs_frame[o0 + t] & 0xFFFFu;
+          const double2 uv = obs_uv[o0 + t];
+          BaObs e;
+          ba_obs_eval(poses + 12 * f, X, uv.x, uv.y, prm.loss, prm.loss_scale, e);
+          double jd0 = 0.0, jd1 = 0.0;  // E^T dc = w J_X^T (J_c dc)
+#pragma unroll
+          for (int p = 0; p < 6; ++p) {
+            const double dcp = delta_c[6 * f + p];
+            jd0 += e.jc[p] * dcp;
+            jd1 += e.jc[6 + p] * dcp;
+          }
+          e0 += e.w * (e.jx[0] * jd0 + e.jx[3] * jd1);
+          e1 += e.w * (e.jx[1] * jd0 + e.jx[4] * jd1);
+          e2 += e.w * (e.jx[2] * jd0 + e.jx[5] * jd1);
+        }
+      }
+      if (__ballot(Tf != 0) != 0ull) {
+        e0 = ba_group_sum<G>(e0);
+        e1 = ba_group_sum<G>(e1);
+        e2 = ba_group_sum<G>(e2);
+      }
+      if (live) {  // every lane of the group holds the landmark's totals
+        const double* __restrict__ c = lmC + 12 * (size_t)lm;
+        const double gl[3] = {c[6], c[7], c[8]}, D[3] = {c[9], c[10], c[11]};
+        const double t0 = gl[0] + e0, t1 = gl[1] + e1, t2 = gl[2] + e2;
+        const double dl[3] = {-(c[0] * t0 + c[1] * t1 + c[2] * t2), -(c[1] * t0 + c[3] * t1 + c[4] * t2),
+                              -(c[2] * t0 + c[4] * t1 + c[5] * t2)};
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          Xn[q] = X[q] + dl[q];
+          if (sub == 0) {  // once per landmark
+            mcc_acc += dl[q] * (D[q] * dl[q] - gl[q]);
+            s2_acc += dl[q] * dl[q];
+            xn2_acc += X[q] * X[q];
+          }
+        }
+        if (sub < 3) Xc[3 * lm + sub] = sub == 0 ? Xn[0] : (sub == 1 ? Xn[1] : Xn[2]);
+      }
+    }
+    const double* pp = mode == 1 ? posesc : poses;
+    {
+      uint32_t word_n = 0;
+      double2 uv_n = make_double2(0.0, 0.0);
+      if (sub < T) {
+        word_n = obs_frame[o0 + sub];
+        uv_n = obs_uv[o0 + sub];
+      }
+      for (uint32_t t = sub; __ballot(t < T) != 0ull; t += G) {
+        const uint32_t f = word_n & 0xFFFFu;
+        const double2 uv = uv_n;
+        if (t + G < T) {
+          word_n = obs_frame[o0 + t + G];
+          uv_n = obs_uv[o0 + t + G];
+        }
+        if (t < T) {
+          double a, b, c;
+          ba_project(pp + 12 * f, Xn, a, b, c);
+          const double ic = ba_rcp(c);
+          const double r0 = a * ic - uv.x, r1 = b * ic - uv.y;
+          double rho, w;
+          ba_loss(prm.loss, prm.loss_scale, r0 * r0 + r1 * r1, rho, w);
+          cost_acc += 0.5 * rho;
+        }
+      }
+    }
+  }
+  cost_acc = ba_wave_sum(cost_acc);
+  mcc_acc = ba_wave_sum(mcc_acc);
+  s2_acc = ba_wave_sum(s2_acc);
+  xn2_acc = ba_wave_sum(xn2_acc);
   if (lane == 0) {
     red[wave] = cost_acc;
     red[BA_WAVES + wave] = mcc_acc;
@@ -1022,10 +1166,11 @@ struct mvo_hip_ba_context {
   hipStream_t stream = nullptr;
   hipError_t last_hip_error = hipSuccess;
   Buf d_poses, d_X, d_lm_off, d_lm_nfree, d_obs_frame, d_obs_uv, d_obs_lm, d_obs_src, d_wg_lm, d_wg_lm_step, d_partS, d_partV,
-      d_redS, d_redV, d_partT, d_delta, d_state, d_trace, d_res, d_sums4;
+      d_redS, d_redV, d_partT, d_delta, d_state, d_trace, d_res, d_sums4, d_lmC;
   bool uploaded = false;
   BaParams prm{};
   uint64_t n_obs = 0;
+  int step_group = 64;  // lanes per landmark in k_ba_step: 8 / 16 for short tracks, a wavefront otherwise
   std::vector<mvo_hip_ba_pose> h_poses0;  // the uploaded point (solve restarts from it)
   std::vector<double> h_X0;
   std::vector<mvo_hip_ba_pose> h_poses;   // result of the last solve
@@ -1127,7 +1272,12 @@ int ba_upload(mvo_hip_ba_context* h, const mvo_hip_ba_pose* poses, uint32_t M, u
     return w;
   };
   const uint32_t n_wg = (uint32_t)std::min<uint64_t>((uint64_t)n_cu, std::max<uint64_t>(1, (L + 2 * BA_SCHUR_WAVES - 1) / (2 * BA_SCHUR_WAVES)));
-  const uint32_t n_wg_step = (uint32_t)std::min<uint64_t>(8ull * n_cu, std::max<uint64_t>(1, (L + 2 * BA_WAVES - 1) / (2 * BA_WAVES)));
+  // lanes per landmark in k_ba_step by the mean track length; workgroups of at least two rounds of landmarks
+  const uint64_t mean_T = L ? n_obs / L : 0;
+  h->step_group = mean_T <= 96 ? 8 : (mean_T <= 224 ? 16 : 64);
+  if (const char* e = std::getenv("MVO_BA_STEP_GROUP")) h->step_group = std::atoi(e);  // tuning knob: 8 | 16 | 64
+  const uint32_t per_round = h->step_group == 64 ? BA_WAVES : BA_THREADS / h->step_group;
+  const uint32_t n_wg_step = (uint32_t)std::min<uint64_t>(8ull * n_cu, std::max<uint64_t>(1, (L + 2 * per_round - 1) / (2 * per_round)));
   const std::vector<uint32_t> wg_lm = partition(n_wg), wg_lm_step = partition(n_wg_step);
 
   BaParams& prm = h->prm;
@@ -1165,6 +1315,7 @@ int ba_upload(mvo_hip_ba_context* h, const mvo_hip_ba_pose* poses, uint32_t M, u
   BA_TRY(h->d_redS.reserve(sizeof(double) * nS));
   BA_TRY(h->d_redV.reserve(sizeof(double) * nV));
   BA_TRY(h->d_partT.reserve(sizeof(double) * 4 * n_wg_step));
+  BA_TRY(h->d_lmC.reserve(sizeof(double) * 12 * (size_t)L));
   BA_TRY(h->d_delta.reserve(sizeof(double) * 6 * M));
   BA_TRY(h->d_state.reserve(sizeof(BaState)));
   hipStream_t s = h->stream;
@@ -1218,7 +1369,7 @@ hipError_t launch_schur(mvo_hip_ba_context* h, double radius_override) {
                      h->d_state.as<BaState>(), radius_override, h->d_poses.as<double>(), h->d_X.as<double>(),
                      h->d_lm_off.as<uint32_t>(), h->d_lm_nfree.as<uint32_t>(), h->d_obs_frame.as<uint32_t>(),
                      h->d_obs_uv.as<double2>(), h->d_wg_lm.as<uint32_t>(), h->d_partS.as<double>(),
-                     h->d_partV.as<double>());
+                     h->d_partV.as<double>(), h->d_lmC.as<double>());
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   const uint32_t n = h->prm.n_blk * 36 + 18 * h->prm.M + 2;
@@ -1229,10 +1380,16 @@ hipError_t launch_schur(mvo_hip_ba_context* h, double radius_override) {
 }
 
 hipError_t launch_step_only(mvo_hip_ba_context* h, int mode) {
-  hipLaunchKernelGGL(k_ba_step, dim3(h->prm.n_wg_step), dim3(BA_THREADS), 0, h->stream, h->prm,
+  const size_t pose_bytes = sizeof(double) * 24 * h->prm.N;
+  const bool in_lds = h->step_group != 64 && pose_bytes <= 48 * 1024;
+  auto kern = &k_ba_step;
+  if (h->step_group == 8) kern = in_lds ? &k_ba_step_g<8, true> : &k_ba_step_g<8, false>;
+  else if (h->step_group == 16) kern = in_lds ? &k_ba_step_g<16, true> : &k_ba_step_g<16, false>;
+  hipLaunchKernelGGL(kern, dim3(h->prm.n_wg_step), dim3(BA_THREADS), in_lds ? pose_bytes : 0, h->stream, h->prm,
                      h->d_state.as<BaState>(), mode, h->d_poses.as<double>(), h->d_X.as<double>(),
-                     h->d_delta.as<double>(), h->d_lm_off.as<uint32_t>(), h->d_obs_frame.as<uint32_t>(),
-                     h->d_obs_uv.as<double2>(), h->d_wg_lm_step.as<uint32_t>(), h->d_partT.as<double>());
+                     h->d_delta.as<double>(), h->d_lm_off.as<uint32_t>(), h->d_lm_nfree.as<uint32_t>(),
+                     h->d_lmC.as<double>(), h->d_obs_frame.as<uint32_t>(), h->d_obs_uv.as<double2>(),
+                     h->d_wg_lm_step.as<uint32_t>(), h->d_partT.as<double>());
   return hipGetLastError();
 }
 
@@ -1432,7 +1589,7 @@ void mvo_hip_ba_destroy(mvo_hip_ba_handle h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   Buf* bufs[] = {&h->d_poses, &h->d_X, &h->d_lm_off, &h->d_lm_nfree, &h->d_obs_frame, &h->d_obs_uv, &h->d_obs_lm,
-                 &h->d_obs_src, &h->d_wg_lm, &h->d_wg_lm_step, &h->d_partS, &h->d_partV, &h->d_redS, &h->d_redV, &h->d_partT,
+                 &h->d_obs_src, &h->d_wg_lm, &h->d_wg_lm_step, &h->d_partS, &h->d_partV, &h->d_redS, &h->d_redV, &h->d_partT, &h->d_lmC,
                  &h->d_delta, &h->d_state, &h->d_trace, &h->d_res, &h->d_sums4};
   for (Buf* b : bufs) b->release();
   if (h->events_ready)
