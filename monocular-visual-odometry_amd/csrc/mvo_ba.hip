@@ -43,7 +43,7 @@
 struct BaParams {
   double ftol, gtol, ptol, loss_scale, initial_radius;
   int32_t max_it, loss, M, N;
-  uint32_t L, n_blk, n_wg, n_wg_step, trace_cap, pad;
+  uint32_t L, n_blk, n_wg, n_wg_step, trace_cap, n_wg_fixed;  // n_wg_fixed: workgroups of k_ba_fixed (0: not launched)
 };
 
 struct BaState {
@@ -189,7 +189,7 @@ struct SchurHdr {  // per staged landmark
 };
 
 struct LmPre {  // one landmark's header and first 64 observations, fetched one group ahead
-  uint32_t o0, T, Tf, word;
+  uint32_t lm, o0, T, Tf, word;
   double X[3];
   double2 uv;
 };
@@ -204,6 +204,7 @@ __global__ __launch_bounds__(BA_SCHUR_THREADS) void k_ba_schur(BaParams prm, con
                                                               const uint32_t* __restrict__ obs_frame,
                                                               const double2* __restrict__ obs_uv,
                                                               const uint32_t* __restrict__ wg_lm,
+                                                              const uint32_t* __restrict__ lm_list,
                                                               double* __restrict__ partS,
                                                               double* __restrict__ partV,
                                                               double* __restrict__ lmC) {
@@ -243,9 +244,13 @@ __global__ __launch_bounds__(BA_SCHUR_THREADS) void k_ba_schur(BaParams prm, con
   const uint32_t lm_begin = wg_lm[g], lm_end = wg_lm[g + 1];
   // software pipeline over the landmarks of this wavefront: the header of landmark i+2 and the
   // observations of landmark i+1 are in flight while landmark i is processed
-  auto fetch_hdr = [&](uint32_t lm, LmPre& p) {
-    p.o0 = p.T = p.Tf = 0;
-    if (lm < lm_end) {
+  // wg_lm cuts POSITIONS of lm_list (the landmarks with an observation in a free frame; those
+  // without go through k_ba_fixed) or, without a list, landmark indices
+  auto fetch_hdr = [&](uint32_t pos, LmPre& p) {
+    p.lm = p.o0 = p.T = p.Tf = 0;
+    if (pos < lm_end) {
+      const uint32_t lm = lm_list ? lm_list[pos] : pos;
+      p.lm = lm;
       p.o0 = lm_off[lm];
       p.T = lm_off[lm + 1] - p.o0;
       p.Tf = lm_nfree[lm];
@@ -269,13 +274,13 @@ __global__ __launch_bounds__(BA_SCHUR_THREADS) void k_ba_schur(BaParams prm, con
   fetch_hdr(lm_begin + wave + BA_SCHUR_WAVES, pb);
   for (uint32_t lm0 = lm_begin; lm0 < lm_end; lm0 += BA_SCHUR_WAVES) {
     // ---------------- phase A ----------------
-    const uint32_t lm = lm0 + wave;
+    const uint32_t pos = lm0 + wave;
     const LmPre pc = pa;
     fetch_obs(pb);
     pa = pb;
-    fetch_hdr(lm + 2 * BA_SCHUR_WAVES, pb);
-    const uint32_t Tf = pc.Tf;
-    if (lm < lm_end) {
+    fetch_hdr(pos + 2 * BA_SCHUR_WAVES, pb);
+    const uint32_t Tf = pc.Tf, lm = pc.lm;
+    if (pos < lm_end) {
       const uint32_t o0 = pc.o0, T = pc.T;
       const double X[3] = {pc.X[0], pc.X[1], pc.X[2]};
       if (Tf && lane < BA_MAXF + 4) hdr[wave].slot_of[lane] = -1;
@@ -446,12 +451,166 @@ __global__ __launch_bounds__(BA_SCHUR_THREADS) void k_ba_schur(BaParams prm, con
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_ba_fixed: the landmarks WITHOUT an observation in a free frame.  They add nothing to the reduced
+// camera system -- only their cost, their gradient (for the gradient-max test) and their own 3 x 3
+// system (C + D)^-1, g_l, D for k_ba_step -- so they do not need k_ba_schur's one-workgroup-per-CU
+// residency: lane groups of G per landmark, thousands of workgroups.  partF[g] = cost | gmax.
+// ---------------------------------------------------------------------------------------------
+template <int G>
+__device__ __forceinline__ double ba_group_sum_any(double v) {
+  if (G == 64) return ba_wave_sum(v);
+  v += dpp_mov_f64<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov_f64<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov_f64<0x141>(v);  // row_half_mirror: the two quads of 8 lanes
+  if (G >= 16) v += dpp_mov_f64<0x128>(v);  // row_ror:8
+  return v;
+}
+
+template <int G, bool POSES_IN_LDS>
+__global__ __launch_bounds__(BA_THREADS) void k_ba_fixed(BaParams prm, const BaState* __restrict__ st,
+                                                        double radius_override, const double* __restrict__ poses2,
+                                                        const double* __restrict__ X2,
+                                                        const uint32_t* __restrict__ lm_off,
+                                                        const uint32_t* __restrict__ obs_frame,
+                                                        const double2* __restrict__ obs_uv,
+                                                        const uint32_t* __restrict__ wg_pos,
+                                                        const uint32_t* __restrict__ lm_list,
+                                                        double* __restrict__ lmC, double* __restrict__ partF) {
+  constexpr uint32_t GROUPS = BA_THREADS / G;
+  extern __shared__ double lds_poses_f[];  // the current pose set (12 N doubles) when POSES_IN_LDS
+  __shared__ double red[2 * BA_WAVES];
+  if (st->status != 0) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t sub = tid & (G - 1), grp = tid / G;
+  const int cur = st->cur;
+  const double radius = radius_override > 0.0 ? radius_override : st->radius;
+  const double inv_radius = 1.0 / radius;
+  const double* __restrict__ poses_g = poses2 + (size_t)cur * 12 * prm.N;
+  if (POSES_IN_LDS) {
+    for (uint32_t i = tid; i < 12 * (uint32_t)prm.N; i += BA_THREADS) lds_poses_f[i] = poses_g[i];
+    __syncthreads();
+  }
+  const double* poses = POSES_IN_LDS ? lds_poses_f : poses_g;
+  const double* __restrict__ Xs = X2 + (size_t)cur * 3 * prm.L;
+  const uint32_t g = blockIdx.x, pos_end = wg_pos[g + 1];
+  double cost_acc = 0.0, gmax_acc = 0.0;
+  for (uint32_t pos0 = wg_pos[g]; pos0 < pos_end; pos0 += GROUPS) {  // workgroup-uniform
+    const uint32_t pos = pos0 + grp;
+    const bool live = pos < pos_end;
+    uint32_t lm = 0, o0 = 0, T = 0;
+    double X[3] = {0.0, 0.0, 1.0};
+    if (live) {
+      lm = lm_list[pos];
+      o0 = lm_off[lm];
+      T = lm_off[lm + 1] - o0;
+      X[0] = Xs[3 * lm];
+      X[1] = Xs[3 * lm + 1];
+      X[2] = Xs[3 * lm + 2];
+    }
+    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // C(6) gl(3)
+    uint32_t word_n = 0;  // the next round's observation is in flight while this one is evaluated
+    double2 uv_n = make_double2(0.0, 0.0);
+    if (sub < T) {
+      word_n = obs_frame[o0 + sub];
+      uv_n = obs_uv[o0 + sub];
+    }
+    for (uint32_t t = sub; __ballot(t < T) != 0ull; t += G) {  // wavefront-uniform trip count
+      const uint32_t f = word_n & 0xFFFFu;
+      const double2 uv = uv_n;
+      if (t + G < T) {
+        word_n = obs_frame[o0 + t + G];
+        uv_n = obs_uv[o0 + t + G];
+      }
+      if (t < T) {
+        BaObs e;
+        ba_obs_eval(poses + 12 * f, X, uv.x, uv.y, prm.loss, prm.loss_scale, e);
+        cost_acc += 0.5 * e.rho;
+        const double w = e.w;
+        acc[0] += w * (e.jx[0] * e.jx[0] + e.jx[3] * e.jx[3]);
+        acc[1] += w * (e.jx[0] * e.jx[1] + e.jx[3] * e.jx[4]);
+        acc[2] += w * (e.jx[0] * e.jx[2] + e.jx[3] * e.jx[5]);
+        acc[3] += w * (e.jx[1] * e.jx[1] + e.jx[4] * e.jx[4]);
+        acc[4] += w * (e.jx[1] * e.jx[2] + e.jx[4] * e.jx[5]);
+        acc[5] += w * (e.jx[2] * e.jx[2] + e.jx[5] * e.jx[5]);
+        acc[6] += w * (e.jx[0] * e.r0 + e.jx[3] * e.r1);
+        acc[7] += w * (e.jx[1] * e.r0 + e.jx[4] * e.r1);
+        acc[8] += w * (e.jx[2] * e.r0 + e.jx[5] * e.r1);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 9; ++q) acc[q] = ba_group_sum_any<G>(acc[q]);
+    if (live) {
+      double C[6] = {acc[0], acc[1], acc[2], acc[3], acc[4], acc[5]}, Ci[6];
+      const double D0 = ba_clamp_diag(C[0]) * inv_radius, D1 = ba_clamp_diag(C[3]) * inv_radius,
+                   D2 = ba_clamp_diag(C[5]) * inv_radius;
+      C[0] += D0;
+      C[3] += D1;
+      C[5] += D2;
+      ba_inv3(C, Ci);
+      gmax_acc = fmax(gmax_acc, fmax(fabs(acc[6]), fmax(fabs(acc[7]), fabs(acc[8]))));
+      if (sub == 0) {
+        double* __restrict__ o = lmC + 12 * (size_t)lm;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) o[q] = Ci[q];
+        o[6] = acc[6];
+        o[7] = acc[7];
+        o[8] = acc[8];
+        o[9] = D0;
+        o[10] = D1;
+        o[11] = D2;
+      }
+    }
+  }
+  cost_acc = ba_wave_sum(cost_acc);
+  gmax_acc = ba_wave_max(gmax_acc);
+  if (lane == 0) {
+    red[wave] = cost_acc;
+    red[BA_WAVES + wave] = gmax_acc;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    partF[2 * (size_t)g] = (red[0] + red[1]) + (red[2] + red[3]);
+    partF[2 * (size_t)g + 1] = fmax(fmax(red[BA_WAVES], red[BA_WAVES + 1]), fmax(red[BA_WAVES + 2], red[BA_WAVES + 3]));
+  }
+}
+
+// one workgroup: k_ba_fixed's partials added up in a fixed order -> partF[2 n | 2 n + 1].  (A "last
+// workgroup adds up" scheme inside k_ba_fixed needs a device-scope fence per workgroup, which on
+// this chip writes the XCD's L2 back: it doubled the kernel's time.)
+__global__ __launch_bounds__(BA_THREADS) void k_ba_fixed_sum(BaParams prm, const BaState* __restrict__ st,
+                                                            double* __restrict__ partF) {
+  __shared__ double fs[BA_THREADS], fm[BA_THREADS];
+  if (st->status != 0) return;
+  const uint32_t tid = threadIdx.x, n = prm.n_wg_fixed;
+  double c = 0.0, m = 0.0;
+  for (uint32_t q = tid; q < n; q += BA_THREADS) {
+    c += partF[2 * (size_t)q];
+    m = fmax(m, partF[2 * (size_t)q + 1]);
+  }
+  fs[tid] = c;
+  fm[tid] = m;
+  __syncthreads();
+  for (uint32_t o = BA_THREADS / 2; o > 0; o >>= 1) {
+    if (tid < o) {
+      fs[tid] += fs[tid + o];
+      fm[tid] = fmax(fm[tid], fm[tid + o]);
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    partF[2 * (size_t)n] = fs[0];
+    partF[2 * (size_t)n + 1] = fm[0];
+  }
+}
+
 // Sums the per-workgroup copies: a block handles 32 entries, 8 threads per entry each summing a
 // contiguous slice of the workgroups (loads in flight together), slices combined in order through
 // LDS -- a fixed summation order.  The last entry of V is a maximum.
 __global__ __launch_bounds__(256) void k_ba_reduce(BaParams prm, const BaState* __restrict__ st,
                                                   const double* __restrict__ partS,
-                                                  const double* __restrict__ partV, double* __restrict__ redS,
+                                                  const double* __restrict__ partV,
+                                                  const double* __restrict__ partF, double* __restrict__ redS,
                                                   double* __restrict__ redV) {
   __shared__ double sl[8][32];
   if (st->status != 0) return;
@@ -474,6 +633,10 @@ __global__ __launch_bounds__(256) void k_ba_reduce(BaParams prm, const BaState* 
     }
     for (; g < g1; ++g) {
       const double v = src[(size_t)g * stride];
+      a = is_max ? fmax(a, v) : a + v;
+    }
+    if (inV && (i - nS) >= nV - 2 && prm.n_wg_fixed && slice == 0) {  // cost | gmax of k_ba_fixed's landmarks
+      const double v = partF[2 * (size_t)prm.n_wg_fixed + (is_max ? 1 : 0)];
       a = is_max ? fmax(a, v) : a + v;
     }
   }
@@ -1166,7 +1329,9 @@ struct mvo_hip_ba_context {
   hipStream_t stream = nullptr;
   hipError_t last_hip_error = hipSuccess;
   Buf d_poses, d_X, d_lm_off, d_lm_nfree, d_obs_frame, d_obs_uv, d_obs_lm, d_obs_src, d_wg_lm, d_wg_lm_step, d_partS, d_partV,
-      d_redS, d_redV, d_partT, d_delta, d_state, d_trace, d_res, d_sums4, d_lmC;
+      d_redS, d_redV, d_partT, d_delta, d_state, d_trace, d_res, d_sums4, d_lmC, d_list_free, d_list_fixed, d_wg_fixed,
+      d_partF;
+  bool split = false;  // landmarks without free observations go through k_ba_fixed
   bool uploaded = false;
   BaParams prm{};
   uint64_t n_obs = 0;
@@ -1271,14 +1436,48 @@ int ba_upload(mvo_hip_ba_context* h, const mvo_hip_ba_pose* poses, uint32_t M, u
       if (w[q] < w[q - 1]) w[q] = w[q - 1];
     return w;
   };
-  const uint32_t n_wg = (uint32_t)std::min<uint64_t>((uint64_t)n_cu, std::max<uint64_t>(1, (L + 2 * BA_SCHUR_WAVES - 1) / (2 * BA_SCHUR_WAVES)));
+  const uint32_t n_wg = (uint32_t)std::min<uint64_t>((uint64_t)n_cu, std::max<uint64_t>(1, (L + 2 * BA_SCHUR_WAVES - 1) / (2 * BA_SCHUR_WAVES)));  // without the split below
   // lanes per landmark in k_ba_step by the mean track length; workgroups of at least two rounds of landmarks
   const uint64_t mean_T = L ? n_obs / L : 0;
   h->step_group = mean_T <= 96 ? 8 : (mean_T <= 224 ? 16 : 64);
   if (const char* e = std::getenv("MVO_BA_STEP_GROUP")) h->step_group = std::atoi(e);  // tuning knob: 8 | 16 | 64
   const uint32_t per_round = h->step_group == 64 ? BA_WAVES : BA_THREADS / h->step_group;
   const uint32_t n_wg_step = (uint32_t)std::min<uint64_t>(8ull * n_cu, std::max<uint64_t>(1, (L + 2 * per_round - 1) / (2 * per_round)));
-  const std::vector<uint32_t> wg_lm = partition(n_wg), wg_lm_step = partition(n_wg_step);
+  const std::vector<uint32_t> wg_lm_step = partition(n_wg_step);
+  // Landmarks without an observation in a free frame leave the reduced camera system alone: when
+  // they are a sizeable share they go through k_ba_fixed (many small workgroups) and k_ba_schur
+  // walks the list of the others.
+  std::vector<uint32_t> list_free, list_fixed;
+  for (uint32_t j = 0; j < L; ++j) (lm_nfree[j] ? list_free : list_fixed).push_back(j);
+  const bool split = list_fixed.size() * 10 >= (size_t)L && !list_fixed.empty();
+  h->split = split;
+  auto partition_list = [&](const std::vector<uint32_t>& list, uint32_t parts) {  // positions, equal observations + 1 each
+    std::vector<uint32_t> w(parts + 1, (uint32_t)list.size());
+    w[0] = 0;
+    uint64_t total = 0;
+    for (uint32_t j : list) total += (lm_off[j + 1] - lm_off[j]) + 1;
+    uint64_t run = 0;
+    uint32_t gq = 1;
+    for (uint32_t k = 0; k < list.size() && gq < parts; ++k) {
+      run += (lm_off[list[k] + 1] - lm_off[list[k]]) + 1;
+      while (gq < parts && run >= total * gq / parts) w[gq++] = k + 1;
+    }
+    for (uint32_t q = 1; q <= parts; ++q)
+      if (w[q] < w[q - 1]) w[q] = w[q - 1];
+    return w;
+  };
+  uint32_t n_wg_fixed = 0;
+  std::vector<uint32_t> wg_lm, wg_fixed;
+  uint32_t n_wg_eff = n_wg;
+  if (split) {
+    n_wg_eff = (uint32_t)std::min<uint64_t>((uint64_t)n_cu, std::max<uint64_t>(1, (list_free.size() + 2 * BA_SCHUR_WAVES - 1) / (2 * BA_SCHUR_WAVES)));
+    wg_lm = partition_list(list_free, n_wg_eff);
+    const uint32_t per_round_f = h->step_group == 64 ? BA_WAVES : BA_THREADS / h->step_group;
+    n_wg_fixed = (uint32_t)std::min<uint64_t>(8ull * n_cu, std::max<uint64_t>(1, (list_fixed.size() + 2 * per_round_f - 1) / (2 * per_round_f)));
+    wg_fixed = partition_list(list_fixed, n_wg_fixed);
+  } else {
+    wg_lm = partition(n_wg);
+  }
 
   BaParams& prm = h->prm;
   prm.ftol = opt->function_tolerance;
@@ -1292,7 +1491,8 @@ int ba_upload(mvo_hip_ba_context* h, const mvo_hip_ba_pose* poses, uint32_t M, u
   prm.N = (int32_t)N;
   prm.L = L;
   prm.n_blk = M * (M + 1) / 2;
-  prm.n_wg = n_wg;
+  prm.n_wg = n_wg_eff;
+  prm.n_wg_fixed = n_wg_fixed;
   prm.n_wg_step = n_wg_step;
   prm.trace_cap = (uint32_t)h->trace_cap;
   h->n_obs = n_obs;
@@ -1308,10 +1508,14 @@ int ba_upload(mvo_hip_ba_context* h, const mvo_hip_ba_pose* poses, uint32_t M, u
   BA_TRY(h->d_obs_uv.reserve(sizeof(double) * 2 * (n_obs + 1)));
   BA_TRY(h->d_obs_lm.reserve(sizeof(uint32_t) * (n_obs + 1)));
   BA_TRY(h->d_obs_src.reserve(sizeof(uint32_t) * (n_obs + 1)));
-  BA_TRY(h->d_wg_lm.reserve(sizeof(uint32_t) * (n_wg + 1)));
+  BA_TRY(h->d_wg_lm.reserve(sizeof(uint32_t) * (n_wg_eff + 1)));
+  BA_TRY(h->d_list_free.reserve(sizeof(uint32_t) * (list_free.size() + 1)));
+  BA_TRY(h->d_list_fixed.reserve(sizeof(uint32_t) * (list_fixed.size() + 1)));
+  BA_TRY(h->d_wg_fixed.reserve(sizeof(uint32_t) * (n_wg_fixed + 2)));
+  BA_TRY(h->d_partF.reserve(sizeof(double) * 2 * (n_wg_fixed + 1)));
   BA_TRY(h->d_wg_lm_step.reserve(sizeof(uint32_t) * (n_wg_step + 1)));
-  BA_TRY(h->d_partS.reserve(sizeof(double) * nS * n_wg));
-  BA_TRY(h->d_partV.reserve(sizeof(double) * nV * n_wg));
+  BA_TRY(h->d_partS.reserve(sizeof(double) * nS * n_wg_eff));
+  BA_TRY(h->d_partV.reserve(sizeof(double) * nV * n_wg_eff));
   BA_TRY(h->d_redS.reserve(sizeof(double) * nS));
   BA_TRY(h->d_redV.reserve(sizeof(double) * nV));
   BA_TRY(h->d_partT.reserve(sizeof(double) * 4 * n_wg_step));
@@ -1321,7 +1525,12 @@ int ba_upload(mvo_hip_ba_context* h, const mvo_hip_ba_pose* poses, uint32_t M, u
   hipStream_t s = h->stream;
   BA_TRY(hipMemcpyAsync(h->d_lm_off.p, lm_off.data(), sizeof(uint32_t) * (L + 1), hipMemcpyHostToDevice, s));
   BA_TRY(hipMemcpyAsync(h->d_lm_nfree.p, lm_nfree.data(), sizeof(uint32_t) * L, hipMemcpyHostToDevice, s));
-  BA_TRY(hipMemcpyAsync(h->d_wg_lm.p, wg_lm.data(), sizeof(uint32_t) * (n_wg + 1), hipMemcpyHostToDevice, s));
+  BA_TRY(hipMemcpyAsync(h->d_wg_lm.p, wg_lm.data(), sizeof(uint32_t) * (n_wg_eff + 1), hipMemcpyHostToDevice, s));
+  if (split) {
+    BA_TRY(hipMemcpyAsync(h->d_list_free.p, list_free.data(), sizeof(uint32_t) * list_free.size(), hipMemcpyHostToDevice, s));
+    BA_TRY(hipMemcpyAsync(h->d_list_fixed.p, list_fixed.data(), sizeof(uint32_t) * list_fixed.size(), hipMemcpyHostToDevice, s));
+    BA_TRY(hipMemcpyAsync(h->d_wg_fixed.p, wg_fixed.data(), sizeof(uint32_t) * (n_wg_fixed + 1), hipMemcpyHostToDevice, s));
+  }
   BA_TRY(hipMemcpyAsync(h->d_wg_lm_step.p, wg_lm_step.data(), sizeof(uint32_t) * (n_wg_step + 1), hipMemcpyHostToDevice, s));
   if (n_obs) {
     BA_TRY(hipMemcpyAsync(h->d_obs_frame.p, frame_word.data(), sizeof(uint32_t) * n_obs, hipMemcpyHostToDevice, s));
@@ -1364,17 +1573,32 @@ hipError_t launch_schur(mvo_hip_ba_context* h, double radius_override) {
   // poses of up to 512 frames are staged in LDS (48 KB); larger windows read them through L2
   const bool in_lds = h->prm.N <= 512;
   const size_t dyn = in_lds ? sizeof(double) * 12 * (size_t)h->prm.N : 0;
+  if (h->split) {
+    auto fk = &k_ba_fixed<64, false>;
+    if (h->step_group == 8) fk = in_lds ? &k_ba_fixed<8, true> : &k_ba_fixed<8, false>;
+    else if (h->step_group == 16) fk = in_lds ? &k_ba_fixed<16, true> : &k_ba_fixed<16, false>;
+    else if (in_lds) fk = &k_ba_fixed<64, true>;
+    hipLaunchKernelGGL(fk, dim3(h->prm.n_wg_fixed), dim3(BA_THREADS), dyn, h->stream, h->prm, h->d_state.as<BaState>(),
+                       radius_override, h->d_poses.as<double>(), h->d_X.as<double>(), h->d_lm_off.as<uint32_t>(),
+                       h->d_obs_frame.as<uint32_t>(), h->d_obs_uv.as<double2>(), h->d_wg_fixed.as<uint32_t>(),
+                       h->d_list_fixed.as<uint32_t>(), h->d_lmC.as<double>(), h->d_partF.as<double>());
+    hipLaunchKernelGGL(k_ba_fixed_sum, dim3(1), dim3(BA_THREADS), 0, h->stream, h->prm, h->d_state.as<BaState>(),
+                       h->d_partF.as<double>());
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
   auto kern = in_lds ? &k_ba_schur<true> : &k_ba_schur<false>;
   hipLaunchKernelGGL(kern, dim3(h->prm.n_wg), dim3(BA_SCHUR_THREADS), dyn, h->stream, h->prm,
                      h->d_state.as<BaState>(), radius_override, h->d_poses.as<double>(), h->d_X.as<double>(),
                      h->d_lm_off.as<uint32_t>(), h->d_lm_nfree.as<uint32_t>(), h->d_obs_frame.as<uint32_t>(),
-                     h->d_obs_uv.as<double2>(), h->d_wg_lm.as<uint32_t>(), h->d_partS.as<double>(),
+                     h->d_obs_uv.as<double2>(), h->d_wg_lm.as<uint32_t>(),
+                     h->split ? h->d_list_free.as<uint32_t>() : (const uint32_t*)nullptr, h->d_partS.as<double>(),
                      h->d_partV.as<double>(), h->d_lmC.as<double>());
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   const uint32_t n = h->prm.n_blk * 36 + 18 * h->prm.M + 2;
   hipLaunchKernelGGL(k_ba_reduce, dim3((n + 31) / 32), dim3(256), 0, h->stream, h->prm, h->d_state.as<BaState>(),
-                     h->d_partS.as<double>(), h->d_partV.as<double>(), h->d_redS.as<double>(),
+                     h->d_partS.as<double>(), h->d_partV.as<double>(), h->d_partF.as<double>(), h->d_redS.as<double>(),
                      h->d_redV.as<double>());
   return hipGetLastError();
 }
@@ -1589,7 +1813,7 @@ void mvo_hip_ba_destroy(mvo_hip_ba_handle h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   Buf* bufs[] = {&h->d_poses, &h->d_X, &h->d_lm_off, &h->d_lm_nfree, &h->d_obs_frame, &h->d_obs_uv, &h->d_obs_lm,
-                 &h->d_obs_src, &h->d_wg_lm, &h->d_wg_lm_step, &h->d_partS, &h->d_partV, &h->d_redS, &h->d_redV, &h->d_partT, &h->d_lmC,
+                 &h->d_obs_src, &h->d_wg_lm, &h->d_wg_lm_step, &h->d_partS, &h->d_partV, &h->d_redS, &h->d_redV, &h->d_partT, &h->d_lmC, &h->d_list_free, &h->d_list_fixed, &h->d_wg_fixed, &h->d_partF,
                  &h->d_delta, &h->d_state, &h->d_trace, &h->d_res, &h->d_sums4};
   for (Buf* b : bufs) b->release();
   if (h->events_ready)
