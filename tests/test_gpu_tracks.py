@@ -167,6 +167,22 @@ def test_argument_errors(solver):
             assert e.value.status == status
         offs, m0, m1 = table.gather(1, 2)
         assert int(offs[-1]) == 10
+        # the refine entry point reports the same conditions, and NULL arguments
+        frames = scene.make_window(3, 1, 5, seed=2).frames
+        with pytest.raises(capi.MvoHipError) as e:
+            table.refine(frames, 1)  # three keyframes asked for, two pushed
+        assert e.value.status == capi.ERR_STATE
+        lib = tracks_capi.load()
+        assert lib.mvo_hip_tracks_refine(table._h, None, 1, 2, None, None) == capi.ERR_INVALID_ARGUMENT
+        assert lib.mvo_hip_tracks_push(table._h, 3, None, None) == capi.ERR_INVALID_ARGUMENT
+        assert lib.mvo_hip_tracks_gather(table._h, 1, 2, None, None, None, 0) == capi.ERR_INVALID_ARGUMENT
+        assert lib.mvo_hip_tracks_push(None, 0, None, None) == capi.ERR_INVALID_ARGUMENT
+        too_small = np.zeros(3, dtype=np.uint64)
+        m = np.zeros((4, 3))
+        assert lib.mvo_hip_tracks_gather(table._h, 1, 2, too_small.ctypes.data, m.ctypes.data, m.ctypes.data, 4) \
+            == capi.ERR_INVALID_ARGUMENT  # 10 blocks do not fit a capacity of 4
+        tm = table.timing()
+        assert tm["residual_blocks"] == 10 and tm["fill_seconds"] == 0.0  # profiling is off by default
 
 
 def test_refine_on_empty_gather(solver):
