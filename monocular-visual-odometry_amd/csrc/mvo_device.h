@@ -46,6 +46,7 @@ struct SolveParams {
   int32_t trace_cap;
   int32_t inline_eval;  // 1: k_lm evaluates the observations itself (small / many windows)
   int32_t fresh;        // 1: first launch of a solve -- the stored state is stale, start from zeros
+  int32_t win_base;     // k_lm: window of workgroup 0 (launches over a range of the windows)
 };
 
 struct TraceRec {  // == mvo_hip_iteration

@@ -58,6 +58,8 @@ struct DevBuf {
 };
 
 constexpr int kMaxTimedLaunches = 128;
+constexpr int kMaxOverlapChunks = 8;
+constexpr int kOverlapChunks = 4;  // a k_lm launch over W / 4 windows takes about as long as a quarter of the fold
 // uploads with at most this many residual blocks stage their rays in the pinned arena too
 constexpr uint64_t kArenaRayLimit = 1u << 16;
 // windows with at most this many residual blocks are evaluated inside k_lm
@@ -128,6 +130,15 @@ struct mvo_hip_context {
   hipEvent_t ev[2 * kMaxTimedLaunches + 2] = {};
   bool events_ready = false;
   mvo_hip_timing timing{};
+  // batched windows without a loss: the fold of chunk c + 1 (HBM-bound) runs on `stream` while the LM
+  // loops of the windows chunk c completed (issue-bound) run on `stream_lm`
+  hipStream_t stream_lm[2] = {nullptr, nullptr};  // alternating: consecutive chunks' LM loops may overlap too
+  hipEvent_t ev_chunk[kMaxOverlapChunks + 2] = {};
+  bool overlap_ready = false;
+  int n_chunks = 0;                                      // 0: no overlap for this upload
+  uint32_t chunk_block_end[kMaxOverlapChunks] = {};      // fold workgroups [.., end)
+  uint32_t chunk_win_end[kMaxOverlapChunks] = {};        // windows whose tiles all lie in workgroups < end
+  std::vector<uint32_t> v_win_last_wave;
 };
 
 namespace {
@@ -233,8 +244,19 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
     if (t >= 1 && t <= 64) waves_per_cu = (uint32_t)t;
   }
   const uint64_t kMinChunk = 256, kMaxWaveTiles = 255;
+  // Batched windows without a loss run the fold in kMaxOverlapChunks launches next to the LM loops of
+  // the chunks before (do_solve): every one of those launches must fill the chip by itself.
+  int overlap_chunks = kOverlapChunks;
+  if (const char* e = std::getenv("MVO_HIP_OVERLAP_CHUNKS")) {  // tuning knob for experiments
+    const int t = std::atoi(e);
+    if (t >= 2 && t <= kMaxOverlapChunks) overlap_chunks = t;
+  }
+  const bool want_overlap = !h->pass_mode && !h->inline_eval && W >= 256 && P <= 256 &&
+                            n_obs >= (uint64_t)kMinChunk * 256 * waves_per_cu * overlap_chunks &&
+                            !std::getenv("MVO_HIP_NO_OVERLAP");
+  const uint64_t max_waves = 256ull * waves_per_cu * (want_overlap ? overlap_chunks : 1);
   uint64_t want_waves = (n_obs + kMinChunk - 1) / kMinChunk;
-  if (want_waves > 256ull * waves_per_cu) want_waves = 256ull * waves_per_cu;
+  if (want_waves > max_waves) want_waves = max_waves;
   if (want_waves == 0) want_waves = 1;
   const uint64_t chunk = (n_obs + want_waves - 1) / want_waves > 0 ? (n_obs + want_waves - 1) / want_waves : 1;
 
@@ -254,7 +276,10 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
   initx.assign((size_t)W * MVO_MAXM * 4, 0.0);
   uint64_t src = 0, cpos = 0;
   uint32_t slot = 0;
+  std::vector<uint32_t>& win_last_wave = h->v_win_last_wave;
+  win_last_wave.assign(W, 0);
   for (uint32_t w = 0; w < W; ++w) {
+    win_last_wave[w] = w ? win_last_wave[w - 1] : 0;  // a window without observations waits for nothing new
     wins[w].frame_off = w * N;
     wins[w].pair_off = w * P;
     wins[w].N = N;
@@ -299,6 +324,7 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
           if (done == 0 || block_start) cur_slot = slot++;
           t.slot = cur_slot;
           tiles.push_back(t);
+          win_last_wave[w] = (uint32_t)wave_tiles.size() - 1;  // index of the wavefront this tile belongs to
           done += take;
           wave_fill += take;
         }
@@ -318,6 +344,23 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
   }
   h->n_slots = slot;
   h->c_elems = cpos + 32;
+
+  // overlap plan (no loss, many windows, LM loop in its own launch): equal ranges of fold workgroups;
+  // a window may start its LM loop once the last workgroup holding one of its tiles is done
+  h->n_chunks = 0;
+  {
+    const uint32_t blocks = (h->n_waves + FOLD_WAVES - 1) / FOLD_WAVES;
+    if (want_overlap && blocks >= 256u * (uint32_t)overlap_chunks) {
+      h->n_chunks = overlap_chunks;
+      uint32_t w = 0;
+      for (int c = 0; c < h->n_chunks; ++c) {
+        const uint32_t end = c + 1 == h->n_chunks ? blocks : (uint32_t)((uint64_t)blocks * (c + 1) / h->n_chunks);
+        h->chunk_block_end[c] = end;
+        while (w < W && win_last_wave[w] / FOLD_WAVES < end) ++w;
+        h->chunk_win_end[c] = c + 1 == h->n_chunks ? W : w;
+      }
+    }
+  }
 
   h->h_frames.assign(frames, frames + (size_t)W * N);
   std::vector<PairDev>& unit = h->v_unit;  // the same pairs, each reading its own row of d_pairsum
@@ -496,6 +539,36 @@ hipError_t launch_lm(mvo_hip_context* h, const SolveParams& prm, bool from_pair_
   return hipGetLastError();
 }
 
+// batched windows, no loss: fold workgroups [b0, b1) on the main stream
+hipError_t launch_fold_range(mvo_hip_context* h, uint32_t b0, uint32_t b1) {
+  const uint32_t w0 = b0 * FOLD_WAVES, w1 = std::min<uint32_t>(h->n_waves, b1 * FOLD_WAVES);
+  if (w1 <= w0) return hipSuccess;
+  hipLaunchKernelGGL((k_fold<false, true>), dim3(b1 - b0), dim3(FOLD_THREADS), pass_lds(h), h->stream, h->t.tiles,
+                     h->t.wave_tiles + w0, w1 - w0, h->t.frames, h->t.m0, h->t.m1, (double*)nullptr, (size_t)0,
+                     h->d_partial.as<double>());
+  return hipGetLastError();
+}
+
+// ... and the whole LM loop of windows [win0, win1) on the second stream
+template <int NT>
+hipError_t launch_lm_range(mvo_hip_context* h, SolveParams prm, uint32_t win0, uint32_t win1, hipStream_t stream) {
+  const size_t dyn = sizeof(double) * 10 * (size_t)h->P;
+  size_t& configured = h->lm_dyn_configured[NT == 64 ? 0 : 1];
+  if (dyn > configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lm<NT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+    if (e != hipSuccess) return e;
+    configured = dyn;
+  }
+  prm.fresh = 1;
+  prm.win_base = (int32_t)win0;
+  hipLaunchKernelGGL(k_lm<NT>, dim3(win1 - win0), dim3(NT), dyn, stream, prm, 0, h->t.wins, h->t.frames,
+                     h->t.initx, h->t.pairs, h->d_partial.as<double>(), h->t.m0, h->t.m1, h->d_pairsum.as<double>(),
+                     h->d_states.as<LmState>(), h->d_results, h->d_pair_u.as<double>(), h->d_status,
+                     h->d_trace.as<TraceRec>(), h->d_done);
+  return hipGetLastError();
+}
+
 hipError_t launch_lm_any(mvo_hip_context* h, SolveParams prm, bool from_pair_sums = false) {
   prm.fresh = h->lm_started ? 0 : 1;  // the first launch of a solve starts from a zeroed state
   h->lm_started = true;
@@ -605,6 +678,38 @@ int do_solve(mvo_hip_context* h) {
     // the whole solve -- observation passes included -- is one launch, one workgroup per window
     HIP_TRY(launch_lm_any(h, prm, true));
     ++lm_launches;
+  } else if (!h->pass_mode && h->n_chunks > 1) {
+    // many windows: fold and LM loops overlap chunk by chunk on two streams
+    if (!h->overlap_ready) {
+      for (auto& q : h->stream_lm) HIP_TRY(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
+      for (auto& e : h->ev_chunk) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      h->overlap_ready = true;
+    }
+    uint32_t b0 = 0, win0 = 0;
+    bool used[2] = {false, false};
+    for (int c = 0; c < h->n_chunks; ++c) {
+      const uint32_t b1 = h->chunk_block_end[c], win1 = h->chunk_win_end[c];
+      HIP_TRY(timed_begin());
+      HIP_TRY(launch_fold_range(h, b0, b1));
+      HIP_TRY(timed_end());
+      ++asm_launches;
+      if (win1 > win0) {
+        hipStream_t q = h->stream_lm[c & 1];
+        used[c & 1] = true;
+        HIP_TRY(hipEventRecord(h->ev_chunk[c], s));
+        HIP_TRY(hipStreamWaitEvent(q, h->ev_chunk[c], 0));
+        HIP_TRY(h->P <= 64 ? launch_lm_range<64>(h, prm, win0, win1, q) : launch_lm_range<256>(h, prm, win0, win1, q));
+        ++lm_launches;
+      }
+      b0 = b1;
+      win0 = win1;
+    }
+    h->lm_started = true;
+    for (int q = 0; q < 2; ++q)
+      if (used[q]) {
+        HIP_TRY(hipEventRecord(h->ev_chunk[kMaxOverlapChunks + q], h->stream_lm[q]));
+        HIP_TRY(hipStreamWaitEvent(s, h->ev_chunk[kMaxOverlapChunks + q], 0));
+      }
   } else if (!h->pass_mode) {
     // one fold+moment pass, then the whole LM loop in a single launch
     if (fold_blocks) {
@@ -694,6 +799,11 @@ int do_solve(mvo_hip_context* h) {
     for (uint32_t w = 0; w < h->W; ++w) evals += (uint64_t)(h->h_results[w].iterations + 1);
     tm.assembly_bytes = h->pass_mode ? (uint64_t)(48.0 * (double)h->n_obs * (double)evals / (double)h->W)
                                      : 48ull * h->n_obs;
+  } else if (!h->pass_mode && h->n_chunks > 1) {
+    // the fold ran as n_chunks launches next to the LM loops of the chunks before: average launch
+    tm.assembly_seconds = tm.assembly_first_seconds + pass_seconds;
+    tm.assembly_launches = nt;
+    tm.assembly_bytes = 48ull * h->n_obs / (uint64_t)h->n_chunks;
   } else if (!h->pass_mode) {
     tm.assembly_seconds = tm.assembly_first_seconds;
     tm.assembly_bytes = 48ull * h->n_obs;  // k_fold<moments>: read m0, m1
@@ -777,6 +887,10 @@ void mvo_hip_destroy(mvo_hip_handle h) {
   if (h->h_ctl) (void)hipHostFree(h->h_ctl);
   if (h->events_ready)
     for (auto& e : h->ev) (void)hipEventDestroy(e);
+  if (h->overlap_ready) {
+    for (auto& e : h->ev_chunk) (void)hipEventDestroy(e);
+    for (auto& q : h->stream_lm) (void)hipStreamDestroy(q);
+  }
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }

@@ -702,7 +702,7 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
   constexpr int PARTS = NT >= 256 ? 8 : 1;   // strided parts of a long class sum
   extern __shared__ double pairbuf[];        // P x 10: T(6) q(3) cost(1)
   __shared__ LmSharedT<PARTS> sh;
-  const int w = blockIdx.x, tid = threadIdx.x;
+  const int w = (int)blockIdx.x + prm.win_base, tid = threadIdx.x;
   const int lane = tid & 63;
   const bool wave0 = tid < 64;
   LmState* __restrict__ gst = states + w;
