@@ -81,6 +81,7 @@ struct LmState {
 struct LmResult {
   double vec[MVO_MAXM][3];
   double t[MVO_MAXM];
+  double scale[MVO_MAXM];  // s(t): the write-back value of IR.cpp:240-246, so that a download is a copy
   double initial_cost, final_cost;
   int32_t termination, reason, iterations, nsucc, nunsucc, pad;
 };

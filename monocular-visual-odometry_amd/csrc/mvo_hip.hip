@@ -823,7 +823,7 @@ int do_download(mvo_hip_context* h, mvo_hip_frame* frames, mvo_hip_summary* summ
       // IR.cpp:240-246: refined frames get scale = s(t) and the optimised direction
       for (uint32_t k = 0; k < h->M; ++k) {
         mvo_hip_frame& f = frames[(size_t)w * h->N + k];
-        f.scale = host_scale(r.t[k], h->opt.highest_length, h->opt.lowest_length);
+        f.scale = r.scale[k];  // s(t) of scaleTemplated, evaluated by the kernel that terminated the window
         f.vec[0] = r.vec[k][0];
         f.vec[1] = r.vec[k][1];
         f.vec[2] = r.vec[k][2];

@@ -991,6 +991,7 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
       res->vec[lane][1] = st.b_vec[lane][1];
       res->vec[lane][2] = st.b_vec[lane][2];
       res->t[lane] = st.b_t[lane];
+      res->scale[lane] = d_scale(st.b_t[lane], prm.max_len, prm.min_len);
     }
     if (lane == 0) {
       res->initial_cost = st.initial_cost;
