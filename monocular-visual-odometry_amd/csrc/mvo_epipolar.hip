@@ -59,7 +59,9 @@ __device__ __forceinline__ double ep_rsqrt(double a) {
   double y = __builtin_amdgcn_rsq(a);
   const double h = 0.5 * a;
   y = y * fma(-h * y, y, 1.5);
+#ifndef MVO_EPI_ONE_NEWTON
   y = y * fma(-h * y, y, 1.5);
+#endif
   return y;
 }
 
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(256) void k_epi_score_tiled(uint32_t N, uint32_t K,
       const double m1b = a0 * b0 + a1 * b1 + a2 * b2;
       const double m2b = c0 * b0 + c1 * b1 + c2 * b2;
       const double x = fma(-m1b, m1b, n1), y = fma(-m2b, m2b, n2), num = fma(-m2b, m1b, m12);
-      const bool ok = fmin(x, y) > 1e-140 && fmax(x, y) < 1e140;
+      const bool ok = x > 1e-140 && y > 1e-140 && x * y < 1e280;  // comfortably positive, product finite
       const double p = num * ep_rsqrt(x * y);
       const bool in = ok && p > threshold;
       cnt[h] += in ? 1u : 0u;
