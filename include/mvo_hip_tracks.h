@@ -17,6 +17,7 @@
 #include <stdint.h>
 
 #include "mvo_hip.h"
+#include "mvo_hip_scaler.h"
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -54,6 +55,18 @@ int mvo_hip_tracks_refine(mvo_hip_tracks_handle t, mvo_hip_frame *frames, uint32
  * be NULL to query the total = pair_offsets[n_pairs] first. */
 int mvo_hip_tracks_gather(mvo_hip_tracks_handle t, uint32_t M, uint32_t N, uint64_t *pair_offsets, double *m0,
                           double *m1, uint64_t capacity);
+
+/* The scale stage on the same tables: Scaler::stage's three-frame gather
+ * (pipeline/Scaler.cpp:22 -> Frame::getCorrespondingFeatures(oldest, newest, {v0, v1, v2}),
+ * sliding_window/Frame.hpp:103-152) runs on the device -- the features of the keyframe `age` pushes
+ * ago (0 = newest) whose track reaches back two more keyframes, in that keyframe's feature order;
+ * v0 = their rays in it, v1 / v2 = one / two keyframes older -- and feeds mvo_hip_scaler_run
+ * (include/mvo_hip_scaler.h: lines 21-68 of the stage) without the rays leaving HBM.  Both handles
+ * must live on the same GPU.  per_track may be NULL.  MVO_HIP_ERR_STATE with fewer than age + 3
+ * keyframes in the table.  The rays reach the formula already unit-normalised (the table stores them so);
+ * Scaler.cpp:35-37 divides by the norm once more, which changes nothing but the last bit. */
+int mvo_hip_tracks_scale(mvo_hip_tracks_handle t, mvo_hip_scaler_handle scaler, uint32_t age,
+                         const mvo_hip_scaler_input *in, double *per_track, mvo_hip_scaler_result *result);
 
 /* Measurement (off by default): HIP events on the solver's stream around the two gather kernels of
  * the last refine / gather call. */

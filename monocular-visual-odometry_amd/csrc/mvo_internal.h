@@ -2,6 +2,7 @@
 // part of the public C ABI in include/).
 #pragma once
 #include "../../include/mvo_hip.h"
+#include "../../include/mvo_hip_scaler.h"
 
 extern "C" {
 void* mvo_hip_internal_stream(mvo_hip_handle h);  // hipStream_t of the handle
@@ -13,4 +14,9 @@ int mvo_hip_internal_device(mvo_hip_handle h);
 int mvo_hip_internal_upload_device_rays(mvo_hip_handle h, const mvo_hip_frame* frames, uint32_t M, uint32_t N,
                                         const mvo_hip_options* options, const mvo_hip_observations* observations,
                                         double** m0_device, double** m1_device);
+// scale stage: room for n_tracks tracks in the handle's own ray buffers (3 doubles per track each), which
+// the caller then fills on the device; the next mvo_hip_scaler_run works on them.  *device is the
+// handle's GPU.
+int mvo_hip_scaler_internal_reserve(mvo_hip_scaler_handle h, uint64_t n_tracks, double** v0, double** v1, double** v2,
+                                    int* device);
 }

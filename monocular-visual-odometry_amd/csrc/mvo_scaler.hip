@@ -20,6 +20,7 @@
 //   serialise on one bin) and merged with integer atomics: order-independent, deterministic.
 #include "../../include/mvo_hip_scaler.h"
 #include "../../include/mvo_hip.h"
+#include "mvo_internal.h"
 
 #include <hip/hip_runtime.h>
 
@@ -621,6 +622,24 @@ int mvo_hip_scaler_last_timing(mvo_hip_scaler_handle h, double* device_seconds, 
   if (!h) return MVO_HIP_ERR_INVALID_ARGUMENT;
   if (device_seconds) *device_seconds = h->device_seconds;
   if (bytes) *bytes = h->bytes;
+  return MVO_HIP_OK;
+}
+
+// library-internal (csrc/mvo_internal.h): the device-side three-frame gather of mvo_tracks.hip writes the
+// rays straight into this handle's buffers
+int mvo_hip_scaler_internal_reserve(mvo_hip_scaler_handle h, uint64_t n_tracks, double** v0, double** v1, double** v2,
+                                    int* device) {
+  if (!h || !v0 || !v1 || !v2) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  if (n_tracks >= (1ull << 32)) return MVO_HIP_ERR_UNSUPPORTED;
+  SC_TRY(hipSetDevice(h->device));
+  SC_TRY(hipStreamSynchronize(h->stream));  // a run may still be reading the buffers about to be replaced
+  const int rc = sc_reserve(h, n_tracks ? n_tracks : 1);
+  if (rc != MVO_HIP_OK) return rc;
+  h->n = n_tracks;
+  *v0 = h->d_v[0];
+  *v1 = h->d_v[1];
+  *v2 = h->d_v[2];
+  if (device) *device = h->device;
   return MVO_HIP_OK;
 }
 

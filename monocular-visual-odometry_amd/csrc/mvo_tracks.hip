@@ -178,6 +178,63 @@ __global__ __launch_bounds__(64) void k_tracks_fill(TracksDev t, uint32_t N, uin
   }
 }
 
+// ---- the scale stage's three-frame gather (Scaler.cpp:22 -> Frame.hpp:103-152, depth 2): features of
+// the frame `age` pushes ago whose track reaches back two more frames, in that frame's order.
+// cnt[g] = such features in the 64-feature group g; one workgroup scans the groups (-> base ranks in
+// place, total behind them); the fill follows the two predecessor links.
+__global__ __launch_bounds__(64) void k_tracks_count3(TracksDev t, uint32_t age, uint32_t* __restrict__ cnt) {
+  const uint32_t g = blockIdx.x, lane = threadIdx.x, slot = tr_slot(t, age), n = t.n_feat[slot];
+  const uint32_t i = g * 64 + lane;
+  const bool take = i < n && t.counter[(size_t)slot * t.max_features + i] >= 2;
+  const unsigned long long bal = __ballot(take);
+  if (lane == 0) cnt[g] = (uint32_t)__popcll(bal);
+}
+
+__global__ __launch_bounds__(1024) void k_tracks_scan3(uint32_t groups, uint32_t* __restrict__ cnt) {
+  __shared__ uint32_t part[1024];
+  const uint32_t tid = threadIdx.x, per = (groups + 1023) / 1024, lo = min(tid * per, groups), hi = min(lo + per, groups);
+  uint32_t sum = 0;
+  for (uint32_t g = lo; g < hi; ++g) sum += cnt[g];
+  part[tid] = sum;
+  __syncthreads();
+  for (uint32_t o = 1; o < 1024; o <<= 1) {  // inclusive scan of the 1024 partial sums
+    const uint32_t v = tid >= o ? part[tid - o] : 0u;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  uint32_t run = part[tid] - sum;
+  for (uint32_t g = lo; g < hi; ++g) {
+    const uint32_t v = cnt[g];
+    cnt[g] = run;
+    run += v;
+  }
+  if (tid == 1023) cnt[groups] = part[1023];
+}
+
+__global__ __launch_bounds__(64) void k_tracks_fill3(TracksDev t, uint32_t age, const uint32_t* __restrict__ base,
+                                                    double* __restrict__ v0, double* __restrict__ v1,
+                                                    double* __restrict__ v2) {
+  const uint32_t g = blockIdx.x, lane = threadIdx.x, slot0 = tr_slot(t, age), n = t.n_feat[slot0];
+  const uint32_t i = g * 64 + lane;
+  const bool take = i < n && t.counter[(size_t)slot0 * t.max_features + i] >= 2;
+  const unsigned long long bal = __ballot(take);
+  if (!take) return;
+  const size_t o = 3 * (size_t)(base[g] + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull)));
+  const uint32_t slot1 = tr_slot(t, age + 1), slot2 = tr_slot(t, age + 2);
+  const uint32_t i1 = (uint32_t)t.pre[(size_t)slot0 * t.max_features + i];
+  const uint32_t i2 = (uint32_t)t.pre[(size_t)slot1 * t.max_features + i1];
+  const double* __restrict__ r0 = t.rays + ((size_t)slot0 * t.max_features + i) * 3;
+  const double* __restrict__ r1 = t.rays + ((size_t)slot1 * t.max_features + i1) * 3;
+  const double* __restrict__ r2 = t.rays + ((size_t)slot2 * t.max_features + i2) * 3;
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    v0[o + q] = r0[q];
+    v1[o + q] = r1[q];
+    v2[o + q] = r2[q];
+  }
+}
+
 struct mvo_hip_tracks_context {
   mvo_hip_handle solver = nullptr;
   int device = 0;
@@ -191,6 +248,7 @@ struct mvo_hip_tracks_context {
   size_t cap_cnt = 0;
   double* d_rays_in = nullptr;  // staging of the caller's rays
   uint32_t g_groups = 0, g_sp = 0;  // shape of d_cnt at the last count
+  uint32_t* h_total = nullptr;      // pinned: number of three-frame tracks
   int32_t* d_pre_in = nullptr;  // staging of the caller's predecessor indices
   uint64_t* d_offsets = nullptr;
   double *d_m0 = nullptr, *d_m1 = nullptr;
@@ -361,6 +419,7 @@ void mvo_hip_tracks_destroy(mvo_hip_tracks_handle t) {
     if (p) (void)hipFree(p);
   if (t->h_counts) (void)hipHostFree(t->h_counts);
   if (t->h_offsets) (void)hipHostFree(t->h_offsets);
+  if (t->h_total) (void)hipHostFree(t->h_total);
   if (t->events_ready)
     for (auto& e : t->ev) (void)hipEventDestroy(e);
   delete t;
@@ -471,6 +530,46 @@ int mvo_hip_tracks_refine(mvo_hip_tracks_handle t, mvo_hip_frame* frames, uint32
   rc = mvo_hip_solve(t->solver);
   if (rc != MVO_HIP_OK) return rc;
   return mvo_hip_download(t->solver, frames, summary);
+}
+
+int mvo_hip_tracks_scale(mvo_hip_tracks_handle t, mvo_hip_scaler_handle scaler, uint32_t age,
+                         const mvo_hip_scaler_input* in, double* per_track, mvo_hip_scaler_result* result) {
+  if (!t || !scaler || !in || !result) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  if ((uint64_t)age + 3 > t->n_pushed || (uint64_t)age + 3 > t->max_frames) return MVO_HIP_ERR_STATE;
+  TR_TRY(hipSetDevice(t->device));
+  hipStream_t s = t->stream;
+  const uint32_t n = t->h_nfeat[(t->head + t->max_frames - age) % t->max_frames];
+  const uint32_t groups = (n + 63) / 64;
+  if ((size_t)groups + 1 > t->cap_cnt) {
+    if (t->d_cnt) (void)hipFree(t->d_cnt);
+    t->d_cnt = nullptr;
+    t->cap_cnt = 0;
+    TR_TRY(hipMalloc((void**)&t->d_cnt, sizeof(uint32_t) * ((size_t)groups + 1)));
+    t->cap_cnt = (size_t)groups + 1;
+  }
+  if (!t->h_total) TR_TRY(hipHostMalloc((void**)&t->h_total, sizeof(uint32_t) * 4, hipHostMallocDefault));
+  t->h_total[0] = 0;
+  const TracksDev d = dev_view(t);
+  if (groups) {
+    hipLaunchKernelGGL(k_tracks_count3, dim3(groups), dim3(64), 0, s, d, age, t->d_cnt);
+    hipLaunchKernelGGL(k_tracks_scan3, dim3(1), dim3(1024), 0, s, groups, t->d_cnt);
+    TR_TRY(hipGetLastError());
+    TR_TRY(hipMemcpyAsync(t->h_total, t->d_cnt + groups, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    TR_TRY(hipStreamSynchronize(s));
+  }
+  const uint32_t total = t->h_total[0];
+  double *v0 = nullptr, *v1 = nullptr, *v2 = nullptr;
+  int sc_device = -1;
+  int rc = mvo_hip_scaler_internal_reserve(scaler, total, &v0, &v1, &v2, &sc_device);
+  if (rc != MVO_HIP_OK) return rc;
+  if (sc_device != t->device) return MVO_HIP_ERR_INVALID_ARGUMENT;  // both handles must live on one GPU
+  TR_TRY(hipSetDevice(t->device));
+  if (total) {
+    hipLaunchKernelGGL(k_tracks_fill3, dim3(groups), dim3(64), 0, s, d, age, t->d_cnt, v0, v1, v2);
+    TR_TRY(hipGetLastError());
+    TR_TRY(hipStreamSynchronize(s));  // the scale stage runs on its own stream
+  }
+  return mvo_hip_scaler_run(scaler, in, per_track, result);
 }
 
 int mvo_hip_tracks_set_profiling(mvo_hip_tracks_handle t, int enabled) {

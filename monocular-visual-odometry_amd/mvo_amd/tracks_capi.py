@@ -6,12 +6,13 @@ import ctypes as C
 
 import numpy as np
 
-from . import capi
+from . import capi, scaler_capi
 
 EXPORTED_SYMBOLS = [
     "mvo_hip_tracks_create", "mvo_hip_tracks_destroy", "mvo_hip_tracks_push", "mvo_hip_tracks_append",
     "mvo_hip_tracks_reset",
-    "mvo_hip_tracks_refine", "mvo_hip_tracks_gather", "mvo_hip_tracks_set_profiling", "mvo_hip_tracks_get_timing",
+    "mvo_hip_tracks_refine", "mvo_hip_tracks_gather", "mvo_hip_tracks_scale", "mvo_hip_tracks_set_profiling",
+    "mvo_hip_tracks_get_timing",
 ]
 
 
@@ -36,6 +37,8 @@ def load():
                                             C.POINTER(capi.Options), C.POINTER(capi.Summary)]
         L.mvo_hip_tracks_gather.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_uint64]
+        L.mvo_hip_tracks_scale.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(scaler_capi.Input),
+                                           C.c_void_p, C.POINTER(scaler_capi.Result)]
         L.mvo_hip_tracks_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.mvo_hip_tracks_get_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
         _BOUND = True
@@ -48,6 +51,7 @@ class TrackTable:
     def __init__(self, solver, max_frames, max_features):
         self._lib = load()
         self._solver = solver  # keeps the solver alive: the table uses its stream
+        self._max_features = int(max_features)
         self._h = C.c_void_p()
         rc = self._lib.mvo_hip_tracks_create(solver._h, int(max_frames), int(max_features), C.byref(self._h))
         if rc != capi.OK:
@@ -119,6 +123,21 @@ class TrackTable:
         if rc != capi.OK:
             raise capi.MvoHipError(rc, "mvo_hip_tracks_refine")
         return frames, summ
+
+    def scale(self, scaler, inp, age=0, per_track=False):
+        """Scaler::stage on the three keyframes age, age + 1, age + 2 pushes ago, gathered on the device
+        -> (scaler_capi.Result, per-track scales or None).  `scaler`: a scaler_capi.Scaler on the same GPU."""
+        scaler_capi.load()
+        res = scaler_capi.Result()
+        out = None
+        if per_track:
+            # the number of three-frame tracks is not known up front: room for every feature of the frame
+            out = np.full(int(self._max_features), np.nan)
+        rc = self._lib.mvo_hip_tracks_scale(self._h, scaler._h, int(age), C.byref(inp),
+                                            out.ctypes.data if out is not None else None, C.byref(res))
+        if rc != capi.OK:
+            raise capi.MvoHipError(rc, "mvo_hip_tracks_scale")
+        return res, (out[: res.n_tracks] if out is not None else None)
 
     def set_profiling(self, enabled):
         rc = self._lib.mvo_hip_tracks_set_profiling(self._h, int(bool(enabled)))

@@ -9,7 +9,7 @@ host-gathered blocks (same kernels, same inputs: array_equal)."""
 import numpy as np
 import pytest
 
-from mvo_amd import capi, scene, tracks_capi
+from mvo_amd import capi, scaler_capi, scene, tracks_capi
 
 pytestmark = pytest.mark.gpu
 
@@ -200,3 +200,41 @@ def test_refine_on_empty_gather(solver):
                          true_scale=w.true_scale, bearing_observations=0, meta={})
     exp, es = solver.refine(empty)
     assert np.array_equal(got, exp) and gs.termination == es.termination
+
+
+@pytest.mark.parametrize("N,L,span,age", [(3, 50, "full", 0), (6, 3000, ("sliding", 4), 0), (6, 3000, ("sliding", 4), 2),
+                                          (5, 40000, ("anchored", 1, 5), 1)], ids=["ref-size", "sliding", "older", "large"])
+def test_scale_stage_from_the_tables(solver, N, L, span, age):
+    """mvo_hip_tracks_scale: Scaler::stage's three-frame gather (Scaler.cpp:22, Frame.hpp:103-152) on the
+    device + the scale stage.  Against the host route -- the same three-frame tracks gathered in numpy
+    (features of the frame with counter >= 2, in its feature order, two predecessor links) from the
+    table's own unit rays and handed to mvo_hip_scaler_scale: identical inputs, so per-track scales
+    and median must be bit-identical."""
+    w = scene.make_window(N, age + 1, L, seed=4500 + N + age, span=span, keep_tracks=True)
+    frames = scene.track_frames(w)  # oldest first
+    fr = frames[::-1]  # index 0 = newest
+    unit = []
+    for rays, _ in fr:
+        sc = 1.0 / np.sqrt((rays[:, 0] * rays[:, 0] + rays[:, 1] * rays[:, 1]) + rays[:, 2] * rays[:, 2])
+        unit.append(rays * sc[:, None])
+    pre0, pre1 = fr[age][1], fr[age + 1][1]
+    ok0 = pre0 >= 0
+    ok1 = np.zeros(len(pre0), dtype=bool)
+    ok1[ok0] = pre1[pre0[ok0]] >= 0
+    sel = np.nonzero(ok1)[0]  # counter >= 2
+    i1 = pre0[sel]
+    i2 = pre1[i1]
+    v0, v1, v2 = unit[age][sel], unit[age + 1][i1], unit[age + 2][i2]
+    t = scaler_capi.synthetic_tracks(4, seed=9)  # rotations / baseline of the input record; the rays come from the table
+    inp = scaler_capi.make_input(t["R0"], t["R1"], t["R2"], t["u1"], t["n1"], 0.25, 2.0)
+    with scaler_capi.Scaler(0) as sc_dev, scaler_capi.Scaler(0) as sc_host:
+        with tracks_capi.TrackTable(solver, max_frames=N + 1, max_features=max(len(p) for _, p in frames)) as table:
+            _push_all(table, frames)
+            res, per = table.scale(sc_dev, inp, age=age, per_track=True)
+            with pytest.raises(capi.MvoHipError) as e:
+                table.scale(sc_dev, inp, age=N - 2)  # needs two older keyframes
+            assert e.value.status == capi.ERR_STATE
+        ref, per_ref = sc_host.scale(inp, np.ascontiguousarray(v0), np.ascontiguousarray(v1), np.ascontiguousarray(v2))
+    assert res.n_tracks == len(sel) == ref.n_tracks and len(sel) > 0
+    assert np.array_equal(per, per_ref)
+    assert res.median == ref.median and res.scale == ref.scale and res.clamped == ref.clamped
