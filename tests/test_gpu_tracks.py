@@ -238,3 +238,43 @@ def test_scale_stage_from_the_tables(solver, N, L, span, age):
     assert res.n_tracks == len(sel) == ref.n_tracks and len(sel) > 0
     assert np.array_equal(per, per_ref)
     assert res.median == ref.median and res.scale == ref.scale and res.clamped == ref.clamped
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_gather_with_shuffled_feature_order(solver, seed):
+    """A tracker does not keep features in landmark order: every frame lists the survivors of the
+    previous one in RANDOM order, interleaved with new features.  Chains then hop all over the
+    tables; offsets, block order and rays must still equal the numpy chain walk bit for bit, and
+    the scale stage's three-frame gather its numpy counterpart."""
+    rng = np.random.default_rng(900 + seed)
+    N, M = 9, 4
+    frames = []
+    n_prev = 0
+    for k in range(N):  # oldest first
+        survivors = rng.permutation(n_prev)[: int(n_prev * rng.uniform(0.6, 0.95))]
+        n_new = int(rng.integers(50, 400))
+        pre = np.concatenate([survivors, -np.ones(n_new, dtype=np.int64)]).astype(np.int32)
+        rng.shuffle(pre)
+        rays = np.column_stack([rng.uniform(-0.6, 0.6, len(pre)), rng.uniform(-0.4, 0.4, len(pre)), np.ones(len(pre))])
+        frames.append((np.ascontiguousarray(rays), pre))
+        n_prev = len(pre)
+    width = max(len(p) for _, p in frames)
+    t = scaler_capi.synthetic_tracks(4, seed=3)
+    inp = scaler_capi.make_input(t["R0"], t["R1"], t["R2"], t["u1"], t["n1"], 0.25, 2.0)
+    with tracks_capi.TrackTable(solver, max_frames=N, max_features=width) as table, scaler_capi.Scaler(0) as sc:
+        _push_all(table, frames)
+        offs, m0, m1 = table.gather(M, N)
+        res, per = table.scale(sc, inp, age=1, per_track=True)
+        eo, e0, e1 = scene.gather_tracks_numpy(frames, M)
+        assert int(eo[-1]) > 1000 and np.array_equal(offs, eo)
+        assert np.array_equal(m0, e0) and np.array_equal(m1, e1)
+        fr = frames[::-1]
+        unit = []  # the table normalises as v * (1 / |v|): restate exactly
+        for r, _ in fr:
+            scl = 1.0 / np.sqrt((r[:, 0] * r[:, 0] + r[:, 1] * r[:, 1]) + r[:, 2] * r[:, 2])
+            unit.append(r * scl[:, None])
+        p0, p1 = fr[1][1], fr[2][1]
+        sel = np.array([i for i in range(len(p0)) if p0[i] >= 0 and p1[p0[i]] >= 0], dtype=np.int64)
+        ref, per_ref = sc.scale(inp, np.ascontiguousarray(unit[1][sel]), np.ascontiguousarray(unit[2][p0[sel]]),
+                                np.ascontiguousarray(unit[3][p1[p0[sel]]]))
+        assert res.n_tracks == len(sel) > 100 and np.array_equal(per, per_ref) and res.median == ref.median
