@@ -8,6 +8,11 @@ import sys
 
 out = sys.argv[1]
 print(f"# rocprofv3 summary ({os.path.basename(out)})\n")
+print("Each trace is ONE workload (`--no-large` on config 2 / 5; config 4 / 4r traced on their own).\n"
+      "`avg_launch_us` in the bench lines below was measured with HIP events UNDER the profiler, which\n"
+      "adds ~10 us to every event interval (config 2: 18 us by events vs 5.7 us in the trace); outside\n"
+      "the profiler the same interval reads 7.4 us (events cost ~2 us around a 5.5-us kernel) and the\n"
+      "config-4-size launches agree within 3 % (88-94 us by events vs 91.5 us here).\n")
 for d in sorted(glob.glob(os.path.join(out, "kt_*"))):
     if not os.path.isdir(d):
         continue
