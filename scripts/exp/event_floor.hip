@@ -1,5 +1,5 @@
 // How much of a HIP-event interval around a short kernel is the events' own cost?
-// build: hipcc --offload-arch=gfx950 -O3 -o /tmp/event_floor scripts/exp/event_floor.hip
+// build: hipcc --offload-arch=gfx950 -O3 -o scripts/exp/event_floor.bin scripts/exp/event_floor.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
