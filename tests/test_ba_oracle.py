@@ -1,7 +1,8 @@
 """Self-checks of the bundle-adjustment oracle (oracle/mvo_ba_oracle.c).  PARITY UNPINNED: the
 reference has no explicit-landmark BA, so the oracle is pinned by finite
-differences, by an independent dense numpy assembly of the normal equations, and by recovering
-noise-free synthetic scenes."""
+differences, by an independent dense numpy assembly of the normal equations, by recovering
+noise-free synthetic scenes, and by scipy.optimize.least_squares on a numpy restatement of the
+problem (same converged minimum)."""
 import numpy as np
 import pytest
 
@@ -113,3 +114,62 @@ def test_outliers_with_cauchy_beat_plain_least_squares():
     robust = bo.refine(sc, bo.make_options(max_num_iterations=25, loss=1, loss_scale=0.003))
     err = lambda p: np.abs(p[:sc.M, 9:] - sc.true_poses[:sc.M, 9:]).max()
     assert err(robust[0]) < 0.3 * err(plain[0])
+
+
+@pytest.mark.parametrize("loss", [0, 1])
+def test_converged_minimum_equals_scipy_least_squares(loss):
+    """Independent minimiser: scipy.optimize.least_squares on a numpy restatement of the problem in the
+    header (rotations through scipy's Rotation, not the oracle's Exp).  Cauchy: scipy's
+    loss='cauchy', f_scale=a minimises 1/2 a^2 sum log(1 + s/a^2) with s = z^2 PER RESIDUAL ENTRY, so
+    the 2-vector of one observation enters as its norm.  Same minimum => same cost, poses, landmarks."""
+    from scipy.optimize import least_squares
+    from scipy.spatial.transform import Rotation
+
+    sc = ba_scene.make_ba_scene(6, 4, 40, seed=21, outlier_fraction=0.05 if loss else 0.0)
+    a = 0.004
+    M, L = sc.M, sc.n_landmarks
+    lm_of_obs = np.repeat(np.arange(L), np.diff(sc.lm_offsets).astype(np.int64))
+    frame = sc.obs_frame.astype(np.int64)
+    target = sc.obs_ray[:, :2] / sc.obs_ray[:, 2:3]
+    R0 = sc.poses[:, :9].reshape(-1, 3, 3)
+    p0 = sc.poses[:, 9:]
+
+    def unpack(x):
+        R, p = R0.copy(), p0.copy()
+        d = x[:6 * M].reshape(M, 6)
+        R[:M] = R0[:M] @ Rotation.from_rotvec(d[:, :3]).as_matrix()
+        p[:M] = p0[:M] + d[:, 3:]
+        return R, p, x[6 * M:].reshape(L, 3)
+
+    def fun(x):
+        R, p, X = unpack(x)
+        q = np.einsum("oji,oj->oi", R[frame], X[lm_of_obs] - p[frame])  # R^T (X - p)
+        r = q[:, :2] / q[:, 2:3] - target
+        return np.sqrt((r * r).sum(1)) if loss else r.ravel()
+
+    opt = bo.make_options(max_num_iterations=200, loss=loss, loss_scale=a, function_tolerance=1e-16,
+                          gradient_tolerance=1e-14, parameter_tolerance=1e-14)
+    poses, X, s, tr = bo.refine(sc, opt)
+    assert s.final_cost < 0.5 * s.initial_cost
+    kw = dict(loss="cauchy", f_scale=a) if loss else {}
+    tol = dict(method="trf", x_scale="jac", xtol=1e-15, ftol=1e-15, gtol=1e-15)
+    if loss:
+        # scipy's robust trust-region crawls on this problem (400 evaluations from the initial guess
+        # still leave it 1 % above the oracle's cost), so it is started AT the oracle's minimiser:
+        # its own statement of the cost must agree there, and it must find nothing lower nearby
+        d = np.zeros((M, 6))
+        d[:, :3] = Rotation.from_matrix(np.einsum("kji,kjl->kil", R0[:M], poses[:M, :9].reshape(-1, 3, 3))).as_rotvec()
+        d[:, 3:] = poses[:M, 9:] - p0[:M]
+        x0 = np.concatenate([d.ravel(), X.ravel()])
+        z = fun(x0)
+        assert np.isclose(0.5 * a * a * np.log1p(z * z / (a * a)).sum(), s.final_cost, rtol=1e-12)
+        ref = least_squares(fun, x0, max_nfev=50, **tol, **kw)
+        assert ref.cost <= s.final_cost * (1 + 1e-12) and np.isclose(ref.cost, s.final_cost, rtol=1e-9)
+    else:
+        x0 = np.concatenate([np.zeros(6 * M), sc.X.ravel()])
+        ref = least_squares(fun, x0, max_nfev=400, **tol)
+        assert np.isclose(s.final_cost, ref.cost, rtol=1e-9)
+    Rr, pr, Xr = unpack(ref.x)
+    assert np.abs(poses[:, :9].reshape(-1, 3, 3) - Rr).max() < 1e-6
+    assert np.abs(poses[:, 9:] - pr).max() < 1e-6 * max(1.0, np.abs(pr).max())
+    assert np.abs(X - Xr).max() < 1e-5 * np.abs(Xr).max()
