@@ -680,11 +680,17 @@ __device__ __forceinline__ void ba_pose_plus(const double* __restrict__ in, cons
 // right-hand side rides along as block row M (forward substitution for free).  Right-looking
 // block L D L^T (no square roots): per block column kb
 //   (1) the diagonal thread factors its block and publishes l (unit lower), d, 1/d      -> LDS
-//   (2) the panel threads (ib > kb, jb = kb) compute X = A l^-T, W = X d^-1, publish both -> LDS
+//   (2) the panel threads (ib > kb, jb = kb) compute X = A l^-T, publish it -> LDS, keep W = X d^-1
 //   (3) every trailing thread (ib >= jb > kb) subtracts W_ib X_jb^T from its registers
 // -- two barriers per block column, no LDS read-modify-write.  The factor is then dumped to LDS
 // and wavefront 0 runs the scalar back substitution without barriers.
 // ---------------------------------------------------------------------------------------------
+// value of lane `src` (wave-uniform) in every lane
+__device__ __forceinline__ double ba_readlane(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ uint32_t tri(uint32_t i, uint32_t j) { return (i * (i + 1)) / 2 + j; }  // j <= i
 
 
@@ -694,9 +700,11 @@ __global__ __launch_bounds__(BA_SOLVE_THREADS) void k_ba_solve(BaParams prm, BaS
                                                               double* __restrict__ poses2,
                                                               double* __restrict__ delta_c) {
   extern __shared__ double Lf[];  // (M+1)(M+2)/2 blocks x 36: the factor, block (ib, jb) at tri(ib, jb)
-  // W rows are read at a per-lane block index (consecutive ib within a wavefront): 37-double rows
-  // keep those reads off a common bank; X rows are mostly read by whole wavefronts at once
-  __shared__ double pubX[2][BA_MAXF + 1][37], pubW[2][BA_MAXF + 1][37];
+  // Only X is published; W_ib = X_ib d^-1 is recomputed by its readers (36 multiplies against 36 LDS
+  // writes and reads).  Rows of 38 doubles = 304 B: 16-byte aligned for b128 accesses, and the rows
+  // read at a per-lane block index (consecutive ib within a wavefront) start 76 banks apart, which
+  // spreads 16 lanes x 4 banks over all 64; X_jb rows are mostly read by whole wavefronts at once
+  __shared__ __align__(16) double pubX[2][BA_MAXF + 1][38];
   __shared__ double dl[2][36], dinvs[2][6];
   __shared__ double xs[6 * BA_MAXF], dc2[6 * BA_MAXF];
   __shared__ int bad_flag;
@@ -763,23 +771,27 @@ __global__ __launch_bounds__(BA_SOLVE_THREADS) void k_ba_solve(BaParams prm, BaS
   for (uint32_t kb = 0; kb < M; ++kb) {
     const int buf = kb & 1;
     if (have && ib == kb && jb == kb) {  // (1) l d l^T of the diagonal block (lower part of a)
+      // right-looking: column c is scaled as soon as its pivot is known and the trailing lower
+      // triangle takes its rank-1 update at once -- per column the dependent chain is reciprocal,
+      // scale, one FMA (the left-looking form accumulates c products before and after the reciprocal)
       bool ok = true;
-      double d[6], iv[6];
+      double iv[6];
 #pragma unroll
       for (int c = 0; c < 6; ++c) {
-        double dcv = a[7 * c];
-#pragma unroll
-        for (int p = 0; p < c; ++p) dcv -= a[6 * c + p] * a[6 * c + p] * d[p];
+        const double dcv = a[7 * c];
         if (!(dcv > 0.0) || isinf(dcv)) ok = false;
-        d[c] = dcv;
         iv[c] = ba_rcp(dcv);
+        double lc[6], oc[6];
 #pragma unroll
         for (int r = c + 1; r < 6; ++r) {
-          double v = a[6 * r + c];
-#pragma unroll
-          for (int p = 0; p < c; ++p) v -= a[6 * r + p] * a[6 * c + p] * d[p];
-          a[6 * r + c] = v * iv[c];
+          oc[r] = a[6 * r + c];  // l_rc d_c
+          lc[r] = oc[r] * iv[c];
+          a[6 * r + c] = lc[r];
         }
+#pragma unroll
+        for (int r = c + 1; r < 6; ++r)
+#pragma unroll
+          for (int q = c + 1; q <= r; ++q) a[6 * r + q] -= lc[r] * oc[q];  // l_rc d_c l_qc
       }
 #pragma unroll
       for (int e = 0; e < 36; ++e) dl[buf][e] = a[e];
@@ -793,33 +805,42 @@ __global__ __launch_bounds__(BA_SOLVE_THREADS) void k_ba_solve(BaParams prm, BaS
     BA_STAMP(1);
     if (bad_flag) break;  // uniform
     if (have && jb == kb && ib > kb) {  // (2) X = A l^-T (row by row), W = X d^-1
+      // column-oriented (entry c final => every later entry of the row takes its product): per row a
+      // dependent chain of 5 FMAs instead of 15
+      double lk[36];
 #pragma unroll
-      for (int r = 0; r < 6; ++r) {
+      for (int c = 1; c < 6; ++c)
 #pragma unroll
-        for (int c = 0; c < 6; ++c) {
-          double v = a[6 * r + c];
+        for (int p = 0; p < c; ++p) lk[6 * c + p] = dl[buf][6 * c + p];
 #pragma unroll
-          for (int p = 0; p < c; ++p) v -= a[6 * r + p] * dl[buf][6 * c + p];
-          a[6 * r + c] = v;
-        }
-      }
+      for (int p = 0; p < 5; ++p)
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+          for (int c = p + 1; c < 6; ++c) a[6 * r + c] -= a[6 * r + p] * lk[6 * c + p];
+      double2* __restrict__ px = reinterpret_cast<double2*>(pubX[buf][ib]);
+#pragma unroll
+      for (int e = 0; e < 18; ++e) px[e] = make_double2(a[2 * e], a[2 * e + 1]);
 #pragma unroll
       for (int r = 0; r < 6; ++r)
 #pragma unroll
-        for (int c = 0; c < 6; ++c) {
-          pubX[buf][ib][6 * r + c] = a[6 * r + c];
-          a[6 * r + c] *= dinvs[buf][c];
-          pubW[buf][ib][6 * r + c] = a[6 * r + c];
-        }
+        for (int c = 0; c < 6; ++c) a[6 * r + c] *= dinvs[buf][c];  // the factor's block: W
     }
     __syncthreads();
     BA_STAMP(2);
     if (have && jb > kb) {  // (3) A_(ib,jb) -= W_ib X_jb^T, both operands read once
-      double x[36], wv[36];
+      double x[36], wv[36], di[6];
+      const double2* __restrict__ xj = reinterpret_cast<const double2*>(pubX[buf][jb]);
+      const double2* __restrict__ xi = reinterpret_cast<const double2*>(pubX[buf][ib]);
 #pragma unroll
-      for (int e = 0; e < 36; ++e) {
-        x[e] = pubX[buf][jb][e];
-        wv[e] = pubW[buf][ib][e];
+      for (int c = 0; c < 6; ++c) di[c] = dinvs[buf][c];
+#pragma unroll
+      for (int e = 0; e < 18; ++e) {
+        const double2 vj = xj[e], vi = xi[e];
+        x[2 * e] = vj.x;
+        x[2 * e + 1] = vj.y;
+        wv[2 * e] = vi.x * di[(2 * e) % 6];
+        wv[2 * e + 1] = vi.y * di[(2 * e + 1) % 6];
       }
 #pragma unroll
       for (int r = 0; r < 6; ++r)
@@ -840,33 +861,66 @@ __global__ __launch_bounds__(BA_SOLVE_THREADS) void k_ba_solve(BaParams prm, BaS
     for (int e = 0; e < 36; ++e) Lf[(size_t)tri(ib, jb) * 36 + e] = a[e];
   }
   __syncthreads();
-  if (!bad) {  // uniform: every thread walks the loop (the barriers inside need all of them)
+  BA_STAMP(6);
+  if (!bad && tid < 64) {
     // Back substitution L^T x = w (w = row 0 of block row M), block row by block row from the
-    // bottom; thread j < n owns component j.  Per block: the 6 x 6 unit-triangular tail is solved by
-    // one thread from LDS, then every thread above the block subtracts its 6 products.
-    const uint32_t j = tid, jb6 = j / 6, jr = j % 6;
-    double y = j < n ? Lf[(size_t)tri(M, jb6) * 36 + jr] : 0.0;
+    // bottom, by wavefront 0 alone and without any exchange through memory: lane l owns components
+    // l, l + 64, l + 128 in registers; the block's 6 values are fetched with v_readlane (their lanes
+    // are wave-uniform), EVERY lane solves the 6 x 6 unit-triangular tail itself, then subtracts the
+    // block's 6 products from its components above it.  LDS is only read (the factor) -- nothing in
+    // the loop waits on a store.
+    const uint32_t lane = tid;
+    uint32_t jj[3], jb6[3], jr[3];
+    double y[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      jj[q] = lane + 64 * q;
+      jb6[q] = jj[q] / 6;
+      jr[q] = jj[q] % 6;
+      y[q] = jj[q] < n ? Lf[(size_t)tri(M, jb6[q]) * 36 + jr[q]] : 0.0;
+    }
     for (int kb = (int)M - 1; kb >= 0; --kb) {
-      if (j < n && (int)jb6 == kb) xs[j] = y;
-      __syncthreads();
-      if (tid == 0) {
-        const double* __restrict__ l = Lf + (size_t)tri(kb, kb) * 36;  // unit lower block: l[6 r + c], r > c
-        double x[6];
+      const double* __restrict__ l = Lf + (size_t)tri(kb, kb) * 36;  // unit lower block: l[6 r + c], r > c
+      // every LDS read of the step is issued up front, unconditionally (lanes without work in this
+      // block row read block (kb, 0) and discard the result): one LDS latency per step
+      double lt[36], lq[3][6];
+      bool act[3];
 #pragma unroll
-        for (int r = 5; r >= 0; --r) {
-          double v = xs[6 * kb + r];
+      for (int q = 0; q < 3; ++q) {
+        act[q] = jj[q] < n && (int)jb6[q] < kb;
+        const double* __restrict__ src = Lf + (size_t)tri(kb, act[q] ? jb6[q] : 0u) * 36 + jr[q];  // L[6 kb + r][j] = src[6 r]
 #pragma unroll
-          for (int r2 = r + 1; r2 < 6; ++r2) v -= l[6 * r2 + r] * x[r2];
-          x[r] = v;
-        }
-#pragma unroll
-        for (int r = 0; r < 6; ++r) xs[6 * kb + r] = x[r];
+        for (int r = 0; r < 6; ++r) lq[q][r] = src[6 * r];
       }
-      __syncthreads();
-      if (j < n && (int)jb6 < kb) {
-        const double* __restrict__ l = Lf + (size_t)tri(kb, jb6) * 36 + jr;  // L[6 kb + r][j] = l[6 r]
 #pragma unroll
-        for (int r = 0; r < 6; ++r) y -= l[6 * r] * xs[6 * kb + r];
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int r2 = r + 1; r2 < 6; ++r2) lt[6 * r2 + r] = l[6 * r2 + r];
+      double x[6];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        const int comp = 6 * kb + r, slot = comp >> 6;  // uniform
+        const double src = slot == 0 ? y[0] : (slot == 1 ? y[1] : y[2]);
+        x[r] = ba_readlane(src, comp & 63);
+      }
+      // column-oriented: as soon as x[k] is final every row above it takes its product, so the
+      // dependent chain is 5 FMAs long instead of 15 (a dependent fp64 FMA costs ~20 cycles here),
+      // and the three y chains advance side by side, newest x first
+      double v[3] = {y[0], y[1], y[2]};
+#pragma unroll
+      for (int k = 5; k >= 0; --k) {
+#pragma unroll
+        for (int r = 0; r < k; ++r) x[r] -= lt[6 * k + r] * x[k];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) v[q] -= lq[q][k] * x[k];
+      }
+#pragma unroll
+      for (int q = 0; q < 3; ++q) y[q] = act[q] ? v[q] : y[q];
+      if (lane < 6) {
+        double xr = x[0];
+#pragma unroll
+        for (int r = 1; r < 6; ++r) xr = lane == (uint32_t)r ? x[r] : xr;
+        xs[6 * kb + lane] = xr;
       }
     }
   }
