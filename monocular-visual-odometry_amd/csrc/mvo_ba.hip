@@ -857,55 +857,46 @@ __global__ __launch_bounds__(BA_SOLVE_THREADS) void k_ba_solve(BaParams prm, BaS
   __syncthreads();
   const bool bad = bad_flag != 0;
   if (have && !bad) {
+    // diagonal blocks: strictly lower part only (see the back substitution)
 #pragma unroll
-    for (int e = 0; e < 36; ++e) Lf[(size_t)tri(ib, jb) * 36 + e] = a[e];
+    for (int e = 0; e < 36; ++e) Lf[(size_t)tri(ib, jb) * 36 + e] = (ib == jb && e % 6 >= e / 6) ? 0.0 : a[e];
   }
   __syncthreads();
   BA_STAMP(6);
   if (!bad && tid < 64) {
     // Back substitution L^T x = w (w = row 0 of block row M), block row by block row from the
-    // bottom, by wavefront 0 alone and without any exchange through memory: lane l owns components
-    // l, l + 64, l + 128 in registers; the block's 6 values are fetched with v_readlane (their lanes
-    // are wave-uniform), EVERY lane solves the 6 x 6 unit-triangular tail itself, then subtracts the
-    // block's 6 products from its components above it.  LDS is only read (the factor) -- nothing in
-    // the loop waits on a store.
-    const uint32_t lane = tid;
-    uint32_t jj[3], jb6[3], jr[3];
+    // bottom, by wavefront 0 alone and without any exchange through memory.  Lane l owns components
+    // 3l, 3l+1, 3l+2 in registers: block kb lives in lanes 2kb and 2kb+1, whose values every lane
+    // fetches with v_readlane (wave-uniform lane numbers, compile-time register) and solves the
+    // 6 x 6 unit-triangular tail itself.  The dumped diagonal blocks are zero on and above their
+    // diagonal, so the update y_j -= sum_r L[6kb+r][j] x_r applied to the block's OWN components
+    // leaves exactly x_j in them: one formula for every lane with jb <= kb, no selects, and LDS is
+    // only read (the factor).
+    const uint32_t lane = tid, jb_l = lane >> 1, jr0 = 3 * (lane & 1);
+    const bool mine = 3 * lane < n;  // n = 6 M: a lane owns three components or none
     double y[3];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      jj[q] = lane + 64 * q;
-      jb6[q] = jj[q] / 6;
-      jr[q] = jj[q] % 6;
-      y[q] = jj[q] < n ? Lf[(size_t)tri(M, jb6[q]) * 36 + jr[q]] : 0.0;
-    }
+    for (int q = 0; q < 3; ++q) y[q] = mine ? Lf[(size_t)tri(M, jb_l) * 36 + jr0 + q] : 0.0;
     for (int kb = (int)M - 1; kb >= 0; --kb) {
       const double* __restrict__ l = Lf + (size_t)tri(kb, kb) * 36;  // unit lower block: l[6 r + c], r > c
       // every LDS read of the step is issued up front, unconditionally (lanes without work in this
       // block row read block (kb, 0) and discard the result): one LDS latency per step
+      const bool act = mine && (int)jb_l <= kb;
+      const double* __restrict__ src = Lf + (size_t)tri(kb, act ? jb_l : 0u) * 36 + jr0;  // L[6 kb + r][j] = src[6 r + q]
       double lt[36], lq[3][6];
-      bool act[3];
 #pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        act[q] = jj[q] < n && (int)jb6[q] < kb;
-        const double* __restrict__ src = Lf + (size_t)tri(kb, act[q] ? jb6[q] : 0u) * 36 + jr[q];  // L[6 kb + r][j] = src[6 r]
+      for (int r = 0; r < 6; ++r)
 #pragma unroll
-        for (int r = 0; r < 6; ++r) lq[q][r] = src[6 * r];
-      }
+        for (int q = 0; q < 3; ++q) lq[q][r] = src[6 * r + q];
 #pragma unroll
       for (int r = 0; r < 6; ++r)
 #pragma unroll
         for (int r2 = r + 1; r2 < 6; ++r2) lt[6 * r2 + r] = l[6 * r2 + r];
       double x[6];
 #pragma unroll
-      for (int r = 0; r < 6; ++r) {
-        const int comp = 6 * kb + r, slot = comp >> 6;  // uniform
-        const double src = slot == 0 ? y[0] : (slot == 1 ? y[1] : y[2]);
-        x[r] = ba_readlane(src, comp & 63);
-      }
-      // column-oriented: as soon as x[k] is final every row above it takes its product, so the
-      // dependent chain is 5 FMAs long instead of 15 (a dependent fp64 FMA costs ~20 cycles here),
-      // and the three y chains advance side by side, newest x first
+      for (int r = 0; r < 6; ++r) x[r] = ba_readlane(y[r % 3], 2 * kb + r / 3);
+      // column-oriented: as soon as x[k] is final every row above it takes its product, and the
+      // three y chains advance side by side, newest x first
       double v[3] = {y[0], y[1], y[2]};
 #pragma unroll
       for (int k = 5; k >= 0; --k) {
@@ -915,13 +906,11 @@ __global__ __launch_bounds__(BA_SOLVE_THREADS) void k_ba_solve(BaParams prm, BaS
         for (int q = 0; q < 3; ++q) v[q] -= lq[q][k] * x[k];
       }
 #pragma unroll
-      for (int q = 0; q < 3; ++q) y[q] = act[q] ? v[q] : y[q];
-      if (lane < 6) {
-        double xr = x[0];
+      for (int q = 0; q < 3; ++q) y[q] = act ? v[q] : y[q];
+    }
+    if (mine) {
 #pragma unroll
-        for (int r = 1; r < 6; ++r) xr = lane == (uint32_t)r ? x[r] : xr;
-        xs[6 * kb + lane] = xr;
-      }
+      for (int q = 0; q < 3; ++q) xs[3 * lane + q] = y[q];
     }
   }
   __syncthreads();
