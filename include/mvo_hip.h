@@ -225,6 +225,12 @@ uint32_t mvo_hip_num_pairs(uint32_t M, uint32_t N);
 const char *mvo_hip_status_string(int status);
 const char *mvo_hip_version(void);
 
+/* Test aid (no counterpart in the reference): fills the LDS of every CU of `device_ordinal` with NaN
+ * bit patterns and returns when that is done.  LDS is not cleared between kernels -- not even between
+ * processes -- so a kernel that reads LDS it never wrote gives results that depend on what ran
+ * before it; the GPU tests call this before every case (tests/conftest.py). */
+int mvo_hip_debug_poison_lds(int device_ordinal);
+
 #ifdef __cplusplus
 }
 #endif

@@ -849,6 +849,16 @@ int do_download(mvo_hip_context* h, mvo_hip_frame* frames, mvo_hip_summary* summ
 // =========================================================================================
 // C ABI
 // =========================================================================================
+// mvo_hip_debug_poison_lds: every workgroup fills its LDS with quiet NaNs and lingers a little so that
+// the launch spreads over all CUs instead of recycling the first few
+__global__ void k_poison_lds(int n_doubles) {
+  extern __shared__ double poison[];
+  for (int i = threadIdx.x; i < n_doubles; i += blockDim.x) poison[i] = __longlong_as_double(0x7ff8dead0000beefLL);
+  __syncthreads();
+  if (poison[(threadIdx.x * 37) % n_doubles] == 0.0) poison[0] = 1.0;  // keeps the stores alive
+  __builtin_amdgcn_s_sleep(64);
+}
+
 extern "C" {
 
 int mvo_hip_create(int device_ordinal, uint32_t max_windows, uint32_t max_frames, uint64_t max_observations,
@@ -1090,5 +1100,16 @@ int mvo_hip_debug_stamps(unsigned long long* out8, int reset) {
 #endif
 
 const char* mvo_hip_version(void) { return "libmvo_hip 0.1 (gfx950)"; }
+
+int mvo_hip_debug_poison_lds(int device_ordinal) {
+  hipDeviceProp_t prop;
+  if (hipSetDevice(device_ordinal) != hipSuccess || hipGetDeviceProperties(&prop, device_ordinal) != hipSuccess)
+    return MVO_HIP_ERR_DEVICE;
+  const int lds_bytes = 64 * 1024;  // two such workgroups share a CU's 160 KB: several rounds cover all of it
+  hipLaunchKernelGGL(k_poison_lds, dim3((unsigned)prop.multiProcessorCount * 16u), dim3(256), lds_bytes, 0,
+                     lds_bytes / 8);
+  if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return MVO_HIP_ERR_DEVICE;
+  return MVO_HIP_OK;
+}
 
 }  // extern "C"

@@ -363,8 +363,8 @@ __device__ int lm_advance_body(LmRegs& r, SH& sh, const SolveParams& prm, int M,
       return 0;
     }
     // TrustRegionStepEvaluator::StepQuality
-    const double rel = (r.se_cur - cost_z) / r.mcc;
-    const double hist = (r.se_ref - cost_z) / (r.se_acc_ref + r.mcc);
+    const double rel = (r.se_cur - cost_z) * fast_rcp(r.mcc);
+    const double hist = (r.se_ref - cost_z) * fast_rcp(r.se_acc_ref + r.mcc);
     it.relative_decrease = fmax(rel, hist);
     it.step_is_valid = 1;
     if (it.relative_decrease > 1e-3) {  // min_relative_decrease
@@ -372,7 +372,7 @@ __device__ int lm_advance_body(LmRegs& r, SH& sh, const SolveParams& prm, int M,
       it.step_is_successful = 1;
       // LevenbergMarquardtStrategy::StepAccepted
       const double q = 2.0 * it.relative_decrease - 1.0;
-      r.radius = r.radius / fmax(1.0 / 3.0, 1.0 - q * q * q);
+      r.radius = r.radius * fast_rcp(fmax(1.0 / 3.0, 1.0 - q * q * q));
       r.radius = fmin(1e16, r.radius);
       r.decf = 2.0;
       r.reuse_diag = 0;
@@ -398,7 +398,7 @@ __device__ int lm_advance_body(LmRegs& r, SH& sh, const SolveParams& prm, int M,
       }
     } else {
       // HandleUnsuccessfulStep + StepRejected
-      r.radius = r.radius / r.decf;
+      r.radius = r.radius * fast_rcp(r.decf);  // a power of two: exact
       r.decf *= 2.0;
       r.reuse_diag = 1;
       it.cost = cost_z;
@@ -486,7 +486,7 @@ __device__ int lm_advance_body(LmRegs& r, SH& sh, const SolveParams& prm, int M,
       for (int j = 0; j < MVO_MAXC; ++j) hrow[j] = Hacc[fl * MVO_MAXC + (fix ? 3 * (j >> 1) + (j & 1) : j)];  // loads first
       gj_setup<0>(a, hrow, r.js, lane, n);
     }
-    const double dd = r.dg / r.radius;
+    const double dd = r.dg * fast_rcp(r.radius);
     if (lane < MVO_MAXC) a_diag_fix(a, lane, (lane < n), dd);
     const double rhs0 = (lane < n) ? r.js * r.g : 0.0;
     MVO_ASTAMP(10);
@@ -719,6 +719,11 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
   // solver state HBM -> LDS (all threads), then the point to evaluate is published by wave 0
   for (int i = tid; i < (int)(sizeof(LmState) / 8); i += NT)
     reinterpret_cast<double*>(&sh.st)[i] = fresh ? 0.0 : reinterpret_cast<const double*>(gst)[i];
+  // The elimination reads whole 15-entry rows of both system buffers; an evaluation writes only the
+  // 3M x 3M corner.  LDS keeps whatever the last workgroup on this CU left there -- a NaN pattern in
+  // an unused column would poison the right-hand side (finite leftovers are harmless: padding rows
+  // are identity rows) -- so the second buffer starts from zero like the first.
+  for (int i = tid; i < MVO_MAXC * MVO_MAXC; i += NT) sh.Hz[i] = 0.0;
   __syncthreads();
   if (wave0) {
     LmState& st = sh.st;

@@ -32,7 +32,7 @@ EXPORTED_SYMBOLS = [
     "mvo_hip_set_profiling",
     "mvo_hip_get_trace", "mvo_hip_get_timing", "mvo_hip_reverse_scale", "mvo_hip_scale",
     "mvo_hip_num_pairs", "mvo_hip_status_string", "mvo_hip_version", "mvo_hip_partial_begin",
-    "mvo_hip_partial_pass", "mvo_hip_partial_advance", "mvo_hip_partial_sums",
+    "mvo_hip_partial_pass", "mvo_hip_partial_advance", "mvo_hip_partial_sums", "mvo_hip_debug_poison_lds",
 ]
 
 
@@ -136,6 +136,7 @@ def load():
         L.mvo_hip_pair_moments.argtypes = [C.c_void_p, C.c_void_p]
         L.mvo_hip_set_trace.argtypes = [C.c_void_p, C.c_int32]
         L.mvo_hip_set_profiling.argtypes = [C.c_void_p, C.c_int]
+        L.mvo_hip_debug_poison_lds.argtypes = [C.c_int]
         L.mvo_hip_partial_begin.argtypes = [C.c_void_p]
         L.mvo_hip_partial_pass.argtypes = [C.c_void_p]
         L.mvo_hip_partial_advance.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
@@ -365,3 +366,10 @@ def reverse_scale(length, highest=2.0, lowest=0.25):
 
 def scale(t, highest=2.0, lowest=0.25):
     return load().mvo_hip_scale(t, highest, lowest)
+
+
+def poison_lds(device=0):
+    """Test aid: NaN patterns into the LDS of every CU (include/mvo_hip.h: mvo_hip_debug_poison_lds)."""
+    rc = load().mvo_hip_debug_poison_lds(device)
+    if rc != 0:
+        raise RuntimeError(f"mvo_hip_debug_poison_lds: status {rc}")

@@ -41,3 +41,15 @@ def solver():
     s = capi.Solver(0)
     yield s
     s.close()
+
+
+@pytest.fixture(autouse=True)
+def _poisoned_lds(request):
+    """Every GPU test starts with NaN patterns in the LDS of all CUs: a kernel that reads LDS it never
+    wrote must not get away with the zeros a fresh box happens to hold (LDS survives kernels AND
+    processes; this is how an unwritten column of k_lm's second system buffer was found)."""
+    if request.node.get_closest_marker("gpu") is not None:
+        from mvo_amd import capi
+
+        capi.poison_lds(0)
+    yield

@@ -93,7 +93,7 @@ def test_track_mirror_equals_host_gathering_adapter(tmp_path, c, use_loss):
     scene.write_track_file(w, tracks, use_loss_function=use_loss, **FIXED10)
     outs = {}
     for mode in ("gather", "refine", "tracks"):
-        outs[mode] = str(tmp_path / f"{mode}.bin")
+        outs[mode] = str(tmp_path / f"out_{mode}.bin")
         subprocess.check_call([EXE, mode, tracks, outs[mode]])
     host_csr = _read_csr(open(outs["gather"], "rb").read(), 0)
     host = open(outs["refine"], "rb").read()
