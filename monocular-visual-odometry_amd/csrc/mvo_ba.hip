@@ -19,6 +19,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include "mvo_alloc.h"
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -1350,7 +1352,7 @@ struct Buf {
     p = nullptr;
     cap = 0;
     const size_t want = bytes + bytes / 8 + 256;
-    hipError_t e = hipMalloc(&p, want);
+    hipError_t e = mvo_device_alloc(&p, want);
     if (e == hipSuccess) cap = want;
     return e;
   }

@@ -17,6 +17,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include "mvo_alloc.h"
+
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -233,7 +235,7 @@ template <class T>
 hipError_t regrow(T*& p, size_t n) {
   if (p) (void)hipFree(p);
   p = nullptr;
-  return hipMalloc((void**)&p, sizeof(T) * n);
+  return mvo_device_alloc((void**)&p, sizeof(T) * n);
 }
 
 unsigned int binom3(unsigned int n) {  // boost::math::binomial_coefficient<double>(n, 3) -> unsigned int
@@ -312,7 +314,7 @@ int mvo_hip_epipolar_create(int device_ordinal, mvo_hip_epipolar_handle* out) {
   h->device = device_ordinal;
   const bool ok = hipSetDevice(device_ordinal) == hipSuccess &&
                   hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess &&
-                  hipMalloc((void**)&h->d_part, sizeof(double) * 6 * kFinalBlocks) == hipSuccess &&
+                  mvo_device_alloc((void**)&h->d_part, sizeof(double) * 6 * kFinalBlocks) == hipSuccess &&
                   hipEventCreate(&h->ev[0]) == hipSuccess && hipEventCreate(&h->ev[1]) == hipSuccess;
   if (!ok) {
     mvo_hip_epipolar_destroy(h);

@@ -7,6 +7,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include "mvo_alloc.h"
+
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -44,7 +46,7 @@ struct DevBuf {
     p = nullptr;
     cap = 0;
     size_t want = bytes + bytes / 8 + 256;
-    hipError_t e = hipMalloc(&p, want);
+    hipError_t e = mvo_device_alloc(&p, want);
     if (e == hipSuccess) cap = want;
     return e;
   }

@@ -24,6 +24,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include "mvo_alloc.h"
+
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -448,9 +450,9 @@ int sc_reserve(mvo_hip_scaler_context* h, uint64_t n) {
   h->d_cand = nullptr;
   h->cap = 0;
   const uint64_t want = n + n / 8 + 64;
-  for (auto& p : h->d_v) SC_TRY(hipMalloc((void**)&p, sizeof(double) * 3 * want));
-  SC_TRY(hipMalloc((void**)&h->d_scales, sizeof(double) * want));
-  SC_TRY(hipMalloc((void**)&h->d_cand, sizeof(unsigned long long) * want));
+  for (auto& p : h->d_v) SC_TRY(mvo_device_alloc((void**)&p, sizeof(double) * 3 * want));
+  SC_TRY(mvo_device_alloc((void**)&h->d_scales, sizeof(double) * want));
+  SC_TRY(mvo_device_alloc((void**)&h->d_cand, sizeof(unsigned long long) * want));
   h->cap = want;
   return MVO_HIP_OK;
 }
@@ -570,7 +572,7 @@ int mvo_hip_scaler_create(int device_ordinal, mvo_hip_scaler_handle* out) {
   h->device = device_ordinal;
   bool ok = hipSetDevice(device_ordinal) == hipSuccess &&
             hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess &&
-            hipMalloc((void**)&h->d_ctl, sizeof(ScalerCtl)) == hipSuccess &&
+            mvo_device_alloc((void**)&h->d_ctl, sizeof(ScalerCtl)) == hipSuccess &&
             hipHostMalloc((void**)&h->h_ctl, sizeof(ScalerCtl), hipHostMallocDefault) == hipSuccess &&
             hipEventCreate(&h->ev[0]) == hipSuccess && hipEventCreate(&h->ev[1]) == hipSuccess &&
             hipEventCreate(&h->ev[2]) == hipSuccess && hipEventCreate(&h->ev[3]) == hipSuccess;

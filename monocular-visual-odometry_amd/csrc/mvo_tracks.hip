@@ -26,6 +26,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include "mvo_alloc.h"
+
 #include <algorithm>
 #include <cstring>
 #include <new>
@@ -304,8 +306,8 @@ int count_pairs(mvo_hip_tracks_context* t, uint32_t M, uint32_t N) {
     t->h_counts = nullptr;
     t->h_offsets = nullptr;
     t->cap_pairs = 0;
-    TR_TRY(hipMalloc((void**)&t->d_counts, sizeof(uint32_t) * (P + 1)));
-    TR_TRY(hipMalloc((void**)&t->d_offsets, sizeof(uint64_t) * (P + 1)));
+    TR_TRY(mvo_device_alloc((void**)&t->d_counts, sizeof(uint32_t) * (P + 1)));
+    TR_TRY(mvo_device_alloc((void**)&t->d_offsets, sizeof(uint64_t) * (P + 1)));
     TR_TRY(hipHostMalloc((void**)&t->h_counts, sizeof(uint32_t) * (P + 1), hipHostMallocDefault));
     TR_TRY(hipHostMalloc((void**)&t->h_offsets, sizeof(uint64_t) * (P + 1), hipHostMallocDefault));
     t->cap_pairs = P;
@@ -328,7 +330,7 @@ int count_pairs(mvo_hip_tracks_context* t, uint32_t M, uint32_t N) {
     if (t->d_cnt) (void)hipFree(t->d_cnt);
     t->d_cnt = nullptr;
     t->cap_cnt = 0;
-    TR_TRY(hipMalloc((void**)&t->d_cnt, sizeof(uint32_t) * cnt_elems));
+    TR_TRY(mvo_device_alloc((void**)&t->d_cnt, sizeof(uint32_t) * cnt_elems));
     t->cap_cnt = cnt_elems;
   }
   if (t->profiling) TR_TRY(hipEventRecord(t->ev[0], s));
@@ -394,13 +396,15 @@ int mvo_hip_tracks_create(mvo_hip_handle solver, uint32_t max_frames, uint32_t m
   t->h_nfeat.assign(max_frames, 0);
   const size_t cells = (size_t)max_frames * max_features;
   const bool ok = hipSetDevice(t->device) == hipSuccess &&
-                  hipMalloc((void**)&t->d_rays, sizeof(double) * 3 * cells) == hipSuccess &&
-                  hipMalloc((void**)&t->d_pre, sizeof(int32_t) * cells) == hipSuccess &&
-                  hipMalloc((void**)&t->d_counter, sizeof(uint32_t) * cells) == hipSuccess &&
-                  hipMalloc((void**)&t->d_pre_in, sizeof(int32_t) * max_features) == hipSuccess &&
-                  hipMalloc((void**)&t->d_rays_in, sizeof(double) * 3 * max_features) == hipSuccess &&
-                  hipMalloc((void**)&t->d_nfeat, sizeof(uint32_t) * max_frames) == hipSuccess &&
-                  hipMemset(t->d_nfeat, 0, sizeof(uint32_t) * max_frames) == hipSuccess;
+                  mvo_device_alloc((void**)&t->d_rays, sizeof(double) * 3 * cells) == hipSuccess &&
+                  mvo_device_alloc((void**)&t->d_pre, sizeof(int32_t) * cells) == hipSuccess &&
+                  mvo_device_alloc((void**)&t->d_counter, sizeof(uint32_t) * cells) == hipSuccess &&
+                  mvo_device_alloc((void**)&t->d_pre_in, sizeof(int32_t) * max_features) == hipSuccess &&
+                  mvo_device_alloc((void**)&t->d_rays_in, sizeof(double) * 3 * max_features) == hipSuccess &&
+                  mvo_device_alloc((void**)&t->d_nfeat, sizeof(uint32_t) * max_frames) == hipSuccess &&
+                  // on the table's stream: the null stream's memset may still be pending when the first push
+                  // (a non-blocking stream, which does not wait for it) writes its feature count
+                  hipMemsetAsync(t->d_nfeat, 0, sizeof(uint32_t) * max_frames, t->stream) == hipSuccess;
   if (!ok) {
     mvo_hip_tracks_destroy(t);
     return MVO_HIP_ERR_DEVICE;
@@ -498,8 +502,8 @@ int mvo_hip_tracks_gather(mvo_hip_tracks_handle t, uint32_t M, uint32_t N, uint6
     t->d_m0 = t->d_m1 = nullptr;
     t->cap_obs = 0;
     const uint64_t want = total + total / 4 + 64;
-    TR_TRY(hipMalloc((void**)&t->d_m0, sizeof(double) * 3 * want));
-    TR_TRY(hipMalloc((void**)&t->d_m1, sizeof(double) * 3 * want));
+    TR_TRY(mvo_device_alloc((void**)&t->d_m0, sizeof(double) * 3 * want));
+    TR_TRY(mvo_device_alloc((void**)&t->d_m1, sizeof(double) * 3 * want));
     t->cap_obs = want;
   }
   rc = fill_pairs(t, M, N, t->d_m0, t->d_m1);
@@ -544,7 +548,7 @@ int mvo_hip_tracks_scale(mvo_hip_tracks_handle t, mvo_hip_scaler_handle scaler, 
     if (t->d_cnt) (void)hipFree(t->d_cnt);
     t->d_cnt = nullptr;
     t->cap_cnt = 0;
-    TR_TRY(hipMalloc((void**)&t->d_cnt, sizeof(uint32_t) * ((size_t)groups + 1)));
+    TR_TRY(mvo_device_alloc((void**)&t->d_cnt, sizeof(uint32_t) * ((size_t)groups + 1)));
     t->cap_cnt = (size_t)groups + 1;
   }
   if (!t->h_total) TR_TRY(hipHostMalloc((void**)&t->h_total, sizeof(uint32_t) * 4, hipHostMallocDefault));

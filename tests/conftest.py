@@ -9,6 +9,11 @@ for p in (os.path.join(ROOT, "monocular-visual-odometry_amd"), os.path.join(ROOT
         sys.path.insert(0, p)
 
 
+# Every device allocation of libmvo_hip.so starts as 0xFF bytes under the tests (csrc/mvo_alloc.h): a
+# kernel must not depend on what hipMalloc happens to hand out.  Inherited by the adapter subprocesses.
+os.environ.setdefault("MVO_HIP_POISON_ALLOC", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     # The shared libraries are build products (git-ignored).  On a fresh checkout compile them
