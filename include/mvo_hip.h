@@ -231,6 +231,12 @@ const char *mvo_hip_version(void);
  * before it; the GPU tests call this before every case (tests/conftest.py). */
 int mvo_hip_debug_poison_lds(int device_ordinal);
 
+/* Test aid: with MVO_HIP_POISON_ALLOC set in the environment every device allocation of the library
+ * starts as 0xFF bytes and carries a 256-byte guard behind its end.  Returns the number of guards
+ * found overwritten so far (at a free, or among the live allocations now; drains the device), or
+ * -1 when the variable is not set. */
+long mvo_hip_debug_check_guards(void);
+
 #ifdef __cplusplus
 }
 #endif

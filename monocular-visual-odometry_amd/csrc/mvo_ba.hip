@@ -1348,7 +1348,7 @@ struct Buf {
   size_t cap = 0;
   hipError_t reserve(size_t bytes) {
     if (bytes <= cap) return hipSuccess;
-    if (p) (void)hipFree(p);
+    if (p) (void)mvo_device_free(p);
     p = nullptr;
     cap = 0;
     const size_t want = bytes + bytes / 8 + 256;
@@ -1357,7 +1357,7 @@ struct Buf {
     return e;
   }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p) (void)mvo_device_free(p);
     p = nullptr;
     cap = 0;
   }

@@ -233,7 +233,7 @@ constexpr uint32_t kFinalBlocks = 256;
 
 template <class T>
 hipError_t regrow(T*& p, size_t n) {
-  if (p) (void)hipFree(p);
+  if (p) (void)mvo_device_free(p);
   p = nullptr;
   return mvo_device_alloc((void**)&p, sizeof(T) * n);
 }
@@ -331,7 +331,7 @@ void mvo_hip_epipolar_destroy(mvo_hip_epipolar_handle h) {
   void* bufs[] = {h->d_mhi, h->d_mt, h->d_hb, h->d_hp, h->d_part, h->d_samples, h->d_hi, h->d_flags,
                   h->d_part_prob, h->d_part_cnt};
   for (void* p : bufs)
-    if (p) (void)hipFree(p);
+    if (p) (void)mvo_device_free(p);
   for (auto& e : h->ev)
     if (e) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);

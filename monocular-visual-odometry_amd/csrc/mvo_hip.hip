@@ -15,6 +15,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
+#include <unordered_map>
 #include <new>
 #include <vector>
 
@@ -25,6 +27,81 @@ static_assert(sizeof(mvo_hip_frame) == MVO_FRAME_DOUBLES * sizeof(double), "fram
 static_assert(sizeof(TraceRec) == sizeof(mvo_hip_iteration), "trace record layout");
 static_assert(sizeof(LmState) % 8 == 0, "LmState is copied as doubles");
 static_assert(MVO_HIP_MAX_REFINE == MVO_MAXM, "M limit");
+
+// ---- csrc/mvo_alloc.h ------------------------------------------------------------------------
+namespace {
+constexpr size_t kGuardBytes = 256;
+constexpr unsigned char kGuardByte = 0xA5;
+struct AllocRegistry {
+  std::mutex mu;
+  std::unordered_map<void*, size_t> live;  // poison mode only: user bytes of every live allocation
+  long violations = 0;
+};
+AllocRegistry& alloc_registry() {
+  static AllocRegistry r;
+  return r;
+}
+bool alloc_poison() {
+  static const bool on = std::getenv("MVO_HIP_POISON_ALLOC") != nullptr;
+  return on;
+}
+// true when the guard behind (p, bytes) is intact; the device must be idle
+bool guard_intact(const void* p, size_t bytes) {
+  unsigned char g[kGuardBytes];
+  if (hipMemcpy(g, static_cast<const char*>(p) + bytes, kGuardBytes, hipMemcpyDeviceToHost) != hipSuccess) return false;
+  for (size_t i = 0; i < kGuardBytes; ++i)
+    if (g[i] != kGuardByte) {
+      std::fprintf(stderr, "libmvo_hip: guard behind a %zu-byte device allocation overwritten at +%zu\n", bytes, i);
+      return false;
+    }
+  return true;
+}
+}  // namespace
+
+hipError_t mvo_device_alloc(void** p, size_t bytes) {
+  if (!alloc_poison()) return hipMalloc(p, bytes);
+  hipError_t e = hipMalloc(p, bytes + kGuardBytes);
+  if (e != hipSuccess) return e;
+  // hipMemset runs on the null stream and may return before it is done; the library's own streams
+  // are non-blocking ones that do not wait for it: drain the device before handing the memory out
+  e = hipMemset(*p, 0xFF, bytes);
+  if (e == hipSuccess) e = hipMemset(static_cast<char*>(*p) + bytes, kGuardByte, kGuardBytes);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) {
+    (void)hipFree(*p);
+    *p = nullptr;
+    return e;
+  }
+  AllocRegistry& r = alloc_registry();
+  std::lock_guard<std::mutex> lock(r.mu);
+  r.live[*p] = bytes;
+  return hipSuccess;
+}
+
+hipError_t mvo_device_free(void* p) {
+  if (alloc_poison() && p) {
+    AllocRegistry& r = alloc_registry();
+    size_t bytes = 0;
+    bool known = false;
+    {
+      std::lock_guard<std::mutex> lock(r.mu);
+      auto it = r.live.find(p);
+      if (it != r.live.end()) {
+        known = true;
+        bytes = it->second;
+        r.live.erase(it);
+      }
+    }
+    if (known) {
+      (void)hipDeviceSynchronize();
+      if (!guard_intact(p, bytes)) {
+        std::lock_guard<std::mutex> lock(r.mu);
+        ++r.violations;
+      }
+    }
+  }
+  return hipFree(p);
+}
 
 namespace {
 
@@ -42,7 +119,7 @@ struct DevBuf {
   size_t cap = 0;
   hipError_t reserve(size_t bytes) {
     if (bytes <= cap) return hipSuccess;
-    if (p) (void)hipFree(p);
+    if (p) (void)mvo_device_free(p);
     p = nullptr;
     cap = 0;
     size_t want = bytes + bytes / 8 + 256;
@@ -51,7 +128,7 @@ struct DevBuf {
     return e;
   }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p) (void)mvo_device_free(p);
     p = nullptr;
     cap = 0;
   }
@@ -1102,6 +1179,17 @@ int mvo_hip_debug_stamps(unsigned long long* out8, int reset) {
 #endif
 
 const char* mvo_hip_version(void) { return "libmvo_hip 0.1 (gfx950)"; }
+
+long mvo_hip_debug_check_guards(void) {
+  if (!alloc_poison()) return -1;
+  if (hipDeviceSynchronize() != hipSuccess) return -2;
+  AllocRegistry& r = alloc_registry();
+  std::lock_guard<std::mutex> lock(r.mu);
+  long bad = r.violations;
+  for (const auto& kv : r.live)
+    if (!guard_intact(kv.first, kv.second)) ++bad;
+  return bad;
+}
 
 int mvo_hip_debug_poison_lds(int device_ordinal) {
   hipDeviceProp_t prop;

@@ -441,11 +441,11 @@ namespace {
 int sc_reserve(mvo_hip_scaler_context* h, uint64_t n) {
   if (n <= h->cap) return MVO_HIP_OK;
   for (auto& p : h->d_v) {
-    if (p) (void)hipFree(p);
+    if (p) (void)mvo_device_free(p);
     p = nullptr;
   }
-  if (h->d_scales) (void)hipFree(h->d_scales);
-  if (h->d_cand) (void)hipFree(h->d_cand);
+  if (h->d_scales) (void)mvo_device_free(h->d_scales);
+  if (h->d_cand) (void)mvo_device_free(h->d_cand);
   h->d_scales = nullptr;
   h->d_cand = nullptr;
   h->cap = 0;
@@ -590,10 +590,10 @@ void mvo_hip_scaler_destroy(mvo_hip_scaler_handle h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (auto& p : h->d_v)
-    if (p) (void)hipFree(p);
-  if (h->d_scales) (void)hipFree(h->d_scales);
-  if (h->d_cand) (void)hipFree(h->d_cand);
-  if (h->d_ctl) (void)hipFree(h->d_ctl);
+    if (p) (void)mvo_device_free(p);
+  if (h->d_scales) (void)mvo_device_free(h->d_scales);
+  if (h->d_cand) (void)mvo_device_free(h->d_cand);
+  if (h->d_ctl) (void)mvo_device_free(h->d_ctl);
   if (h->h_ctl) (void)hipHostFree(h->h_ctl);
   for (auto& e : h->ev)
     if (e) (void)hipEventDestroy(e);

@@ -297,8 +297,8 @@ int count_pairs(mvo_hip_tracks_context* t, uint32_t M, uint32_t N) {
   TR_TRY(hipSetDevice(t->device));
   const uint32_t P = num_pairs(M, N);
   if (P > t->cap_pairs) {
-    if (t->d_counts) (void)hipFree(t->d_counts);
-    if (t->d_offsets) (void)hipFree(t->d_offsets);
+    if (t->d_counts) (void)mvo_device_free(t->d_counts);
+    if (t->d_offsets) (void)mvo_device_free(t->d_offsets);
     if (t->h_counts) (void)hipHostFree(t->h_counts);
     if (t->h_offsets) (void)hipHostFree(t->h_offsets);
     t->d_counts = nullptr;
@@ -327,7 +327,7 @@ int count_pairs(mvo_hip_tracks_context* t, uint32_t M, uint32_t N) {
   t->g_sp = SP;
   const size_t cnt_elems = (size_t)M * groups * SP;
   if (cnt_elems > t->cap_cnt) {
-    if (t->d_cnt) (void)hipFree(t->d_cnt);
+    if (t->d_cnt) (void)mvo_device_free(t->d_cnt);
     t->d_cnt = nullptr;
     t->cap_cnt = 0;
     TR_TRY(mvo_device_alloc((void**)&t->d_cnt, sizeof(uint32_t) * cnt_elems));
@@ -420,7 +420,7 @@ void mvo_hip_tracks_destroy(mvo_hip_tracks_handle t) {
   void* bufs[] = {t->d_rays, t->d_pre, t->d_counter, t->d_nfeat, t->d_counts, t->d_pre_in, t->d_offsets, t->d_m0, t->d_m1,
                   t->d_cnt, t->d_rays_in};
   for (void* p : bufs)
-    if (p) (void)hipFree(p);
+    if (p) (void)mvo_device_free(p);
   if (t->h_counts) (void)hipHostFree(t->h_counts);
   if (t->h_offsets) (void)hipHostFree(t->h_offsets);
   if (t->h_total) (void)hipHostFree(t->h_total);
@@ -497,8 +497,8 @@ int mvo_hip_tracks_gather(mvo_hip_tracks_handle t, uint32_t M, uint32_t N, uint6
   if (capacity < total) return MVO_HIP_ERR_INVALID_ARGUMENT;
   if (total == 0) return MVO_HIP_OK;
   if (total > t->cap_obs) {
-    if (t->d_m0) (void)hipFree(t->d_m0);
-    if (t->d_m1) (void)hipFree(t->d_m1);
+    if (t->d_m0) (void)mvo_device_free(t->d_m0);
+    if (t->d_m1) (void)mvo_device_free(t->d_m1);
     t->d_m0 = t->d_m1 = nullptr;
     t->cap_obs = 0;
     const uint64_t want = total + total / 4 + 64;
@@ -545,7 +545,7 @@ int mvo_hip_tracks_scale(mvo_hip_tracks_handle t, mvo_hip_scaler_handle scaler, 
   const uint32_t n = t->h_nfeat[(t->head + t->max_frames - age) % t->max_frames];
   const uint32_t groups = (n + 63) / 64;
   if ((size_t)groups + 1 > t->cap_cnt) {
-    if (t->d_cnt) (void)hipFree(t->d_cnt);
+    if (t->d_cnt) (void)mvo_device_free(t->d_cnt);
     t->d_cnt = nullptr;
     t->cap_cnt = 0;
     TR_TRY(mvo_device_alloc((void**)&t->d_cnt, sizeof(uint32_t) * ((size_t)groups + 1)));

@@ -33,6 +33,7 @@ EXPORTED_SYMBOLS = [
     "mvo_hip_get_trace", "mvo_hip_get_timing", "mvo_hip_reverse_scale", "mvo_hip_scale",
     "mvo_hip_num_pairs", "mvo_hip_status_string", "mvo_hip_version", "mvo_hip_partial_begin",
     "mvo_hip_partial_pass", "mvo_hip_partial_advance", "mvo_hip_partial_sums", "mvo_hip_debug_poison_lds",
+    "mvo_hip_debug_check_guards",
 ]
 
 
@@ -137,6 +138,8 @@ def load():
         L.mvo_hip_set_trace.argtypes = [C.c_void_p, C.c_int32]
         L.mvo_hip_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.mvo_hip_debug_poison_lds.argtypes = [C.c_int]
+        L.mvo_hip_debug_check_guards.argtypes = []
+        L.mvo_hip_debug_check_guards.restype = C.c_long
         L.mvo_hip_partial_begin.argtypes = [C.c_void_p]
         L.mvo_hip_partial_pass.argtypes = [C.c_void_p]
         L.mvo_hip_partial_advance.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
@@ -373,3 +376,8 @@ def poison_lds(device=0):
     rc = load().mvo_hip_debug_poison_lds(device)
     if rc != 0:
         raise RuntimeError(f"mvo_hip_debug_poison_lds: status {rc}")
+
+
+def guard_violations():
+    """Test aid: overwritten allocation guards so far (-1: MVO_HIP_POISON_ALLOC is not set)."""
+    return int(load().mvo_hip_debug_check_guards())

@@ -52,9 +52,14 @@ def solver():
 def _poisoned_lds(request):
     """Every GPU test starts with NaN patterns in the LDS of all CUs: a kernel that reads LDS it never
     wrote must not get away with the zeros a fresh box happens to hold (LDS survives kernels AND
-    processes; this is how an unwritten column of k_lm's second system buffer was found)."""
+    processes; this is how an unwritten column of k_lm's second system buffer was found), and ends
+    with a check of the guards behind the library's device allocations (csrc/mvo_alloc.h)."""
     if request.node.get_closest_marker("gpu") is not None:
         from mvo_amd import capi
 
         capi.poison_lds(0)
+        yield
+        # ... and no kernel of the test wrote past the end of a device allocation (256-byte guards)
+        assert capi.guard_violations() == 0
+        return
     yield
