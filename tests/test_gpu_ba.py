@@ -31,6 +31,10 @@ SCENES = {
     "spans_28_free": lambda: ba_scene.make_ba_scene(30, 28, 600, seed=8, span=12),
     "mostly_fixed": lambda: ba_scene.make_ba_scene(40, 6, 500, seed=9, span=10),
     "long_tracks": lambda: ba_scene.make_ba_scene(100, 5, 64, seed=10),  # 100 observations per landmark
+    # more frames than the kernels stage in LDS: k_ba_step reads poses through L2 from 257 frames on,
+    # k_ba_schur / k_ba_fixed from 513 on
+    "frames_300": lambda: ba_scene.make_ba_scene(300, 7, 900, seed=12, span=30),
+    "frames_600": lambda: ba_scene.make_ba_scene(600, 9, 1500, seed=13, span=25),
 }
 
 
