@@ -105,6 +105,7 @@ typedef struct mvo_hip_observations {
 #define MVO_HIP_REASON_MIN_RADIUS 5
 #define MVO_HIP_REASON_INVALID_STEPS 6
 #define MVO_HIP_REASON_LINEAR_SOLVER 7
+#define MVO_HIP_REASON_EVALUATION_FAILED 8 /* non-finite residuals at the initial point: FAILURE before any step */
 
 typedef struct mvo_hip_summary {
   int32_t termination;           /* MVO_HIP_CONVERGENCE / NO_CONVERGENCE / FAILURE */

@@ -335,7 +335,21 @@ __device__ int lm_advance_body(LmRegs& r, SH& sh, const SolveParams& prm, int M,
 
   bool take_z = false;
   const bool first = (r.phase == PH_EVAL_X0);
-  const double cost_z = sh.cost_z;
+  // Ceres 1.14 rejects non-finite residuals (ResidualBlock::Evaluate / IsEvaluationValid): at the
+  // initial point the minimizer fails before any step; a candidate that "failed to evaluate" gets
+  // cost = max and is rejected.  A NaN/Inf residual makes the summed cost non-finite.
+  const double cost_z = (first || isfinite(sh.cost_z)) ? sh.cost_z : DBL_MAX;
+  if (first && !isfinite(cost_z)) {
+    r.iteration = 0;
+    r.ntrace = 1;  // iteration 0 is the one (failed) record: summary.iterations = 0
+    it.cost = cost_z;
+    if (trace && lane == 0 && prm.trace_cap > 0) trace[0] = it;
+    r.nsucc = r.nunsucc = 0;
+    r.initial_cost = r.final_cost = cost_z;
+    r.bv[0] = r.xv[0]; r.bv[1] = r.xv[1]; r.bv[2] = r.xv[2]; r.bt = r.xt;  // written back untouched
+    lm_terminate(r, 2, 8);
+    return 0;
+  }
   if (first) {
     // IterationZero
     take_z = true;

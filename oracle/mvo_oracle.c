@@ -726,6 +726,24 @@ int32_t mvo_oracle_refine(mvo_oracle_frame *frames, uint32_t M, uint32_t N,
   /* ---- IterationZero + EvaluateGradientAndJacobian ---- */
   x_norm = point_diff_norm(&c, &x, NULL, 0);
   x_cost = evaluate(&c, (const double(*)[3])x.vecs, x.t, 0, res, J, grad);
+  if (!isfinite(x_cost)) {
+    /* Ceres 1.14: ResidualBlock::Evaluate rejects non-finite residuals (IsEvaluationValid), so
+     * TrustRegionMinimizer::IterationZero fails: "Residual and Jacobian evaluation failed." =>
+     * FAILURE before any step; the reference logs it and writes the untouched parameters back
+     * (IR.cpp:235-246) */
+    S.termination = MVO_ORACLE_FAILURE;
+    S.reason = MVO_ORACLE_REASON_EVALUATION_FAILED;
+    S.initial_cost = S.final_cost = x_cost;
+    for (uint32_t k = 0; k < M; k++) {
+      frames[k].scale = mvo_oracle_scale(x.t[k], opt->highest_length, opt->lowest_length);
+      for (int j = 0; j < 3; j++) frames[k].vec[j] = x.vecs[k][j];
+    }
+    if (summary) *summary = S;
+    if (trace_len) *trace_len = 0;
+    free(J);
+    free(res);
+    return 0;
+  }
   for (int j = 0; j < n; j++) {
     double s2 = 0.0;
     for (uint64_t i = 0; i < m; i++) s2 += J[i * n + j] * J[i * n + j];
@@ -833,6 +851,7 @@ int32_t mvo_oracle_refine(mvo_oracle_frame *frames, uint32_t M, uint32_t N,
     /* ---- ComputeCandidatePointAndEvaluateCost ---- */
     point_plus(&c, &x, delta, &cand);
     double cand_cost = evaluate(&c, (const double(*)[3])cand.vecs, cand.t, 0, NULL, NULL, NULL);
+    if (!isfinite(cand_cost)) cand_cost = DBL_MAX; /* Ceres: "Step failed to evaluate" => candidate_cost_ = max */
 
     /* ---- ParameterToleranceReached ---- */
     it.step_norm = point_diff_norm(&c, &x, &cand, 0);

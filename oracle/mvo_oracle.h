@@ -75,7 +75,8 @@ enum {
   MVO_ORACLE_REASON_FUNCTION_TOLERANCE = 4,
   MVO_ORACLE_REASON_MIN_RADIUS = 5,
   MVO_ORACLE_REASON_INVALID_STEPS = 6,
-  MVO_ORACLE_REASON_LINEAR_SOLVER = 7
+  MVO_ORACLE_REASON_LINEAR_SOLVER = 7,
+  MVO_ORACLE_REASON_EVALUATION_FAILED = 8 /* non-finite residuals at the initial point */
 };
 
 typedef struct {

@@ -3,6 +3,15 @@ import sys
 
 import pytest
 
+try:
+    # torch's wheel carries its own copy of the HIP runtime.  In one process it has to come up BEFORE
+    # the system runtime that libmvo_hip.so links (the other order leaves torch with "No HIP GPUs are
+    # available"), so it is imported here, ahead of any fixture that touches the library -- a full
+    # run imports it during collection anyway, a single test file would not.
+    import torch  # noqa: F401
+except ImportError:  # the CPU-only checks do not need it
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (os.path.join(ROOT, "monocular-visual-odometry_amd"), os.path.join(ROOT, "oracle"), os.path.dirname(__file__)):
     if p not in sys.path:

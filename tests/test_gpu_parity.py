@@ -298,3 +298,31 @@ def test_handle_reuse_across_shapes_and_modes(oracle):
                 assert x.iterations == y.iterations == z.iterations and x.final_cost == y.final_cost == z.final_cost
             if k == 3:
                 assert np.abs(np.asarray(part_frames) - np.asarray(fa)).max() < 1e-9
+
+
+@pytest.mark.parametrize("shape", ["inline", "tiled"])
+@pytest.mark.parametrize("use_loss", [False, True])
+def test_non_finite_and_degenerate_rays_end_with_a_verdict(solver, oracle, shape, use_loss):
+    """Ceres answers NaN residuals with FAILURE and the reference writes the parameters back anyway
+    (IR.cpp:235-246).  Here: a NaN ray, and all rays identical (every c = 0: nothing to minimise),
+    must come back promptly with a termination verdict -- no hang, no device error -- on the
+    single-launch path and on the tiled passes, and the handle must work afterwards."""
+    w = scene.make_window(6, 3, 60, seed=77) if shape == "inline" else scene.make_window(10, 5, 400, seed=78)
+    mode = capi.ASSEMBLY_AUTO if shape == "inline" else capi.ASSEMBLY_TILED
+    kw = dict(use_loss_function=use_loss, **FIXED10)
+    bad = scene.Window(**{**w.__dict__, "m0": w.m0.copy(), "m1": w.m1.copy()})
+    bad.m1[len(bad.m1) // 2, 1] = np.nan
+    f, s = solver.refine(bad, capi.make_options(assembly_mode=mode, **kw))
+    fo, so, _ = oracle.refine(bad, oracle.make_options(**kw))
+    assert s.termination == so.termination == 2 and s.reason == so.reason == 8  # FAILURE: evaluation failed
+    assert s.iterations == so.iterations == 0
+    assert np.array_equal(f[w.M:], w.frames[w.M:])
+    # untouched parameters go back (the scale through s(reverseScale(n)): equal to rounding)
+    assert np.array_equal(f[:w.M, 9:12], w.frames[:w.M, 9:12]) and np.allclose(f[:w.M, 12], w.frames[:w.M, 12], rtol=1e-14)
+    assert np.array_equal(f[:w.M, 9:12], fo[:w.M, 9:12])
+    flat = scene.Window(**{**w.__dict__, "m0": np.tile(w.m0[:1], (len(w.m0), 1)), "m1": np.tile(w.m0[:1], (len(w.m1), 1))})
+    f, s = solver.refine(flat, capi.make_options(assembly_mode=mode, **kw))
+    assert s.termination in (0, 1, 2) and s.iterations <= 10
+    good, sg = solver.refine(w, capi.make_options(assembly_mode=mode, **kw))
+    go, so, _ = oracle.refine(w, oracle.make_options(**kw))
+    assert np.abs(refined(good, w.M) - refined(go, w.M)).max() < TOL_FINAL
