@@ -126,3 +126,20 @@ def test_error_behaviour(ba):
     ba.solve()
     poses, X, s = ba.download()
     assert s.iterations == 0 and s.termination == 1 and np.array_equal(X, sc.X)
+
+
+def test_non_finite_observation_ends_as_failure_like_the_oracle(ba):
+    """A NaN bearing: no valid step exists; both sides give up after five invalid steps (FAILURE) and
+    hand the poses and landmarks back untouched and finite."""
+    sc = ba_scene.make_ba_scene(8, 5, 120, seed=3, span=6)
+    sc.obs_ray[17, 1] = np.nan
+    kw = dict(max_num_iterations=8, **FIXED)
+    poses, X, s = ba.refine(sc, ba_capi.make_options(**kw))
+    po, Xo, so, _ = bo.refine(sc, bo.make_options(**kw))
+    assert s.termination == so.termination == 2 and s.iterations == so.iterations
+    assert np.array_equal(poses, sc.poses) and np.array_equal(po, sc.poses)
+    assert np.array_equal(X, sc.X) and np.array_equal(Xo, sc.X)
+    good = ba_scene.make_ba_scene(8, 5, 120, seed=3, span=6)  # and the handle still works
+    poses, X, s = ba.refine(good, ba_capi.make_options(**kw))
+    po, Xo, so, _ = bo.refine(good, bo.make_options(**kw))
+    assert s.termination == so.termination and np.abs(poses - po).max() < 1e-6
