@@ -184,6 +184,25 @@ __device__ unsigned long long mvo_ba_stamps[16];
 #define BA_STAMP(i) do { } while (0)
 #endif
 
+// global -> LDS copy of n doubles (n even, both 16-byte aligned) by all nt threads: 16-byte loads, four
+// in flight per thread before the first store (a one-load-per-iteration loop pays the L2 latency per
+// iteration)
+__device__ __forceinline__ void ba_stage_lds(double* dst, const double* __restrict__ src, uint32_t n, uint32_t tid,
+                                             uint32_t nt) {
+  const double2* __restrict__ s2 = reinterpret_cast<const double2*>(src);
+  double2* d2 = reinterpret_cast<double2*>(dst);
+  const uint32_t n2 = n / 2;
+  uint32_t i = tid;
+  for (; i + 3 * nt < n2; i += 4 * nt) {
+    const double2 a = s2[i], b = s2[i + nt], c = s2[i + 2 * nt], d = s2[i + 3 * nt];
+    d2[i] = a;
+    d2[i + nt] = b;
+    d2[i + 2 * nt] = c;
+    d2[i + 3 * nt] = d;
+  }
+  for (; i < n2; i += nt) d2[i] = s2[i];
+}
+
 struct SchurHdr {  // per staged landmark
   double gl[3];
   int32_t n_free, pad;
@@ -225,7 +244,7 @@ __global__ __launch_bounds__(BA_SCHUR_THREADS) void k_ba_schur(BaParams prm, con
   const double* __restrict__ Xs = X2 + (size_t)cur * 3 * prm.L;
   const uint32_t g = blockIdx.x;
   if (POSES_IN_LDS) {
-    for (int i = tid; i < 12 * prm.N; i += BA_SCHUR_THREADS) lds_poses[i] = poses_g[i];
+    ba_stage_lds(lds_poses, poses_g, 12 * (uint32_t)prm.N, (uint32_t)tid, BA_SCHUR_THREADS);
     __syncthreads();
   }
   const double* poses = POSES_IN_LDS ? lds_poses : poses_g;
@@ -490,7 +509,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_fixed(BaParams prm, const BaS
   const double inv_radius = 1.0 / radius;
   const double* __restrict__ poses_g = poses2 + (size_t)cur * 12 * prm.N;
   if (POSES_IN_LDS) {
-    for (uint32_t i = tid; i < 12 * (uint32_t)prm.N; i += BA_THREADS) lds_poses_f[i] = poses_g[i];
+    ba_stage_lds(lds_poses_f, poses_g, 12 * (uint32_t)prm.N, (uint32_t)tid, BA_THREADS);
     __syncthreads();
   }
   const double* poses = POSES_IN_LDS ? lds_poses_f : poses_g;
@@ -1090,7 +1109,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_step_g(BaParams prm, const Ba
   const uint32_t sub = tid & (G - 1), grp = tid / G;
   const int cur = st->cur;
   if (POSES_IN_LDS) {  // the pose of an observation's frame is then one LDS read behind the frame index
-    for (uint32_t i = tid; i < 24 * (uint32_t)prm.N; i += BA_THREADS) lds_poses2[i] = poses2[i];
+    ba_stage_lds(lds_poses2, poses2, 24 * (uint32_t)prm.N, (uint32_t)tid, BA_THREADS);
     __syncthreads();
   }
   const double* pbase = POSES_IN_LDS ? lds_poses2 : poses2;
