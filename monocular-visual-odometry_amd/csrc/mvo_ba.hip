@@ -40,6 +40,9 @@
 #define BA_STAGE 51                      // doubles per free observation in a wave's LDS stage:
                                          // E(18) Y(18) sqrt(w) J_c(12) sqrt(w) r(2) frame(1)
 #define BA_SOLVE_THREADS 512
+#ifndef BA_PREFETCH
+#define BA_PREFETCH 4  // rounds of observations in flight per lane in k_ba_fixed / k_ba_step_g
+#endif
 #define BA_NOSLOT 0xFFFFu
 
 struct BaParams {
@@ -530,33 +533,49 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_fixed(BaParams prm, const BaS
       X[2] = Xs[3 * lm + 2];
     }
     double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // C(6) gl(3)
-    uint32_t word_n = 0;  // the next round's observation is in flight while this one is evaluated
-    double2 uv_n = make_double2(0.0, 0.0);
-    if (sub < T) {
-      word_n = obs_frame[o0 + sub];
-      uv_n = obs_uv[o0 + sub];
+    // BA_PREFETCH rounds of observations are in flight per lane, each in a register slot of its own
+    // (consumed and refilled in place: no copies, so the compiler waits only for the slot it
+    // needs).  The loop is bound by memory concurrency: 16 wavefronts per CU with one round each in
+    // flight sustain ~2 TB/s.  The loads are UNCONDITIONAL, at an index clamped to the landmark's
+    // last observation (the arrays hold one spare element): a load inside a divergent `if` is
+    // waited for on the spot.
+    const uint32_t t_last = T ? T - 1 : 0;
+    uint32_t word_q[BA_PREFETCH];
+    double2 uv_q[BA_PREFETCH];
+#pragma unroll
+    for (int d = 0; d < BA_PREFETCH; ++d) {
+      const uint32_t t = sub + d * G;
+      const uint32_t tc = t < t_last ? t : t_last;
+      word_q[d] = obs_frame[o0 + tc];
+      uv_q[d] = obs_uv[o0 + tc];
     }
-    for (uint32_t t = sub; __ballot(t < T) != 0ull; t += G) {  // wavefront-uniform trip count
-      const uint32_t f = word_n & 0xFFFFu;
-      const double2 uv = uv_n;
-      if (t + G < T) {
-        word_n = obs_frame[o0 + t + G];
-        uv_n = obs_uv[o0 + t + G];
-      }
-      if (t < T) {
-        BaObs e;
-        ba_obs_eval(poses + 12 * f, X, uv.x, uv.y, prm.loss, prm.loss_scale, e);
-        cost_acc += 0.5 * e.rho;
-        const double w = e.w;
-        acc[0] += w * (e.jx[0] * e.jx[0] + e.jx[3] * e.jx[3]);
-        acc[1] += w * (e.jx[0] * e.jx[1] + e.jx[3] * e.jx[4]);
-        acc[2] += w * (e.jx[0] * e.jx[2] + e.jx[3] * e.jx[5]);
-        acc[3] += w * (e.jx[1] * e.jx[1] + e.jx[4] * e.jx[4]);
-        acc[4] += w * (e.jx[1] * e.jx[2] + e.jx[4] * e.jx[5]);
-        acc[5] += w * (e.jx[2] * e.jx[2] + e.jx[5] * e.jx[5]);
-        acc[6] += w * (e.jx[0] * e.r0 + e.jx[3] * e.r1);
-        acc[7] += w * (e.jx[1] * e.r0 + e.jx[4] * e.r1);
-        acc[8] += w * (e.jx[2] * e.r0 + e.jx[5] * e.r1);
+    for (uint32_t t0 = sub; __ballot(t0 < T) != 0ull; t0 += BA_PREFETCH * G) {  // wavefront-uniform trip count
+#pragma unroll
+      for (int d = 0; d < BA_PREFETCH; ++d) {
+        const uint32_t t = t0 + d * G;
+        const uint32_t f = word_q[d] & 0xFFFFu;
+        const double2 uv = uv_q[d];
+        {
+          const uint32_t tn = t + BA_PREFETCH * G;
+          const uint32_t tc = tn < t_last ? tn : t_last;
+          word_q[d] = obs_frame[o0 + tc];
+          uv_q[d] = obs_uv[o0 + tc];
+        }
+        if (t < T) {
+          BaObs e;
+          ba_obs_eval(poses + 12 * f, X, uv.x, uv.y, prm.loss, prm.loss_scale, e);
+          cost_acc += 0.5 * e.rho;
+          const double w = e.w;
+          acc[0] += w * (e.jx[0] * e.jx[0] + e.jx[3] * e.jx[3]);
+          acc[1] += w * (e.jx[0] * e.jx[1] + e.jx[3] * e.jx[4]);
+          acc[2] += w * (e.jx[0] * e.jx[2] + e.jx[3] * e.jx[5]);
+          acc[3] += w * (e.jx[1] * e.jx[1] + e.jx[4] * e.jx[4]);
+          acc[4] += w * (e.jx[1] * e.jx[2] + e.jx[4] * e.jx[5]);
+          acc[5] += w * (e.jx[2] * e.jx[2] + e.jx[5] * e.jx[5]);
+          acc[6] += w * (e.jx[0] * e.r0 + e.jx[3] * e.r1);
+          acc[7] += w * (e.jx[1] * e.r0 + e.jx[4] * e.r1);
+          acc[8] += w * (e.jx[2] * e.r0 + e.jx[5] * e.r1);
+        }
       }
     }
 #pragma unroll
@@ -1180,27 +1199,43 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_step_g(BaParams prm, const Ba
     }
     const double* pp = mode == 1 ? posesc : poses;
     {
-      uint32_t word_n = 0;
-      double2 uv_n = make_double2(0.0, 0.0);
-      if (sub < T) {
-        word_n = obs_frame[o0 + sub];
-        uv_n = obs_uv[o0 + sub];
+      // BA_PREFETCH rounds of observations are in flight per lane, each in a register slot of its own
+      // (consumed and refilled in place: no copies, so the compiler waits only for the slot it
+      // needs).  The loop is bound by memory concurrency: 16 wavefronts per CU with one round each in
+      // flight sustain ~2 TB/s.  The loads are UNCONDITIONAL, at an index clamped to the landmark's
+      // last observation (the arrays hold one spare element): a load inside a divergent `if` is
+      // waited for on the spot.
+      const uint32_t t_last = T ? T - 1 : 0;
+      uint32_t word_q[BA_PREFETCH];
+      double2 uv_q[BA_PREFETCH];
+#pragma unroll
+      for (int d = 0; d < BA_PREFETCH; ++d) {
+        const uint32_t t = sub + d * G;
+        const uint32_t tc = t < t_last ? t : t_last;
+        word_q[d] = obs_frame[o0 + tc];
+        uv_q[d] = obs_uv[o0 + tc];
       }
-      for (uint32_t t = sub; __ballot(t < T) != 0ull; t += G) {
-        const uint32_t f = word_n & 0xFFFFu;
-        const double2 uv = uv_n;
-        if (t + G < T) {
-          word_n = obs_frame[o0 + t + G];
-          uv_n = obs_uv[o0 + t + G];
-        }
-        if (t < T) {
-          double a, b, c;
-          ba_project(pp + 12 * f, Xn, a, b, c);
-          const double ic = ba_rcp(c);
-          const double r0 = a * ic - uv.x, r1 = b * ic - uv.y;
-          double rho, w;
-          ba_loss(prm.loss, prm.loss_scale, r0 * r0 + r1 * r1, rho, w);
-          cost_acc += 0.5 * rho;
+      for (uint32_t t0 = sub; __ballot(t0 < T) != 0ull; t0 += BA_PREFETCH * G) {  // wavefront-uniform trip count
+#pragma unroll
+        for (int d = 0; d < BA_PREFETCH; ++d) {
+          const uint32_t t = t0 + d * G;
+          const uint32_t f = word_q[d] & 0xFFFFu;
+          const double2 uv = uv_q[d];
+          {
+            const uint32_t tn = t + BA_PREFETCH * G;
+            const uint32_t tc = tn < t_last ? tn : t_last;
+            word_q[d] = obs_frame[o0 + tc];
+            uv_q[d] = obs_uv[o0 + tc];
+          }
+          if (t < T) {
+            double a, b, c;
+            ba_project(pp + 12 * f, Xn, a, b, c);
+            const double ic = ba_rcp(c);
+            const double r0 = a * ic - uv.x, r1 = b * ic - uv.y;
+            double rho, w;
+            ba_loss(prm.loss, prm.loss_scale, r0 * r0 + r1 * r1, rho, w);
+            cost_acc += 0.5 * rho;
+          }
         }
       }
     }
