@@ -796,10 +796,12 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
         if (tid < P) pair_load(in0, tid, N, M, unit_slots != 0, wp, partial, win.pair_off, fr);
         have0 = !prm.pass_mode;
       }
+      // unconditional, at a clamped pair index: a load inside a divergent `if` is waited for on the
+      // spot, which would serialise the rounds' L2 latencies instead of overlapping them
 #pragma unroll
       for (int rr = 1; rr < ROUNDS; ++rr) {
         const int p = tid + rr * NT;
-        if (p < P) pair_load(in[rr], p, N, M, unit_slots != 0, wp, partial, win.pair_off, fr);
+        pair_load(in[rr], p < P ? p : P - 1, N, M, unit_slots != 0, wp, partial, win.pair_off, fr);
       }
       if (tid < P) pair_eval(in0, sh, M, prm.pass_mode, pairbuf + (size_t)tid * 10);
 #pragma unroll
