@@ -297,8 +297,10 @@ __global__ __launch_bounds__(256) void k_scaler_hist(uint64_t n, const double* _
     for (int j = 0; j < 4; ++j) {  // four loads in flight per thread
       const uint64_t i = base + j * 256 + threadIdx.x;
       valid[j] = i < count;
-      k[j] = 0;
-      if (valid[j]) k[j] = FROM_SCALES ? sc_key(scales[i]) : cand[i];
+      // unconditional, at a clamped index (count > 0 inside this loop): a load inside a divergent `if`
+      // is waited for on the spot, which serialises the four
+      const uint64_t ic = valid[j] ? i : count - 1;
+      k[j] = FROM_SCALES ? sc_key(scales[ic]) : cand[ic];
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -340,7 +342,7 @@ __global__ __launch_bounds__(256) void k_scaler_compact(uint64_t n, const double
     for (int j = 0; j < 4; ++j) {  // four loads in flight per thread
       const uint64_t i = base + j * 256 + threadIdx.x;
       valid[j] = i < n;
-      k[j] = valid[j] ? sc_key(scales[i]) : 0ull;
+      k[j] = sc_key(scales[valid[j] ? i : n - 1]);  // unconditional load at a clamped index (n > 0 here)
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
