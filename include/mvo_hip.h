@@ -106,6 +106,7 @@ typedef struct mvo_hip_observations {
 #define MVO_HIP_REASON_INVALID_STEPS 6
 #define MVO_HIP_REASON_LINEAR_SOLVER 7
 #define MVO_HIP_REASON_EVALUATION_FAILED 8 /* non-finite residuals at the initial point: FAILURE before any step */
+#define MVO_HIP_REASON_BAD_INPUT 9         /* mvo_hip_refine_noalloc: device-side pair_offsets inconsistent */
 
 typedef struct mvo_hip_summary {
   int32_t termination;           /* MVO_HIP_CONVERGENCE / NO_CONVERGENCE / FAILURE */
@@ -217,6 +218,33 @@ int mvo_hip_get_trace(mvo_hip_handle h, mvo_hip_iteration *rows, int32_t capacit
  * (IterativeRefinement.cpp:231-234). */
 int mvo_hip_set_profiling(mvo_hip_handle h, int enabled);
 int mvo_hip_get_timing(mvo_hip_handle h, mvo_hip_timing *out);
+
+/* The one entry point that allocates nothing.  NO COUNTERPART IN THE REFERENCE: it exists for
+ * callers that cannot allocate -- code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc.  It is mvo_hip_refine for ONE window with every buffer in device memory:
+ * frames_device[N] in/out (records [0, M) receive the refined vec and scale, as
+ * IterativeRefinement.cpp:240-246), pair_offsets_device[P + 1], m0_device / m1_device
+ * [3 * n_blocks], summary_device (may be NULL); options is host memory, read before the call
+ * returns.  Three kernel launches are queued on `stream` (a hipStream_t; NULL = the null stream) of
+ * device `device_ordinal`; the call does not wait for them, copies nothing and calls no hipMalloc,
+ * hipFree or any other allocating routine.  All working memory (pair tables, per-pair sums, solver
+ * state, result record) lives in one file-scope device array of MVO_HIP_NOALLOC_SCRATCH_BYTES that
+ * every GPU the library runs on holds until the process ends.  Limits, rejected with
+ * MVO_HIP_ERR_UNSUPPORTED: N <= MVO_HIP_MAX_FRAMES, M <= MVO_HIP_MAX_REFINE,
+ * n_blocks <= MVO_HIP_NOALLOC_MAX_BLOCKS (the window is solved by one workgroup).  n_blocks must
+ * equal pair_offsets_device[P]; that, and the offsets being non-decreasing from 0, is checked on
+ * the device: on a mismatch no ray is read, the frames stay untouched and the summary reports
+ * MVO_HIP_FAILURE / MVO_HIP_REASON_BAD_INPUT.  The initial t = reverseScale(scale) is evaluated with
+ * the device's log instead of the host's (mvo_hip_refine), so results agree with mvo_hip_refine to
+ * rounding, not bit for bit.  Every call on a GPU shares that GPU's array: calls that overlap on
+ * one GPU (two streams, two threads) race; calls queued on one stream do not.  The first call on a
+ * device resolves the array's address (hipGetSymbolAddress) -- make it outside graph capture. */
+#define MVO_HIP_NOALLOC_SCRATCH_BYTES (192 * 1024)
+#define MVO_HIP_NOALLOC_MAX_BLOCKS (1u << 22)
+int mvo_hip_refine_noalloc(int device_ordinal, void *stream, mvo_hip_frame *frames_device, uint32_t M,
+                           uint32_t N, const mvo_hip_options *options, const uint64_t *pair_offsets_device,
+                           const double *m0_device, const double *m1_device, uint64_t n_blocks,
+                           mvo_hip_summary *summary_device);
 
 /* scalar helpers exported for bindings and tests (host code, libm):
  * reverseScale (IterativeRefinement.cpp:348-368) and scaleTemplated<double> (:298-309). */

@@ -58,6 +58,9 @@ bool guard_intact(const void* p, size_t bytes) {
 }
 }  // namespace
 
+// resolves this device's address of the no-alloc entry point's scratch array (defined at the end of the file)
+hipError_t mvo_noalloc_resolve(int device);
+
 hipError_t mvo_device_alloc(void** p, size_t bytes) {
   if (!alloc_poison()) return hipMalloc(p, bytes);
   hipError_t e = hipMalloc(p, bytes + kGuardBytes);
@@ -951,7 +954,8 @@ int mvo_hip_create(int device_ordinal, uint32_t max_windows, uint32_t max_frames
   if (!h) return MVO_HIP_ERR_OUT_OF_MEMORY;
   h->device = device_ordinal;
   if (hipSetDevice(device_ordinal) != hipSuccess ||
-      hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+      hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+      mvo_noalloc_resolve(device_ordinal) != hipSuccess) {  // the library's set-up call: scratch address, once per device
     delete h;
     return MVO_HIP_ERR_DEVICE;
   }
@@ -1203,3 +1207,221 @@ int mvo_hip_debug_poison_lds(int device_ordinal) {
 }
 
 }  // extern "C"
+
+// =========================================================================================
+// mvo_hip_refine_noalloc: the one entry point that allocates nothing (include/mvo_hip.h).
+// Same kernels as mvo_hip_refine's single-launch path (k_lm with the window's own observation
+// passes); everything those kernels keep beyond the caller's inputs and outputs -- window and pair
+// tables, the initial point, per-pair sums, LM state, result record, status / done words -- lives
+// in ONE file-scope device array.  Host code never passes the array's name to a kernel: its
+// address on a device is resolved once per device with hipGetSymbolAddress and kept.
+// =========================================================================================
+namespace {
+constexpr uint32_t kNoallocMaxPairs = MVO_MAXM * (MVO_HIP_MAX_FRAMES - 1) - (MVO_MAXM * (MVO_MAXM - 1)) / 2;
+constexpr size_t na_align(size_t x) { return (x + 255) & ~(size_t)255; }
+constexpr size_t kNaWin = 0;                                                    // WinDev
+constexpr size_t kNaCtl = na_align(kNaWin + sizeof(WinDev));                    // int32: status, done, bad
+constexpr size_t kNaResult = na_align(kNaCtl + 3 * 64);                         // LmResult
+constexpr size_t kNaState = na_align(kNaResult + sizeof(LmResult));             // LmState
+constexpr size_t kNaInitX = na_align(kNaState + sizeof(LmState));               // MVO_MAXM x (vec, t)
+constexpr size_t kNaPairs = na_align(kNaInitX + sizeof(double) * 4 * MVO_MAXM); // PairDev[P]
+constexpr size_t kNaSums = na_align(kNaPairs + sizeof(PairDev) * kNoallocMaxPairs);  // 8 doubles per pair
+constexpr size_t kNaEnd = na_align(kNaSums + sizeof(double) * 8 * kNoallocMaxPairs);
+static_assert(kNaEnd <= MVO_HIP_NOALLOC_SCRATCH_BYTES, "scratch layout exceeds the declared size");
+constexpr int kNaMaxDevices = 64;
+}  // namespace
+
+static __device__ __align__(256) unsigned char scratch[MVO_HIP_NOALLOC_SCRATCH_BYTES];
+
+namespace {
+struct NoallocDevice {
+  unsigned char* ptr = nullptr;  // this device's copy of `scratch`
+  size_t lm_dyn[2] = {0, 0};     // dynamic LDS already granted to k_lm<64> / k_lm<256> here
+};
+NoallocDevice g_noalloc[kNaMaxDevices];
+std::mutex g_noalloc_mu;
+
+// once per device, with that device current
+hipError_t noalloc_setup(int device, NoallocDevice** out) {
+  if (device < 0 || device >= kNaMaxDevices) return hipErrorInvalidDevice;
+  std::lock_guard<std::mutex> lock(g_noalloc_mu);
+  NoallocDevice& d = g_noalloc[device];
+  if (!d.ptr) {
+    void* p = nullptr;
+    hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    if (!p) return hipErrorInvalidSymbol;
+    d.ptr = static_cast<unsigned char*>(p);
+  }
+  *out = &d;
+  return hipSuccess;
+}
+
+}  // namespace
+
+hipError_t mvo_noalloc_resolve(int device) {
+  NoallocDevice* d = nullptr;
+  return noalloc_setup(device, &d);
+}
+
+namespace {
+// IR.cpp:348-368 on the device (one clamp step instead of the recursion: the clamped value lies
+// strictly inside the interval unless the interval itself is degenerate)
+__device__ double d_reverse_scale(double length, double max_len, double min_len) {
+  const double eps = DBL_EPSILON;
+  if (length <= min_len) length = min_len + (length * eps) + eps;
+  else if (length >= max_len) length = max_len - (length * eps + eps);
+  return -1.0 * log((max_len - length) / (length - min_len));
+}
+
+// tables of the one window, built where they are used: what do_upload builds on the host
+__global__ __launch_bounds__(256) void k_noalloc_prep(unsigned char* sc, const double* __restrict__ frames,
+                                                      const uint64_t* __restrict__ offs, uint32_t M, uint32_t N,
+                                                      uint32_t P, uint64_t n_blocks, double max_len, double min_len) {
+  __shared__ int bad_s;
+  const int tid = threadIdx.x;
+  if (tid == 0) bad_s = 0;
+  __syncthreads();
+  int bad = 0;
+  for (uint32_t p = tid; p < P; p += 256)
+    if (offs[p + 1] < offs[p] || offs[p + 1] > n_blocks) bad = 1;
+  if (tid == 0 && (offs[0] != 0 || offs[P] != n_blocks)) bad = 1;
+  if (bad) bad_s = 1;
+  __syncthreads();
+  const bool ok = bad_s == 0;
+  PairDev* pairs = reinterpret_cast<PairDev*>(sc + kNaPairs);
+  for (uint32_t p = tid; p < P; p += 256) {
+    int a, b;
+    pair_ab((int)N, (int)M, (int)p, a, b);
+    PairDev pd;
+    pd.slot_begin = p;
+    pd.slot_end = p + 1;
+    pd.a = (uint32_t)a;
+    pd.b = (uint32_t)b;
+    pd.src_start = ok ? (uint32_t)offs[p] : 0u;
+    pd.count = ok ? (uint32_t)(offs[p + 1] - offs[p]) : 0u;  // inconsistent offsets: nothing is read
+    pairs[p] = pd;
+  }
+  if (tid < (int)M) {
+    double* x = reinterpret_cast<double*>(sc + kNaInitX) + 4 * tid;
+    const double* f = frames + MVO_FRAME_DOUBLES * tid;
+    x[0] = f[9];
+    x[1] = f[10];
+    x[2] = f[11];
+    x[3] = d_reverse_scale(f[12], max_len, min_len);  // IR.cpp:102
+  }
+  if (tid == 0) {
+    WinDev w{};
+    w.frame_off = 0;
+    w.pair_off = 0;
+    w.N = N;
+    w.M = M;
+    w.P = P;
+    *reinterpret_cast<WinDev*>(sc + kNaWin) = w;
+    int32_t* ctl = reinterpret_cast<int32_t*>(sc + kNaCtl);
+    ctl[0] = 0;         // window status
+    ctl[16] = 0;        // done counter
+    ctl[32] = bad_s;    // inconsistent pair_offsets
+  }
+}
+
+// IR.cpp:240-246 on the device: refined vec / scale into the caller's frames, summary out
+__global__ void k_noalloc_finish(const unsigned char* sc, double* __restrict__ frames, uint32_t M,
+                                 mvo_hip_summary* __restrict__ summary) {
+  const LmResult* r = reinterpret_cast<const LmResult*>(sc + kNaResult);
+  const int32_t* ctl = reinterpret_cast<const int32_t*>(sc + kNaCtl);
+  const bool bad = ctl[32] != 0 || ctl[0] == 0;  // bad offsets, or the window never terminated
+  const int k = threadIdx.x;
+  if (!bad && k < (int)M) {
+    double* f = frames + MVO_FRAME_DOUBLES * k;
+    f[9] = r->vec[k][0];
+    f[10] = r->vec[k][1];
+    f[11] = r->vec[k][2];
+    f[12] = r->scale[k];
+  }
+  if (k == 0 && summary) {
+    mvo_hip_summary s;
+    s.termination = bad ? MVO_HIP_FAILURE : r->termination;
+    s.reason = bad ? MVO_HIP_REASON_BAD_INPUT : r->reason;
+    s.iterations = bad ? 0 : r->iterations;
+    s.num_successful_steps = bad ? 0 : r->nsucc;
+    s.num_unsuccessful_steps = bad ? 0 : r->nunsucc;
+    s.reserved = 0;
+    s.initial_cost = bad ? 0.0 : r->initial_cost;
+    s.final_cost = bad ? 0.0 : r->final_cost;
+    *summary = s;
+  }
+}
+}  // namespace
+
+int mvo_hip_refine_noalloc(int device_ordinal, void* stream, mvo_hip_frame* frames_device, uint32_t M, uint32_t N,
+                           const mvo_hip_options* options, const uint64_t* pair_offsets_device,
+                           const double* m0_device, const double* m1_device, uint64_t n_blocks,
+                           mvo_hip_summary* summary_device) {
+  if (!frames_device || !options || !pair_offsets_device) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  if (M == 0 || N <= M) return MVO_HIP_ERR_INVALID_ARGUMENT;   // IR.cpp:29-30
+  if (M > MVO_HIP_MAX_REFINE) return MVO_HIP_ERR_UNSUPPORTED;  // IR.cpp:450
+  if (N > MVO_HIP_MAX_FRAMES) return MVO_HIP_ERR_UNSUPPORTED;  // beyond the scratch array's pair tables
+  if (n_blocks > MVO_HIP_NOALLOC_MAX_BLOCKS) return MVO_HIP_ERR_UNSUPPORTED;
+  if (n_blocks > 0 && (!m0_device || !m1_device)) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  if (options->max_num_iterations < 0 || !(options->highest_length > options->lowest_length))
+    return MVO_HIP_ERR_INVALID_ARGUMENT;
+  if (hipSetDevice(device_ordinal) != hipSuccess) return MVO_HIP_ERR_DEVICE;
+  NoallocDevice* dev = nullptr;
+  if (noalloc_setup(device_ordinal, &dev) != hipSuccess) return MVO_HIP_ERR_DEVICE;
+  unsigned char* sc = dev->ptr;  // never the array's name: that is a host-side stand-in
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const uint32_t P = num_pairs(M, N);
+
+  SolveParams prm{};
+  prm.ftol = options->function_tolerance;
+  prm.gtol = options->gradient_tolerance;
+  prm.ptol = options->parameter_tolerance;
+  prm.min_len = options->lowest_length;
+  prm.max_len = options->highest_length;
+  prm.max_it = options->max_num_iterations;
+  prm.use_loss = options->use_loss_function ? 1 : 0;
+  prm.fix_length = options->fix_length ? 1 : 0;
+  prm.pass_mode = (options->use_loss_function || (options->assembly_mode & MVO_HIP_ASSEMBLY_PASSES)) ? 1 : 0;
+  prm.trace_cap = 0;
+  prm.inline_eval = 1;  // the window's workgroup runs its own observation passes: one launch
+  prm.fresh = 1;        // k_lm starts from a zero state of its own: nothing of the last call is read
+  prm.win_base = 0;
+
+  const double* fr = reinterpret_cast<const double*>(frames_device);
+  hipLaunchKernelGGL(k_noalloc_prep, dim3(1), dim3(256), 0, s, sc, fr, pair_offsets_device, M, N, P, n_blocks,
+                     prm.max_len, prm.min_len);
+  if (hipGetLastError() != hipSuccess) return MVO_HIP_ERR_DEVICE;
+
+  const size_t dyn = sizeof(double) * 10 * (size_t)P;
+  const bool small = P <= 64;
+  {
+    std::lock_guard<std::mutex> lock(g_noalloc_mu);
+    size_t& configured = dev->lm_dyn[small ? 0 : 1];
+    if (dyn > configured) {
+      const void* fn = small ? reinterpret_cast<const void*>(&k_lm<64>) : reinterpret_cast<const void*>(&k_lm<256>);
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess)
+        return MVO_HIP_ERR_DEVICE;
+      configured = dyn;
+    }
+  }
+  const WinDev* wins = reinterpret_cast<const WinDev*>(sc + kNaWin);
+  const PairDev* pairs = reinterpret_cast<const PairDev*>(sc + kNaPairs);
+  double* sums = reinterpret_cast<double*>(sc + kNaSums);
+  int32_t* ctl = reinterpret_cast<int32_t*>(sc + kNaCtl);
+  auto launch = [&](auto kernel, int nt) {
+    hipLaunchKernelGGL(kernel, dim3(1), dim3(nt), dyn, s, prm, 1, wins, fr,
+                       reinterpret_cast<const double*>(sc + kNaInitX), pairs, (const double*)sums, m0_device,
+                       m1_device, sums, reinterpret_cast<LmState*>(sc + kNaState),
+                       reinterpret_cast<LmResult*>(sc + kNaResult), (double*)nullptr, ctl, (TraceRec*)nullptr,
+                       ctl + 16);
+  };
+  if (small) launch(k_lm<64>, 64);
+  else launch(k_lm<256>, 256);
+  if (hipGetLastError() != hipSuccess) return MVO_HIP_ERR_DEVICE;
+
+  hipLaunchKernelGGL(k_noalloc_finish, dim3(1), dim3(64), 0, s, (const unsigned char*)sc,
+                     reinterpret_cast<double*>(frames_device), M, summary_device);
+  if (hipGetLastError() != hipSuccess) return MVO_HIP_ERR_DEVICE;
+  return MVO_HIP_OK;
+}

@@ -33,7 +33,7 @@ EXPORTED_SYMBOLS = [
     "mvo_hip_get_trace", "mvo_hip_get_timing", "mvo_hip_reverse_scale", "mvo_hip_scale",
     "mvo_hip_num_pairs", "mvo_hip_status_string", "mvo_hip_version", "mvo_hip_partial_begin",
     "mvo_hip_partial_pass", "mvo_hip_partial_advance", "mvo_hip_partial_sums", "mvo_hip_debug_poison_lds",
-    "mvo_hip_debug_check_guards",
+    "mvo_hip_debug_check_guards", "mvo_hip_refine_noalloc",
 ]
 
 
@@ -144,6 +144,8 @@ def load():
         L.mvo_hip_partial_pass.argtypes = [C.c_void_p]
         L.mvo_hip_partial_advance.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
         L.mvo_hip_partial_sums.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]
+        L.mvo_hip_refine_noalloc.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(Options),
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         L.mvo_hip_get_trace.argtypes = [C.c_void_p, C.POINTER(Iteration), C.c_int32, C.POINTER(C.c_int32)]
         L.mvo_hip_get_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
         L.mvo_hip_reverse_scale.argtypes = [C.c_double] * 3
@@ -357,6 +359,12 @@ class Solver:
         if rc != OK:
             raise MvoHipError(rc, "mvo_hip_get_timing")
         return {f[0]: getattr(t, f[0]) for f in Timing._fields_}
+
+
+def refine_noalloc(device, stream, frames_ptr, M, N, options, offsets_ptr, m0_ptr, m1_ptr, n_blocks, summary_ptr):
+    """mvo_hip_refine_noalloc on DEVICE pointers (ints); returns the status code, waits for nothing."""
+    return int(load().mvo_hip_refine_noalloc(int(device), stream, frames_ptr, M, N, C.byref(options), offsets_ptr,
+                                             m0_ptr, m1_ptr, int(n_blocks), summary_ptr))
 
 
 def num_pairs(M, N):

@@ -1,0 +1,97 @@
+"""mvo_hip_refine_noalloc (include/mvo_hip.h): the entry point that allocates nothing, against
+mvo_hip_refine on the same windows, through the C ABI.  Device buffers are torch tensors (the
+caller's memory); the entry point itself only queues three kernels on the stream it is given.
+Bar: refined vec / scale within 1e-6 after the fixed iteration count (BASELINE.json north_star; the
+initial t = reverseScale(scale) comes from the device's log instead of the host's, so agreement is
+to rounding, not bit for bit -- measured 1e-12 on well-conditioned windows, 2e-8 on the sliding
+window whose lengths saturate at highestLength, where one ulp in t is amplified), identical
+termination and iteration counts.  Two calls in a row share the scratch array, the second on a smaller window.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from _util import FIXED10, refined
+from mvo_amd import capi, scene
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6
+
+
+def _device_call(torch, w, opt):
+    dev = torch.device("cuda", 0)
+    frames = torch.from_numpy(np.ascontiguousarray(w.frames, dtype=np.float64)).to(dev)
+    offs = torch.from_numpy(np.ascontiguousarray(w.pair_offsets, dtype=np.uint64).view(np.int64)).to(dev)
+    m0 = torch.from_numpy(np.ascontiguousarray(w.m0, dtype=np.float64)).to(dev)
+    m1 = torch.from_numpy(np.ascontiguousarray(w.m1, dtype=np.float64)).to(dev)
+    summ = torch.zeros(C.sizeof(capi.Summary), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    stream = torch.cuda.current_stream().cuda_stream
+    rc = capi.refine_noalloc(0, stream, frames.data_ptr(), w.M, w.N, opt, offs.data_ptr(),
+                             m0.data_ptr() if len(w.m0) else None, m1.data_ptr() if len(w.m1) else None,
+                             w.n_residual_blocks, summ.data_ptr())
+    assert rc == capi.OK, capi.status_string(rc)
+    torch.cuda.synchronize()
+    s = capi.Summary.from_buffer_copy(summ.cpu().numpy().tobytes())
+    return frames.cpu().numpy(), s
+
+
+def _check(torch, solver, w, **kw):
+    opt = capi.make_options(**kw)
+    fe, se = solver.refine(w, opt)           # the existing entry point
+    fn, sn = _device_call(torch, w, opt)     # the one that allocates nothing
+    # with function_tolerance = 0 a FUNCTION_TOLERANCE verdict means "the cost did not change in the
+    # last bit": rounding decides it, so the two entry points may part there (both then sit at the
+    # same point, which the parameter comparison below checks)
+    knife_edge = opt.function_tolerance == 0.0 and 4 in (sn.reason, se.reason)
+    if not knife_edge:
+        assert (sn.termination, sn.reason, sn.iterations) == (se.termination, se.reason, se.iterations), kw
+        assert sn.num_successful_steps == se.num_successful_steps
+    err = float(np.abs(refined(fn, w.M) - refined(fe, w.M)).max())
+    assert err < TOL, (err, kw)
+    assert abs(sn.final_cost - se.final_cost) <= 1e-9 * max(se.initial_cost, 1e-300)
+    assert abs(sn.initial_cost - se.initial_cost) <= 1e-12 * max(se.initial_cost, 1e-300)
+    # frames that are not refined, and every rotation, come back untouched
+    assert np.array_equal(fn[w.M:], w.frames[w.M:]) and np.array_equal(fn[:, :9], w.frames[:, :9])
+
+
+def test_noalloc_matches_refine_twice_second_smaller(solver):
+    import torch
+
+    big = scene.make_window(30, 5, 800, seed=41, span=("sliding", 18))     # 135 pairs: k_lm<256>
+    small = scene.make_window(6, 3, 120, seed=11)                          # 12 pairs: k_lm<64>
+    _check(torch, solver, big, **FIXED10)
+    _check(torch, solver, small, **FIXED10)   # second call, smaller input, same scratch array
+    _check(torch, solver, big, use_loss_function=True, **FIXED10)
+    _check(torch, solver, scene.reference_defaults_window())               # shipped tolerances
+    _check(torch, solver, small, fix_length=True, **FIXED10)
+
+
+def test_noalloc_rejects_sizes_and_inconsistent_offsets(solver):
+    import torch
+
+    w = scene.make_window(6, 3, 120, seed=11)
+    opt = capi.make_options(**FIXED10)
+    one = torch.zeros(64, dtype=torch.float64, device="cuda")
+    p = one.data_ptr()
+    assert capi.refine_noalloc(0, None, p, 3, 257, opt, p, p, p, 10, None) == capi.ERR_UNSUPPORTED
+    assert capi.refine_noalloc(0, None, p, 6, 8, opt, p, p, p, 10, None) == capi.ERR_UNSUPPORTED
+    assert capi.refine_noalloc(0, None, p, 3, 6, opt, p, p, p, (1 << 22) + 1, None) == capi.ERR_UNSUPPORTED
+    assert capi.refine_noalloc(0, None, p, 0, 6, opt, p, p, p, 10, None) == capi.ERR_INVALID_ARGUMENT
+    assert capi.refine_noalloc(0, None, None, 3, 6, opt, p, p, p, 10, None) == capi.ERR_INVALID_ARGUMENT
+    # n_blocks that does not match pair_offsets[P]: verdict on the device, frames untouched
+    dev = torch.device("cuda", 0)
+    frames = torch.from_numpy(np.ascontiguousarray(w.frames)).to(dev)
+    offs = torch.from_numpy(w.pair_offsets.astype(np.uint64).view(np.int64)).to(dev)
+    m0 = torch.from_numpy(np.ascontiguousarray(w.m0)).to(dev)
+    m1 = torch.from_numpy(np.ascontiguousarray(w.m1)).to(dev)
+    summ = torch.zeros(C.sizeof(capi.Summary), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    rc = capi.refine_noalloc(0, None, frames.data_ptr(), w.M, w.N, opt, offs.data_ptr(), m0.data_ptr(), m1.data_ptr(),
+                             w.n_residual_blocks - 1, summ.data_ptr())
+    assert rc == capi.OK
+    torch.cuda.synchronize()
+    s = capi.Summary.from_buffer_copy(summ.cpu().numpy().tobytes())
+    assert (s.termination, s.reason) == (2, 9)
+    assert np.array_equal(frames.cpu().numpy(), w.frames)
