@@ -155,8 +155,11 @@ int mvo_hip_create(int device_ordinal, uint32_t max_windows, uint32_t max_frames
 void mvo_hip_destroy(mvo_hip_handle h);
 
 /* Replaces IterativeRefinement::refine (IterativeRefinement.cpp:15-250) from the solver set-up
- * (:63-109) to the write-back (:240-246): frames[0..M) receive the refined vec and scale, even
- * after FAILURE, exactly as the reference does.  summary may be NULL. */
+ * (:63-109) to the write-back (:240-246): frames[0..M) receive the refined vec and scale.  After
+ * FAILURE (summary.termination == MVO_HIP_FAILURE) Ceres leaves the caller's parameter arrays at
+ * their INITIAL values (the summary is not usable) and the reference writes those back
+ * (:235-246): frames[0..M) then receive vec_0 and s(reverseScale(scale_0)), whatever progress the
+ * solve made before it failed.  summary may be NULL. */
 int mvo_hip_refine(mvo_hip_handle h, mvo_hip_frame *frames, uint32_t M, uint32_t N,
                    const mvo_hip_options *options, const mvo_hip_observations *observations,
                    mvo_hip_summary *summary);

@@ -434,7 +434,10 @@ __device__ int lm_advance_body(LmRegs& r, SH& sh, const SolveParams& prm, int M,
     r.g = lane < n ? sh.gz[fl] : 0.0;
     r.hdiag = lane < n ? Hnew[fl * MVO_MAXC + fl] : 0.0;
     if (first) {
-      r.js = 1.0 / (1.0 + sqrt(r.hdiag));  // jacobi_scaling, fixed at iteration 0
+      // jacobi_scaling, fixed at iteration 0.  Ceres takes the column norm of J, a sum of squares; here
+      // H_ll = G^T W G can come out as -1e-37 for a column the data do not constrain at all (every
+      // baseline parallel to u: P v = 0 up to rounding) -- the square root of that must not be NaN.
+      r.js = 1.0 / (1.0 + sqrt(fmax(r.hdiag, 0.0)));
       r.initial_cost = r.final_cost = r.x_cost;
       r.se_min = r.se_cur = r.se_ref = r.se_cand = r.x_cost;
       r.se_acc_ref = r.se_acc_cand = 0.0;
@@ -1008,11 +1011,17 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
     const LmState& st = sh.st;
     LmResult* __restrict__ res = results + w;
     if (lane < MVO_MAXM) {
-      res->vec[lane][0] = st.b_vec[lane][0];
-      res->vec[lane][1] = st.b_vec[lane][1];
-      res->vec[lane][2] = st.b_vec[lane][2];
-      res->t[lane] = st.b_t[lane];
-      res->scale[lane] = d_scale(st.b_t[lane], prm.max_len, prm.min_len);
+      // Ceres hands the lowest-cost iterate back only when the summary is usable (CONVERGENCE /
+      // NO_CONVERGENCE: Solver::Summary::IsSolutionUsable); after FAILURE the user's arrays keep
+      // their INITIAL values, and IR.cpp:240-246 then writes s(reverseScale(scale_0)) and vec_0.
+      const bool usable = st.termination != 2;
+      const double* __restrict__ x0 = init_x + ((size_t)w * MVO_MAXM + lane) * 4;
+      const double bt = usable ? st.b_t[lane] : x0[3];
+      res->vec[lane][0] = usable ? st.b_vec[lane][0] : x0[0];
+      res->vec[lane][1] = usable ? st.b_vec[lane][1] : x0[1];
+      res->vec[lane][2] = usable ? st.b_vec[lane][2] : x0[2];
+      res->t[lane] = bt;
+      res->scale[lane] = d_scale(bt, prm.max_len, prm.min_len);
     }
     if (lane == 0) {
       res->initial_cost = st.initial_cost;

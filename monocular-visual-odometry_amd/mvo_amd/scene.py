@@ -82,6 +82,7 @@ def make_window(
     init_scale_jitter: float = 0.2,
     min_abs_vx: float = 0.2,
     keep_tracks: bool = False,
+    direction=None,
 ) -> Window:
     """Build one window.
 
@@ -89,6 +90,12 @@ def make_window(
           ("anchored", lo_span, hi_span): alive from the newest frame, length U[lo,hi] |
           ("sliding", length): contiguous spans of `length` frames, start uniform so that about
           half of the landmarks are alive in the newest M frames.
+    direction: None = the parity recipe (|v.x| >= 0.2); (axis, vx) = the chart-singularity stress
+          recipe of SURVEY.md section 7: every frame moves along `axis` ("z": forward motion (0,0,1),
+          "y": (0,1,0)) with the x component of the true AND of the initial direction set to exactly
+          `vx` -- J_loc = [[-2y, 2z], [2x, 0], [0, -2x]] (IterativeRefinement.cpp:282-296,334-346) has
+          rank 1 at x = 0.  The initial guess is the true direction turned about the x axis, which
+          leaves x untouched.
     """
     assert 1 <= M < N
     rng = np.random.Generator(np.random.MT19937(seed))
@@ -99,7 +106,12 @@ def make_window(
         [0.35 + rng.uniform(0.0, 0.3, N), rng.normal(0.0, 0.1, N), np.ones(N)], axis=1
     )
     true_vec = d / np.linalg.norm(d, axis=1, keepdims=True)
-    assert np.all(np.abs(true_vec[:, 0]) >= min_abs_vx - 1e-12)
+    if direction is not None:
+        axis, vx = direction
+        rest = np.sqrt(1.0 - vx * vx)
+        true_vec = np.tile(np.array([vx, 0.0, rest] if axis == "z" else [vx, rest, 0.0]), (N, 1))
+    else:
+        assert np.all(np.abs(true_vec[:, 0]) >= min_abs_vx - 1e-12)
     pos = np.zeros((N + 1, 3))
     for i in range(N):
         pos[i + 1] = pos[i] + true_scale[i] * true_vec[i]
@@ -178,6 +190,13 @@ def make_window(
     frames[:, 12] = true_scale
     for k in range(M):
         frames[k, 9:12] = _rotate_about_random_axis(rng, true_vec[k], np.deg2rad(init_angle_deg))
+        if direction is not None:  # turn about the x axis: the x component stays exactly vx
+            ang = np.deg2rad(init_angle_deg) * (1.0 if rng.random() < 0.5 else -1.0)
+            c, sn = np.cos(ang), np.sin(ang)
+            v = true_vec[k]
+            r = np.array([0.0, c * v[1] - sn * v[2], sn * v[1] + c * v[2]])
+            r *= np.sqrt(1.0 - v[0] * v[0]) / np.linalg.norm(r)
+            frames[k, 9:12] = [v[0], r[1], r[2]]
         s = true_scale[k] * rng.uniform(1.0 - init_scale_jitter, 1.0 + init_scale_jitter)
         frames[k, 12] = float(np.clip(s, LOWEST_LENGTH + 0.01, HIGHEST_LENGTH - 0.01))
 

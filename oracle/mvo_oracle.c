@@ -900,7 +900,11 @@ int32_t mvo_oracle_refine(mvo_oracle_frame *frames, uint32_t M, uint32_t N,
   }
 
   S.final_cost = final_cost;
-  /* IR.cpp:240-246: write back (Ceres leaves the lowest-cost iterate in the user's arrays) */
+  /* IR.cpp:240-246: write back.  Ceres leaves the lowest-cost iterate in the user's arrays when the
+   * summary is usable (Solver::Summary::IsSolutionUsable: CONVERGENCE / NO_CONVERGENCE); after
+   * FAILURE it restores the INITIAL parameter values, so the reference writes
+   * s(reverseScale(scale_0)) and vec_0 back. */
+  if (S.termination == MVO_ORACLE_FAILURE) initial_point(&c, best.vecs, best.t);
   for (uint32_t k = 0; k < M; k++) {
     frames[k].scale = mvo_oracle_scale(best.t[k], opt->highest_length, opt->lowest_length);
     for (int j = 0; j < 3; j++) frames[k].vec[j] = best.vecs[k][j];

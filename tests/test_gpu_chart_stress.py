@@ -1,0 +1,97 @@
+"""Chart-singularity stress ("Hard parts"): J_loc = [[-2y, 2z], [2x, 0], [0, -2x]]
+(IterativeRefinement.cpp:282-296, 334-346) has rank 1 at vec.x = 0 -- forward motion along the camera's
+z axis, the reference's ordinary use.  There the two chart columns of a frame are parallel (or one of
+them vanishes), which is where a solve of the normal equations and Ceres' dense QR of [J; D]
+(IterativeRefinement.cpp:67) part ways.  GPU (through the C ABI) against the oracle's QR on the cost
+sequence, the accept / reject sequence, the radii, the termination verdict and the final values.
+"""
+import numpy as np
+import pytest
+
+from _util import FIXED10, refined
+from mvo_amd import capi, scene
+
+pytestmark = pytest.mark.gpu
+
+VX = [0.0, 1e-12, -1e-12, 1e-6, -1e-6, 1e-3, -1e-3]
+SHAPES = [(4, 1), (3, 2), (6, 3), (8, 4), (10, 5)]
+LONG = dict(max_num_iterations=40, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
+
+
+def _compare(solver, oracle, w, kw, modes=(capi.ASSEMBLY_AUTO, capi.ASSEMBLY_TILED), min_live=0):
+    """Iteration-by-iteration comparison.  Rows are compared while the oracle's cost still changes by
+    more than 1e-7 of itself: once |cost_change| approaches the rounding level of the cost, the
+    relative decrease (hence the radius), accept / reject and a zero-tolerance FUNCTION_TOLERANCE
+    verdict are decided by the last bits in BOTH solvers and carry no information.  The verdict and
+    the iteration count are compared when every row was live."""
+    fo, so, to = oracle.refine(w, oracle.make_options(**kw))
+    c0 = to[0]["cost"]
+    live = next((i for i, b in enumerate(to) if i > 0 and b["step_is_valid"] and abs(b["cost_change"]) <= 1e-7 * b["cost"]),
+                len(to))
+    for mode in modes:
+        solver.set_trace(64)
+        fg, sg = solver.refine(w, capi.make_options(assembly_mode=mode, **kw))
+        tg = solver.trace(64)
+        solver.set_trace(0)
+        tag = (w.meta.get("direction"), w.N, w.M, kw, mode)
+        assert live >= min_live, (tag, live)
+        if live == len(to):
+            assert (sg.termination, sg.reason) == (so.termination, so.reason), tag
+            assert len(tg) == len(to) and sg.iterations == so.iterations, tag
+        assert len(tg) >= live, tag
+        for i, (a, b) in enumerate(zip(tg[:live], to[:live])):
+            assert a["step_is_valid"] == b["step_is_valid"], (tag, i)
+            assert a["step_is_successful"] == b["step_is_successful"], (tag, i)
+            # relative to the larger of the initial cost and the row's own (a rejected step can cost 1e4 x more)
+            assert abs(a["cost"] - b["cost"]) <= 1e-8 * max(c0, abs(b["cost"])), (tag, i, a["cost"], b["cost"])
+            assert abs(a["trust_region_radius"] - b["trust_region_radius"]) <= 1e-5 * b["trust_region_radius"], (tag, i)
+        assert abs(sg.final_cost - so.final_cost) <= 1e-8 * c0, tag
+        assert np.abs(refined(fg, w.M)[:, :3] - refined(fo, w.M)[:, :3]).max() < 1e-6, tag
+        if live == len(to):  # lengths of a window without a fixed frame are a gauge once converged
+            assert np.abs(refined(fg, w.M) - refined(fo, w.M)).max() < 1e-6, tag
+
+
+@pytest.mark.parametrize("axis", ["z", "y"])
+@pytest.mark.parametrize("vx", VX)
+def test_forward_motion_matches_the_qr_oracle(solver, oracle, axis, vx):
+    for N, M in SHAPES:
+        w = scene.make_window(N, M, 120, seed=900 + M, direction=(axis, vx))
+        w.meta["direction"] = (axis, vx)
+        _compare(solver, oracle, w, FIXED10)
+
+
+@pytest.mark.parametrize("axis", ["z", "y"])
+@pytest.mark.parametrize("use_loss,fix", [(True, False), (False, True), (True, True)])
+def test_forward_motion_with_loss_and_fixed_length(solver, oracle, axis, use_loss, fix):
+    for vx in (0.0, 1e-12, -1e-6):
+        for N, M in ((3, 2), (10, 5)):
+            w = scene.make_window(N, M, 150, seed=950 + M, direction=(axis, vx), outlier_fraction=0.2 if use_loss else 0.0)
+            w.meta["direction"] = (axis, vx)
+            _compare(solver, oracle, w, dict(use_loss_function=use_loss, fix_length=fix, **FIXED10))
+
+
+@pytest.mark.parametrize("axis", ["z", "y"])
+def test_forward_motion_long_runs_and_default_tolerances(solver, oracle, axis):
+    """40 iterations with zero tolerances (the radius keeps growing while steps are accepted; rows are
+    compared until the cost has converged to rounding) and the reference's shipped tolerances
+    (mvo.cfg:39-53): same verdict as the QR oracle."""
+    for vx in (0.0, 1e-6):
+        for N, M in ((3, 2), (6, 3), (10, 5)):
+            w = scene.make_window(N, M, 120, seed=970 + M, direction=(axis, vx))
+            w.meta["direction"] = (axis, vx)
+            _compare(solver, oracle, w, LONG, modes=(capi.ASSEMBLY_AUTO,), min_live=8)
+            fo, so, _ = oracle.refine(w, oracle.make_options())
+            fg, sg = solver.refine(w, capi.make_options())
+            assert sg.termination == so.termination and abs(sg.iterations - so.iterations) <= 1
+            assert abs(sg.final_cost - so.final_cost) <= 1e-6 * so.final_cost
+            assert np.abs(refined(fg, w.M)[:, :3] - refined(fo, w.M)[:, :3]).max() < 1e-4
+
+
+def test_noise_free_forward_motion_stays_on_the_singular_chart(solver, oracle):
+    """Without noise the optimum itself has x = 0 for the z axis: column a of J_loc vanishes at
+    (0, 0, 1), column b at (0, 1, 0), at every accepted point."""
+    for axis in "zy":
+        for N, M in ((3, 2), (10, 5)):
+            w = scene.make_window(N, M, 100, seed=990 + M, direction=(axis, 0.0), noise_sigma=0.0)
+            w.meta["direction"] = (axis, 0.0)
+            _compare(solver, oracle, w, FIXED10)

@@ -326,3 +326,44 @@ def test_non_finite_and_degenerate_rays_end_with_a_verdict(solver, oracle, shape
     good, sg = solver.refine(w, capi.make_options(assembly_mode=mode, **kw))
     go, so, _ = oracle.refine(w, oracle.make_options(**kw))
     assert np.abs(refined(good, w.M) - refined(go, w.M)).max() < TOL_FINAL
+
+
+def _rank_one_window(v0, N, M, n=8):
+    """Identity rotations, every residual block the same pair of rays: c = (1, 0, 0) for all of them,
+    r = u_x.  LM drives u_x to 1e-160 and the cost underflows to exactly 0; from there every step has
+    model_cost_change = 0 -- five invalid steps in a row, Ceres' FAILURE, after ~20 accepted steps."""
+    frames = np.zeros((N, 13))
+    frames[:, 0] = frames[:, 4] = frames[:, 8] = 1.0
+    frames[:, 9:12] = np.asarray(v0) / np.linalg.norm(v0)
+    frames[:, 12] = 1.0
+    P = scene.num_pairs(M, N)
+    return scene.Window(N=N, M=M, frames=frames, pair_offsets=np.arange(P + 1, dtype=np.uint64) * n,
+                        m0=np.tile([0.0, 1.0, 0.0], (n * P, 1)), m1=np.tile([0.0, 0.0, 1.0], (n * P, 1)),
+                        true_vec=np.zeros((N, 3)), true_scale=np.zeros(N))
+
+
+@pytest.mark.parametrize("mode", [capi.ASSEMBLY_AUTO, capi.ASSEMBLY_TILED])
+def test_failure_after_progress_writes_the_initial_values_back(solver, oracle, mode):
+    """Ceres copies the solution into the user's arrays only when the summary is usable; after FAILURE
+    they keep their initial values and IR.cpp:240-246 writes vec_0 and s(reverseScale(scale_0)) --
+    not the lowest-cost iterate the solve had reached before it failed.  Whether a given window ends
+    in FAILURE is decided among denormals (the two sides form model_cost_change differently), so a
+    family of windows is run: most must fail on both sides, and every failure must hand the inputs back."""
+    kw = dict(max_num_iterations=60, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
+    rng = np.random.default_rng(5)
+    both = 0
+    for i in range(16):
+        v0 = [rng.uniform(0.05, 0.6), rng.uniform(0.05, 0.6), 0.8]
+        N, M = [(2, 1), (3, 2)][i % 2]
+        w = _rank_one_window(v0, N, M, n=[8, 1, 3, 50][i % 4])
+        fo, so, _ = oracle.refine(w, oracle.make_options(**kw))
+        fg, sg = solver.refine(w, capi.make_options(assembly_mode=mode, **kw))
+        for f, sm in ((fg, sg), (fo, so)):
+            if sm.termination == 2:
+                assert sm.reason == 6 and sm.num_successful_steps > 5 and sm.final_cost < 1e-300  # progress was made ...
+                assert np.array_equal(f[:M, 9:12], w.frames[:M, 9:12])                            # ... and is not handed back
+                assert np.allclose(f[:M, 12], w.frames[:M, 12], rtol=1e-14, atol=0)
+        if sg.termination == 2 and so.termination == 2:
+            both += 1
+            assert sg.iterations == so.iterations and np.array_equal(fg[:M, 9:12], fo[:M, 9:12])
+    assert both >= 10
