@@ -206,6 +206,19 @@ int mvo_hip_eval(mvo_hip_handle h, const mvo_hip_frame *frames, uint32_t M, uint
                  const mvo_hip_options *options, const mvo_hip_observations *observations,
                  double *residuals, double *jacobian, double *cost);
 
+/* The same at an explicit point: point[4 * k .. 4 * k + 3] = (vec_k[3], t_k) for k < M replaces the
+ * initial point (vec from the frames, t = reverseScale(scale)); NULL = mvo_hip_eval.  Lets a test
+ * reach the saturated branch of scaleTemplated (IterativeRefinement.cpp:301-307: exp(-t) infinite =>
+ * s = lowestLength, derivative 0), which reverseScale can never produce (|t| <~ 36). */
+int mvo_hip_eval_at(mvo_hip_handle h, const mvo_hip_frame *frames, uint32_t M, uint32_t N,
+                    const mvo_hip_options *options, const mvo_hip_observations *observations,
+                    const double *point, double *residuals, double *jacobian, double *cost);
+
+/* Test aid: replaces the starting point of window `window` of the last upload (for the solves that
+ * follow, until the next upload) by point[4 * k .. 4 * k + 3] = (vec_k[3], t_k): the only way to
+ * start the LM loop on the saturated branch of scaleTemplated.  A FAILURE hands this point back. */
+int mvo_hip_debug_set_point(mvo_hip_handle h, uint32_t window, const double *point);
+
 /* Debug/parity: per-pair second moments S_p = sum_i c_i c_i^T (xx,xy,xz,yy,yz,zz) of the last
  * upload, window-major, n_windows * n_pairs * 6 doubles. */
 int mvo_hip_pair_moments(mvo_hip_handle h, double *moments);

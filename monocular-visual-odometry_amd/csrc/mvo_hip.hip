@@ -1039,9 +1039,17 @@ int mvo_hip_refine(mvo_hip_handle h, mvo_hip_frame* frames, uint32_t M, uint32_t
 int mvo_hip_eval(mvo_hip_handle h, const mvo_hip_frame* frames, uint32_t M, uint32_t N,
                  const mvo_hip_options* options, const mvo_hip_observations* observations, double* residuals,
                  double* jacobian, double* cost) {
+  return mvo_hip_eval_at(h, frames, M, N, options, observations, nullptr, residuals, jacobian, cost);
+}
+
+int mvo_hip_eval_at(mvo_hip_handle h, const mvo_hip_frame* frames, uint32_t M, uint32_t N,
+                    const mvo_hip_options* options, const mvo_hip_observations* observations, const double* point,
+                    double* residuals, double* jacobian, double* cost) {
   if (!h) return MVO_HIP_ERR_INVALID_ARGUMENT;
   int rc = do_upload(h, 1, frames, M, N, options, observations);
   if (rc != MVO_HIP_OK) return rc;
+  // explicit point (vec_k, t_k): replaces the uploaded initial point; queued behind the upload's copy
+  if (point) HIP_TRY(hipMemcpyAsync(h->t.initx, point, sizeof(double) * 4 * M, hipMemcpyHostToDevice, h->stream));
   const uint64_t n = h->n_obs;
   const bool want_res = residuals || cost;
   if (want_res) HIP_TRY(h->d_res.reserve(sizeof(double) * (n + 1)));
@@ -1070,6 +1078,17 @@ int mvo_hip_eval(mvo_hip_handle h, const mvo_hip_frame* frames, uint32_t M, uint
     for (uint64_t i = 0; i < n; ++i) c += 0.5 * rdst[i] * rdst[i];
     *cost = c;
   }
+  return MVO_HIP_OK;
+}
+
+int mvo_hip_debug_set_point(mvo_hip_handle h, uint32_t window, const double* point) {
+  if (!h || !point) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  if (!h->uploaded) return MVO_HIP_ERR_STATE;
+  if (window >= h->W) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipMemcpyAsync(h->t.initx + (size_t)window * MVO_MAXM * 4, point, sizeof(double) * 4 * h->M,
+                         hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));  // the caller's array may change once this call returns
   return MVO_HIP_OK;
 }
 

@@ -33,7 +33,7 @@ EXPORTED_SYMBOLS = [
     "mvo_hip_get_trace", "mvo_hip_get_timing", "mvo_hip_reverse_scale", "mvo_hip_scale",
     "mvo_hip_num_pairs", "mvo_hip_status_string", "mvo_hip_version", "mvo_hip_partial_begin",
     "mvo_hip_partial_pass", "mvo_hip_partial_advance", "mvo_hip_partial_sums", "mvo_hip_debug_poison_lds",
-    "mvo_hip_debug_check_guards", "mvo_hip_refine_noalloc",
+    "mvo_hip_debug_check_guards", "mvo_hip_refine_noalloc", "mvo_hip_eval_at", "mvo_hip_debug_set_point",
 ]
 
 
@@ -134,6 +134,9 @@ def load():
         L.mvo_hip_download.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Summary)]
         L.mvo_hip_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(Options),
                                    C.POINTER(Observations), C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+        L.mvo_hip_eval_at.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(Options),
+                                      C.POINTER(Observations), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+        L.mvo_hip_debug_set_point.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         L.mvo_hip_pair_moments.argtypes = [C.c_void_p, C.c_void_p]
         L.mvo_hip_set_trace.argtypes = [C.c_void_p, C.c_int32]
         L.mvo_hip_set_profiling.argtypes = [C.c_void_p, C.c_int]
@@ -313,20 +316,30 @@ class Solver:
             raise MvoHipError(ERR_DEVICE, "partitioned solve did not terminate")
 
     # -- debug / parity -------------------------------------------------------------------
-    def evaluate(self, window, options=None):
-        """-> (residuals[n], jacobian[n,3M], cost) at the initial point (raw, no loss)."""
+    def evaluate(self, window, options=None, point=None):
+        """-> (residuals[n], jacobian[n,3M], cost), raw (no loss), at the initial point or at
+        point[M, 4] = (vec, t) per refined frame."""
         opt = options or make_options()
+        pt = None if point is None else np.ascontiguousarray(point, dtype=np.float64).reshape(window.M, 4)
         frames = np.ascontiguousarray(window.frames, dtype=np.float64)
         pk = _Packed([window])
         n = int(window.pair_offsets[-1])
         res = np.zeros(n)
         jac = np.zeros((n, 3 * window.M))
         cost = C.c_double(0.0)
-        rc = self._lib.mvo_hip_eval(self._h, frames.ctypes.data, window.M, window.N, C.byref(opt), pk.arr,
-                                    res.ctypes.data, jac.ctypes.data, C.byref(cost))
+        rc = self._lib.mvo_hip_eval_at(self._h, frames.ctypes.data, window.M, window.N, C.byref(opt), pk.arr,
+                                       None if pt is None else pt.ctypes.data, res.ctypes.data, jac.ctypes.data,
+                                       C.byref(cost))
         if rc != OK:
-            raise MvoHipError(rc, "mvo_hip_eval")
+            raise MvoHipError(rc, "mvo_hip_eval_at")
         return res, jac, cost.value
+
+    def set_point(self, window, point):
+        """Test aid: start window `window` of the last upload at point[M, 4] = (vec, t)."""
+        pt = np.ascontiguousarray(point, dtype=np.float64).reshape(self._M, 4)
+        rc = self._lib.mvo_hip_debug_set_point(self._h, int(window), pt.ctypes.data)
+        if rc != OK:
+            raise MvoHipError(rc, "mvo_hip_debug_set_point")
 
     def pair_moments(self):
         out = np.zeros((self._W * num_pairs(self._M, self._N), 6))

@@ -327,6 +327,24 @@ int32_t mvo_oracle_eval(const mvo_oracle_frame *frames, uint32_t M, uint32_t N,
   return 0;
 }
 
+int32_t mvo_oracle_eval_at(const mvo_oracle_frame *frames, uint32_t M, uint32_t N,
+                           const mvo_oracle_options *opt, const uint64_t *pair_offsets,
+                           const double *m0, const double *m1, const double *point, double *residuals,
+                           double *jacobian, double *cost) {
+  ctx_t c;
+  if (ctx_init(&c, frames, M, N, opt, pair_offsets, m0, m1)) return -1;
+  double vecs[MAXM][3], t[MAXM];
+  initial_point(&c, vecs, t);
+  if (point)
+    for (uint32_t k = 0; k < M; k++) {
+      for (int j = 0; j < 3; j++) vecs[k][j] = point[4 * k + j];
+      t[k] = point[4 * k + 3];
+    }
+  double v = evaluate(&c, (const double(*)[3])vecs, t, 1, residuals, jacobian, NULL);
+  if (cost) *cost = v;
+  return 0;
+}
+
 int32_t mvo_oracle_pair_moments(const mvo_oracle_frame *frames, uint32_t M, uint32_t N,
                                 const uint64_t *off, const double *m0, const double *m1,
                                 double *moments) {
@@ -686,6 +704,15 @@ int32_t mvo_oracle_refine(mvo_oracle_frame *frames, uint32_t M, uint32_t N,
                           const double *m0, const double *m1, mvo_oracle_summary *summary,
                           mvo_oracle_iteration *trace, int32_t trace_capacity,
                           int32_t *trace_len) {
+  return mvo_oracle_refine_from(frames, M, N, opt, pair_offsets, m0, m1, NULL, summary, trace, trace_capacity,
+                                trace_len);
+}
+
+int32_t mvo_oracle_refine_from(mvo_oracle_frame *frames, uint32_t M, uint32_t N,
+                               const mvo_oracle_options *opt, const uint64_t *pair_offsets,
+                               const double *m0, const double *m1, const double *point,
+                               mvo_oracle_summary *summary, mvo_oracle_iteration *trace,
+                               int32_t trace_capacity, int32_t *trace_len) {
   ctx_t c;
   if (ctx_init(&c, frames, M, N, opt, pair_offsets, m0, m1)) return -1;
   const int n = c.ncol;
@@ -708,9 +735,15 @@ int32_t mvo_oracle_refine(mvo_oracle_frame *frames, uint32_t M, uint32_t N,
     return -2;
   }
   double grad[MAXC], jscale_[MAXC], diag[MAXC], lmd[MAXC], step[MAXC], delta[MAXC];
-  point_t x, cand, best, proj;
+  point_t x, cand, best, proj, start;
   initial_point(&c, x.vecs, x.t);
+  if (point) /* test aid: start somewhere reverseScale cannot reach (t = -800: the saturated branch) */
+    for (uint32_t k = 0; k < M; k++) {
+      for (int j = 0; j < 3; j++) x.vecs[k][j] = point[4 * k + j];
+      x.t[k] = point[4 * k + 3];
+    }
   best = x;
+  start = x;
 
   mvo_oracle_summary S;
   memset(&S, 0, sizeof S);
@@ -904,7 +937,7 @@ int32_t mvo_oracle_refine(mvo_oracle_frame *frames, uint32_t M, uint32_t N,
    * summary is usable (Solver::Summary::IsSolutionUsable: CONVERGENCE / NO_CONVERGENCE); after
    * FAILURE it restores the INITIAL parameter values, so the reference writes
    * s(reverseScale(scale_0)) and vec_0 back. */
-  if (S.termination == MVO_ORACLE_FAILURE) initial_point(&c, best.vecs, best.t);
+  if (S.termination == MVO_ORACLE_FAILURE) best = start;
   for (uint32_t k = 0; k < M; k++) {
     frames[k].scale = mvo_oracle_scale(best.t[k], opt->highest_length, opt->lowest_length);
     for (int j = 0; j < 3; j++) frames[k].vec[j] = best.vecs[k][j];

@@ -133,6 +133,12 @@ int32_t mvo_oracle_eval(const mvo_oracle_frame *frames, uint32_t M, uint32_t N,
                         const double *m0, const double *m1, double *residuals,
                         double *jacobian, double *cost);
 
+/* The same at an explicit point: point[4k..4k+3] = (vec_k, t_k); NULL = the initial point. */
+int32_t mvo_oracle_eval_at(const mvo_oracle_frame *frames, uint32_t M, uint32_t N,
+                           const mvo_oracle_options *opt, const uint64_t *pair_offsets,
+                           const double *m0, const double *m1, const double *point, double *residuals,
+                           double *jacobian, double *cost);
+
 /* Same outputs, Jacobian obtained by forward-mode dual numbers pushed through the
  * reference's own expression tree (what Ceres' AutoDiffCostFunction +
  * AutoDiffLocalParameterization compute). */
@@ -156,6 +162,13 @@ int32_t mvo_oracle_refine(mvo_oracle_frame *frames, uint32_t M, uint32_t N,
                           const double *m0, const double *m1, mvo_oracle_summary *summary,
                           mvo_oracle_iteration *trace, int32_t trace_capacity,
                           int32_t *trace_len);
+
+/* The same from an explicit starting point: point[4k..4k+3] = (vec_k, t_k); NULL = mvo_oracle_refine. */
+int32_t mvo_oracle_refine_from(mvo_oracle_frame *frames, uint32_t M, uint32_t N,
+                               const mvo_oracle_options *opt, const uint64_t *pair_offsets,
+                               const double *m0, const double *m1, const double *point,
+                               mvo_oracle_summary *summary, mvo_oracle_iteration *trace,
+                               int32_t trace_capacity, int32_t *trace_len);
 
 #ifdef __cplusplus
 }

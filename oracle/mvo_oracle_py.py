@@ -148,6 +148,23 @@ def evaluate(w, opt=None, autodiff=False):
     return res, jac, cost.value
 
 
+def evaluate_at(w, point, opt=None):
+    """-> (residuals[n], jacobian[n, 3M], cost), raw, at point[M, 4] = (vec, t) per refined frame."""
+    opt = opt or make_options()
+    frames, offs, m0, m1 = _prep(w)
+    pt = np.ascontiguousarray(point, dtype=np.float64).reshape(w.M, 4)
+    n = int(offs[-1])
+    res = np.zeros(n)
+    jac = np.zeros((n, 3 * w.M))
+    cost = C.c_double(0.0)
+    rc = lib().mvo_oracle_eval_at(_p(frames, C.c_double), C.c_uint32(w.M), C.c_uint32(w.N), C.byref(opt),
+                                  _p(offs, C.c_uint64), _p(m0, C.c_double), _p(m1, C.c_double),
+                                  _p(pt, C.c_double), _p(res, C.c_double), _p(jac, C.c_double), C.byref(cost))
+    if rc != 0:
+        raise RuntimeError(f"oracle eval_at failed rc={rc}")
+    return res, jac, cost.value
+
+
 def pair_moments(w):
     frames, offs, m0, m1 = _prep(w)
     out = np.zeros((len(offs) - 1, 6))
@@ -159,17 +176,18 @@ def pair_moments(w):
     return out
 
 
-def refine(w, opt=None, trace_capacity=256):
-    """-> (frames_out[N,13], Summary, trace list of dict)."""
+def refine(w, opt=None, trace_capacity=256, point=None):
+    """-> (frames_out[N,13], Summary, trace list of dict).  point[M, 4] = (vec, t): explicit start."""
     opt = opt or make_options()
     frames, offs, m0, m1 = _prep(w)
     summ = Summary()
     tr = (Iteration * trace_capacity)()
     tl = C.c_int32(0)
-    rc = lib().mvo_oracle_refine(_p(frames, C.c_double), C.c_uint32(w.M), C.c_uint32(w.N),
-                                 C.byref(opt), _p(offs, C.c_uint64), _p(m0, C.c_double),
-                                 _p(m1, C.c_double), C.byref(summ), tr, C.c_int32(trace_capacity),
-                                 C.byref(tl))
+    pt = None if point is None else np.ascontiguousarray(point, dtype=np.float64).reshape(w.M, 4)
+    rc = lib().mvo_oracle_refine_from(_p(frames, C.c_double), C.c_uint32(w.M), C.c_uint32(w.N),
+                                      C.byref(opt), _p(offs, C.c_uint64), _p(m0, C.c_double),
+                                      _p(m1, C.c_double), None if pt is None else _p(pt, C.c_double),
+                                      C.byref(summ), tr, C.c_int32(trace_capacity), C.byref(tl))
     if rc != 0:
         raise RuntimeError(f"oracle refine failed rc={rc}")
     trace = [

@@ -178,3 +178,58 @@ def test_config3_fold_lm_overlap_equals_the_single_pass(solver, oracle):
     # twice in a row on the same handle: the second stream and the events are reused
     f2, s2 = solver.refine_batch(ws, opt)
     assert np.array_equal(f2, fo)
+
+
+def _oracle_threads(oracle):
+    import os
+
+    return max(1, min(16, int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)))
+
+
+@pytest.mark.parametrize("robust", [False, True])
+def test_config4_full_size_against_oracle(solver, oracle, big, robust):
+    """All 9.8 M residual blocks of config 4 (and config 5 at that size: 20 % outliers + Cauchy), fixed
+    10 iterations, GPU against the oracle's per-residual Jacobian + dense QR.  The oracle runs on the
+    box's CPU share (threads change its summation order in the last bits: the bar stays 1e-6)."""
+    w = scene.config4(outlier_fraction=0.2) if robust else big
+    kw = dict(use_loss_function=robust, **FIXED10)
+    solver.set_trace(16)
+    fg, sg = solver.refine(w, capi.make_options(**kw))
+    tg = solver.trace(16)
+    solver.set_trace(0)
+    oracle.set_threads(_oracle_threads(oracle))
+    try:
+        fo, so, to = oracle.refine(w, oracle.make_options(**kw))
+    finally:
+        oracle.set_threads(1)
+    # rows are compared while the cost still changes by more than 1e-7 of itself; past that a
+    # zero-tolerance FUNCTION_TOLERANCE verdict (cost change exactly 0.0) is decided by the last bits
+    live = next((i for i, b in enumerate(to) if i > 0 and abs(b["cost_change"]) <= 1e-7 * b["cost"]), len(to))
+    assert live >= 5 and so.iterations == 10
+    if live == len(to):
+        assert sg.iterations == 10 and (sg.termination, sg.reason) == (so.termination, so.reason)
+    assert sg.iterations >= live - 1
+    assert abs(sg.initial_cost - so.initial_cost) <= 1e-9 * so.initial_cost
+    assert abs(sg.final_cost - so.final_cost) <= 1e-8 * so.initial_cost
+    for a, b in zip(tg[:live], to[:live]):
+        assert a["step_is_successful"] == b["step_is_successful"]
+        assert abs(a["cost"] - b["cost"]) <= 1e-8 * so.initial_cost
+    assert np.abs(refined(fg, 5) - refined(fo, 5)).max() < 1e-6
+    assert np.array_equal(fg[5:], w.frames[5:])
+
+
+def test_config3_all_4096_windows_in_one_batch(solver, oracle):
+    """BASELINE.json configs[2] at its full size: one mvo_hip_refine_batch of 4096 windows; every window
+    terminates at the cap, sampled windows match the oracle, and a window's result does not depend on
+    the batch it is in (same bar as against the oracle: tile sizes change the summation order)."""
+    ws = [scene.config3_window(i) for i in range(4096)]
+    fb, sb = solver.refine_batch(ws, capi.make_options(**FIXED10))
+    assert solver.timing()["lm_launches"] == 4  # the fold / LM overlap path
+    assert all(s.termination in (0, 1) and 6 <= s.iterations <= 10 for s in sb)
+    assert sum(s.iterations == 10 for s in sb) > 2048
+    for i in (0, 1, 1023, 1024, 2047, 2048, 3071, 3072, 4000, 4095):
+        fo, so, _ = oracle.refine(ws[i], oracle.make_options(**FIXED10))
+        assert np.abs(refined(fb[i], 5) - refined(fo, 5)).max() < 1e-6, i
+        assert abs(sb[i].final_cost - so.final_cost) <= 1e-8 * so.initial_cost, i
+        f1, s1 = solver.refine(ws[i], capi.make_options(**FIXED10))
+        assert np.abs(refined(fb[i], 5) - refined(f1, 5)).max() < 1e-6, i

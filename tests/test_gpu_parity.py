@@ -367,3 +367,39 @@ def test_failure_after_progress_writes_the_initial_values_back(solver, oracle, m
             both += 1
             assert sg.iterations == so.iterations and np.array_equal(fg[:M, 9:12], fo[:M, 9:12])
     assert both >= 10
+
+
+# ------------------------------------------------------------------ the saturated branch of scaleTemplated
+@pytest.mark.parametrize("name", ["n6m3", "config1"])
+def test_saturated_sigmoid_branch_on_the_device(solver, oracle, name):
+    """IR.cpp:301-307: exp(-t) infinite => s = lowestLength as a constant (derivative 0).  reverseScale
+    never yields such a t (|t| <~ 36), so residuals / Jacobian are evaluated, and the LM loop is
+    started, at an explicit point with t = -800 (and one frame at t = +800, the other flat end)."""
+    w = shapes()[name]()
+    M = w.M
+    pt = np.zeros((M, 4))
+    pt[:, :3] = w.frames[:M, 9:12]
+    pt[:, 3] = [capi.reverse_scale(s) for s in w.frames[:M, 12]]
+    pt[0, 3] = -800.0
+    if M > 2:
+        pt[2, 3] = 800.0
+    assert capi.scale(-800.0) == 0.25 and capi.scale(800.0) == 2.0
+    r, J, c = solver.evaluate(w, point=pt)
+    ro, Jo, co = oracle.evaluate_at(w, pt)
+    assert rel_inf(r, ro) < TOL_RJ and rel_inf(J, Jo) < TOL_RJ and abs(c - co) <= 1e-12 * co
+    assert np.all(J[:, 2] == 0.0) and np.all(Jo[:, 2] == 0.0)       # d r / d t_0 = 0 on the saturated branch
+    assert np.abs(J[:, 5]).max() > 0                                 # ... and only there
+    r0, _, _ = solver.evaluate(w)                                    # and the point really was used
+    assert rel_inf(r, r0) > 1e-3
+    for mode in MODES:
+        for kw in (dict(**FIXED10), dict(use_loss_function=True, **FIXED10)):
+            solver.upload([w], capi.make_options(assembly_mode=mode, **kw))
+            solver.set_point(0, pt)
+            solver.solve()
+            fg, sg = solver.download()
+            fo, so, _ = oracle.refine(w, oracle.make_options(**kw), point=pt)
+            assert (sg[0].termination, sg[0].iterations) == (so.termination, so.iterations)
+            assert abs(sg[0].initial_cost - so.initial_cost) <= 1e-9 * so.initial_cost
+            assert abs(sg[0].final_cost - so.final_cost) <= 1e-8 * so.initial_cost
+            assert np.abs(refined(fg[0], M) - refined(fo, M)).max() < TOL_FINAL
+            assert fg[0][0, 12] == 0.25                              # t_0 never leaves the flat branch
