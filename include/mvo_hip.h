@@ -45,7 +45,7 @@ extern "C" {
 #define MVO_HIP_ERR_OUT_OF_MEMORY 3
 #define MVO_HIP_ERR_DEVICE 4           /* a HIP runtime call failed */
 #define MVO_HIP_ERR_NO_DEVICE 5        /* no gfx950 device: there is NO CPU fallback */
-#define MVO_HIP_ERR_STATE 6            /* solve/download without a prior upload */
+#define MVO_HIP_ERR_STATE 6            /* solve without a prior upload; download / get_trace without a completed solve */
 
 /* IterativeRefinement::RefinementFrame (IterativeRefinement.hpp:171-175).
  * R: cv::Matx33d row-major (IterativeRefinement.cpp:320-324); vec: unit baseline direction
@@ -114,7 +114,10 @@ typedef struct mvo_hip_summary {
   int32_t iterations;            /* index of the last finalized Ceres iteration */
   int32_t num_successful_steps;
   int32_t num_unsuccessful_steps;
-  int32_t reserved;
+  /* which initial lengths reverseScale had to clamp into (lowestLength, highestLength) before the
+   * solve: bit 2k = frame k was <= lowestLength (the ROS_WARN of IterativeRefinement.cpp:357),
+   * bit 2k+1 = frame k was >= highestLength (:363).  The library never logs; the adapter does. */
+  int32_t clamped_scales;
   double initial_cost;
   double final_cost;
 } mvo_hip_summary;

@@ -69,6 +69,11 @@ MVO_HD static inline void mvo_epi_row(const double* m1, const double* m2, double
 
 // pInlier of EpipolarGeometry.cpp:90-94
 MVO_HD static inline double mvo_epi_pinlier(const double* m1, const double* m2, const double* b) {
+  // every operation rounded by itself, as the reference's host build does (x86-64 without FMA): a
+  // contracted multiply-add would move p by an ulp, and `p > threshold` feeds an integer count
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
   const double m1b = m1[0] * b[0] + m1[1] * b[1] + m1[2] * b[2];
   const double m2b = m2[0] * b[0] + m2[1] * b[1] + m2[2] * b[2];
   const double m12 = m1[0] * m2[0] + m1[1] * m2[1] + m1[2] * m2[2];

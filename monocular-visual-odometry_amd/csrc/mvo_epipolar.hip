@@ -112,8 +112,13 @@ __global__ __launch_bounds__(256) void k_epi_score_tiled(uint32_t N, uint32_t K,
       const double m1b = a0 * b0 + a1 * b1 + a2 * b2;
       const double m2b = c0 * b0 + c1 * b1 + c2 * b2;
       const double x = fma(-m1b, m1b, n1), y = fma(-m2b, m2b, n2), num = fma(-m2b, m1b, m12);
-      const bool ok = x > 1e-140 && y > 1e-140 && x * y < 1e280;  // comfortably positive, product finite
       const double p = num * ep_rsqrt(x * y);
+      // comfortably positive radicands, finite product -- and p not within 1e-12 of the threshold:
+      // `p > threshold` feeds an INTEGER (the inlier count, hence the adaptive iteration count and the
+      // winner, EpipolarGeometry.cpp:100-118), so a correspondence that close takes the reference's own
+      // expression below, the one k_epi_final and the oracle decide with
+      const bool ok = x > 1e-140 && y > 1e-140 && x * y < 1e280 &&
+                      fabs(p - threshold) > 1e-12 * fmax(1.0, fabs(threshold));
       const bool in = ok && p > threshold;
       cnt[h] += in ? 1u : 0u;
       prob[h] += in ? p : 0.0;

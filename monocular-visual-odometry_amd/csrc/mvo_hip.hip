@@ -186,6 +186,7 @@ struct mvo_hip_context {
   std::vector<TileDev> v_tiles;
   std::vector<uint32_t> v_wave_tiles;
   std::vector<double> v_initx;
+  std::vector<int32_t> v_clamped;  // per window: bit 2k = scale_k clamped low, bit 2k+1 = high (IR.cpp:350-363)
   bool lm_started = false;  // false until the first k_lm launch of the current solve
   // The done counter is never cleared between solves: a solve is complete when it has advanced by W
   // past done_base (one fill less per solve).  done_ready = the counter holds done_base.
@@ -195,6 +196,7 @@ struct mvo_hip_context {
   bool profiling = false;  // record HIP events around the launches (mvo_hip_set_profiling)
   // problem description of the last upload
   bool uploaded = false;
+  bool solved = false;  // h_results hold the results of a completed solve of the current upload
   uint32_t W = 0, M = 0, N = 0, P = 0;
   uint64_t n_obs = 0;      // residual blocks (all windows)
   uint64_t c_elems = 0;    // padded plane length
@@ -232,10 +234,23 @@ double host_scale(double t, double max_len, double min_len) {
 }
 
 // IR.cpp:348-368
-double host_reverse_scale(double length, double max_len, double min_len) {
+// The reference recurses on the clamped value; one clamp step lands strictly inside the interval
+// whenever the interval is wider than a few ulps of its ends (validate() demands that), so the
+// recursion is at most one level deep -- written as a bounded loop so that no input can overflow the
+// stack.  *clamped: 0 none, 1 low (IR.cpp:350-357), 2 high (IR.cpp:358-363) -- the reference warns.
+double host_reverse_scale(double length, double max_len, double min_len, int* clamped = nullptr) {
   const double eps = std::numeric_limits<double>::epsilon();
-  if (length <= min_len) return host_reverse_scale(min_len + (length * eps) + eps, max_len, min_len);
-  if (length >= max_len) return host_reverse_scale(max_len - (length * eps + eps), max_len, min_len);
+  for (int depth = 0; depth < 4; ++depth) {
+    if (length <= min_len) {
+      if (clamped && !*clamped) *clamped = 1;
+      length = min_len + (length * eps) + eps;
+    } else if (length >= max_len) {
+      if (clamped && !*clamped) *clamped = 2;
+      length = max_len - (length * eps + eps);
+    } else {
+      break;
+    }
+  }
   return -1.0 * std::log((max_len - length) / (length - min_len));
 }
 
@@ -248,7 +263,22 @@ int validate(uint32_t n_windows, const void* frames, uint32_t M, uint32_t N, con
   if (M > MVO_HIP_MAX_REFINE) return MVO_HIP_ERR_UNSUPPORTED; // IR.cpp:450
   if (N > MVO_HIP_MAX_FRAMES) return MVO_HIP_ERR_UNSUPPORTED;
   if (opt->max_num_iterations < 0) return MVO_HIP_ERR_INVALID_ARGUMENT;
-  if (!(opt->highest_length > opt->lowest_length)) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  if (!(opt->highest_length > opt->lowest_length) || !std::isfinite(opt->highest_length) ||
+      !std::isfinite(opt->lowest_length))
+    return MVO_HIP_ERR_INVALID_ARGUMENT;
+  {
+    // reverseScale's clamp (IR.cpp:350-363) must land strictly inside (lowest, highest); the
+    // reference would recurse forever otherwise (e.g. lowest 4, highest 4 + 1 ulp)
+    const double eps = std::numeric_limits<double>::epsilon();
+    const double lo = opt->lowest_length + (opt->lowest_length * eps) + eps;
+    const double hi = opt->highest_length - (opt->highest_length * eps + eps);
+    if (!(lo > opt->lowest_length && lo < opt->highest_length && hi < opt->highest_length && hi > opt->lowest_length))
+      return MVO_HIP_ERR_INVALID_ARGUMENT;
+    const mvo_hip_frame* fr = static_cast<const mvo_hip_frame*>(frames);
+    for (uint32_t w = 0; w < n_windows; ++w)
+      for (uint32_t k = 0; k < M; ++k)
+        if (std::isinf(fr[(size_t)w * N + k].scale)) return MVO_HIP_ERR_INVALID_ARGUMENT;  // the reference would recurse forever
+  }
   const uint32_t P = num_pairs(M, N);
   uint64_t total = 0;
   for (uint32_t w = 0; w < n_windows; ++w) {
@@ -296,6 +326,7 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
   if (rc != MVO_HIP_OK) return rc;
   HIP_TRY(hipSetDevice(h->device));
   h->uploaded = false;
+  h->solved = false;
   const uint32_t P = num_pairs(M, N);
   h->W = W;
   h->M = M;
@@ -356,6 +387,7 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
   uint64_t wave_fill = 0;  // residual blocks already given to the current wavefront
   std::vector<double>& initx = h->v_initx;
   initx.assign((size_t)W * MVO_MAXM * 4, 0.0);
+  h->v_clamped.assign(W, 0);
   uint64_t src = 0, cpos = 0;
   uint32_t slot = 0;
   std::vector<uint32_t>& win_last_wave = h->v_win_last_wave;
@@ -373,7 +405,9 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
       x[0] = f.vec[0];
       x[1] = f.vec[1];
       x[2] = f.vec[2];
-      x[3] = host_reverse_scale(f.scale, opt->highest_length, opt->lowest_length);  // IR.cpp:102
+      int clamped = 0;
+      x[3] = host_reverse_scale(f.scale, opt->highest_length, opt->lowest_length, &clamped);  // IR.cpp:102
+      if (clamped) h->v_clamped[w] |= 1 << (2 * k + (clamped - 1));
     }
     uint32_t p = 0;
     for (uint32_t a = 0; a < M; ++a)
@@ -676,7 +710,8 @@ int partial_begin(mvo_hip_context* h) {
   // window status words and the done counter are adjacent: one fill
   HIP_TRY(hipMemsetAsync(h->d_status, 0, (size_t)((char*)h->d_done - (char*)h->d_status) + 16, s));
   h->done_base = 0;
-  h->done_ready = true;
+  h->done_ready = false;  // until this partitioned solve has been seen to complete (it may be abandoned)
+  h->solved = false;
   HIP_TRY(hipMemsetAsync(h->d_pairsum.p, 0, sizeof(double) * 8 * (size_t)n, s));
   if (!h->pass_mode) {
     HIP_TRY(launch_fold(h, false));
@@ -715,6 +750,8 @@ int partial_advance(mvo_hip_context* h, int32_t* done) {
     h->done_base = (uint32_t)h->h_done[0];
     HIP_TRY(hipMemcpyAsync(h->h_results, h->d_results, sizeof(LmResult) * h->W, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    h->done_ready = true;
+    h->solved = true;
   }
   if (done) *done = all ? 1 : 0;
   return MVO_HIP_OK;
@@ -741,6 +778,7 @@ int do_solve(mvo_hip_context* h) {
     h->done_base = 0;
   }
   h->done_ready = false;  // until this solve has been seen to complete
+  h->solved = false;
   const uint32_t done_base = h->done_base;
 
   const uint32_t fold_blocks = pass_blocks(h);
@@ -852,6 +890,7 @@ int do_solve(mvo_hip_context* h) {
   if ((uint32_t)h->h_done[0] - done_base != h->W) return MVO_HIP_ERR_DEVICE;  // every window must have terminated
   h->done_base = (uint32_t)h->h_done[0];
   h->done_ready = true;
+  h->solved = true;
 
   mvo_hip_timing& tm = h->timing;
   tm.solve_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
@@ -898,7 +937,7 @@ int do_solve(mvo_hip_context* h) {
 }
 
 int do_download(mvo_hip_context* h, mvo_hip_frame* frames, mvo_hip_summary* summaries) {
-  if (!h->uploaded) return MVO_HIP_ERR_STATE;
+  if (!h->uploaded || !h->solved) return MVO_HIP_ERR_STATE;  // nothing solved yet: the result records are stale
   for (uint32_t w = 0; w < h->W; ++w) {
     const LmResult& r = h->h_results[w];
     if (frames) {
@@ -918,7 +957,7 @@ int do_download(mvo_hip_context* h, mvo_hip_frame* frames, mvo_hip_summary* summ
       sm.iterations = r.iterations;
       sm.num_successful_steps = r.nsucc;
       sm.num_unsuccessful_steps = r.nunsucc;
-      sm.reserved = 0;
+      sm.clamped_scales = h->v_clamped[w];
       sm.initial_cost = r.initial_cost;
       sm.final_cost = r.final_cost;
     }
@@ -1146,7 +1185,7 @@ int mvo_hip_set_trace(mvo_hip_handle h, int32_t capacity) {
 
 int mvo_hip_get_trace(mvo_hip_handle h, mvo_hip_iteration* rows, int32_t capacity, int32_t* n_rows) {
   if (!h || !n_rows) return MVO_HIP_ERR_INVALID_ARGUMENT;
-  if (!h->uploaded) return MVO_HIP_ERR_STATE;
+  if (!h->uploaded || !h->solved) return MVO_HIP_ERR_STATE;
   const int32_t produced = h->h_results[0].iterations + 1;
   *n_rows = produced;
   int32_t n = produced < h->trace_cap ? produced : h->trace_cap;
@@ -1240,7 +1279,7 @@ constexpr uint32_t kNoallocMaxPairs = MVO_MAXM * (MVO_HIP_MAX_FRAMES - 1) - (MVO
 constexpr size_t na_align(size_t x) { return (x + 255) & ~(size_t)255; }
 constexpr size_t kNaWin = 0;                                                    // WinDev
 constexpr size_t kNaCtl = na_align(kNaWin + sizeof(WinDev));                    // int32: status, done, bad
-constexpr size_t kNaResult = na_align(kNaCtl + 3 * 64);                         // LmResult
+constexpr size_t kNaResult = na_align(kNaCtl + 4 * 64);                         // LmResult
 constexpr size_t kNaState = na_align(kNaResult + sizeof(LmResult));             // LmState
 constexpr size_t kNaInitX = na_align(kNaState + sizeof(LmState));               // MVO_MAXM x (vec, t)
 constexpr size_t kNaPairs = na_align(kNaInitX + sizeof(double) * 4 * MVO_MAXM); // PairDev[P]
@@ -1286,10 +1325,16 @@ hipError_t mvo_noalloc_resolve(int device) {
 namespace {
 // IR.cpp:348-368 on the device (one clamp step instead of the recursion: the clamped value lies
 // strictly inside the interval unless the interval itself is degenerate)
-__device__ double d_reverse_scale(double length, double max_len, double min_len) {
+__device__ double d_reverse_scale(double length, double max_len, double min_len, int& clamped) {
   const double eps = DBL_EPSILON;
-  if (length <= min_len) length = min_len + (length * eps) + eps;
-  else if (length >= max_len) length = max_len - (length * eps + eps);
+  clamped = 0;
+  if (length <= min_len) {
+    length = min_len + (length * eps) + eps;
+    clamped = 1;
+  } else if (length >= max_len) {
+    length = max_len - (length * eps + eps);
+    clamped = 2;
+  }
   return -1.0 * log((max_len - length) / (length - min_len));
 }
 
@@ -1297,9 +1342,9 @@ __device__ double d_reverse_scale(double length, double max_len, double min_len)
 __global__ __launch_bounds__(256) void k_noalloc_prep(unsigned char* sc, const double* __restrict__ frames,
                                                       const uint64_t* __restrict__ offs, uint32_t M, uint32_t N,
                                                       uint32_t P, uint64_t n_blocks, double max_len, double min_len) {
-  __shared__ int bad_s;
+  __shared__ int bad_s, clamp_s;
   const int tid = threadIdx.x;
-  if (tid == 0) bad_s = 0;
+  if (tid == 0) bad_s = clamp_s = 0;
   __syncthreads();
   int bad = 0;
   for (uint32_t p = tid; p < P; p += 256)
@@ -1327,8 +1372,11 @@ __global__ __launch_bounds__(256) void k_noalloc_prep(unsigned char* sc, const d
     x[0] = f[9];
     x[1] = f[10];
     x[2] = f[11];
-    x[3] = d_reverse_scale(f[12], max_len, min_len);  // IR.cpp:102
+    int clamped;
+    x[3] = d_reverse_scale(f[12], max_len, min_len, clamped);  // IR.cpp:102
+    if (clamped) atomicOr(&clamp_s, 1 << (2 * tid + (clamped - 1)));
   }
+  __syncthreads();
   if (tid == 0) {
     WinDev w{};
     w.frame_off = 0;
@@ -1341,6 +1389,7 @@ __global__ __launch_bounds__(256) void k_noalloc_prep(unsigned char* sc, const d
     ctl[0] = 0;         // window status
     ctl[16] = 0;        // done counter
     ctl[32] = bad_s;    // inconsistent pair_offsets
+    ctl[48] = clamp_s;  // which initial lengths reverseScale clamped
   }
 }
 
@@ -1365,7 +1414,7 @@ __global__ void k_noalloc_finish(const unsigned char* sc, double* __restrict__ f
     s.iterations = bad ? 0 : r->iterations;
     s.num_successful_steps = bad ? 0 : r->nsucc;
     s.num_unsuccessful_steps = bad ? 0 : r->nunsucc;
-    s.reserved = 0;
+    s.clamped_scales = ctl[48];
     s.initial_cost = bad ? 0.0 : r->initial_cost;
     s.final_cost = bad ? 0.0 : r->final_cost;
     *summary = s;

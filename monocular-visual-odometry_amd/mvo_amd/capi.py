@@ -70,7 +70,7 @@ class Summary(C.Structure):
         ("iterations", C.c_int32),
         ("num_successful_steps", C.c_int32),
         ("num_unsuccessful_steps", C.c_int32),
-        ("reserved", C.c_int32),
+        ("clamped_scales", C.c_int32),
         ("initial_cost", C.c_double),
         ("final_cost", C.c_double),
     ]

@@ -50,9 +50,14 @@ def shard_landmarks(sc, rank: int, world: int):
     offs = np.asarray(sc.lm_offsets, dtype=np.uint64)
     n_obs = int(offs[-1])
     cuts = [int(np.searchsorted(offs, (n_obs * r) // world, side="left")) for r in range(world + 1)]
-    cuts[0], cuts[-1] = 0, len(offs) - 1
-    for r in range(1, world + 1):
-        cuts[r] = max(cuts[r], cuts[r - 1])
+    L = len(offs) - 1
+    if world > L:
+        # mvo_hip_ba_upload refuses an empty landmark range; raised on EVERY rank alike (the plan
+        # depends on the scene and `world` only), i.e. before any rank enters a collective
+        raise ValueError(f"cannot partition {L} landmarks over {world} ranks: every rank needs at least one")
+    cuts[0], cuts[-1] = 0, L
+    for r in range(1, world):  # every rank owns at least one landmark, however skewed the track lengths
+        cuts[r] = min(max(cuts[r], cuts[r - 1] + 1), L - (world - r))
     lo, hi = cuts[rank], cuts[rank + 1]
     o0, o1 = int(offs[lo]), int(offs[hi])
     shard = replace(sc, X=np.ascontiguousarray(sc.X[lo:hi]),

@@ -7,6 +7,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -112,3 +113,25 @@ def test_landmark_shards_tile_the_scene():
         for p, _ in parts:
             assert p.poses is sc.poses and int(p.lm_offsets[0]) == 0
             assert abs(p.n_observations - sc.n_observations / world) <= 7
+
+
+def test_landmark_shards_are_never_empty():
+    """mvo_hip_ba_upload refuses L == 0, and a rank that raises while the others enter the all-reduce
+    hangs the job: every rank owns at least one landmark however skewed the track lengths are, and a
+    world larger than the scene is refused on every rank alike, before any collective."""
+    from dataclasses import replace
+    from mvo_amd import ba_scene
+
+    sc = ba_scene.make_ba_scene(12, 6, 40, seed=5, span=7)
+    # one very long track up front: an observation-balanced cut alone would leave ranks empty
+    offs = np.asarray(sc.lm_offsets, dtype=np.int64)
+    small = replace(sc, X=sc.X[:5], lm_offsets=offs[:6].astype(np.uint64), obs_frame=sc.obs_frame[:offs[5]],
+                    obs_ray=sc.obs_ray[:offs[5]], true_X=sc.true_X[:5])
+    for world in (2, 4, 5):
+        parts = [sharding.shard_landmarks(small, r, world) for r in range(world)]
+        assert all(p.n_landmarks >= 1 for p, _ in parts)
+        assert sum(p.n_landmarks for p, _ in parts) == 5
+        assert sum(p.n_observations for p, _ in parts) == small.n_observations
+    for rank in range(8):
+        with pytest.raises(ValueError):
+            sharding.shard_landmarks(small, rank, 8)

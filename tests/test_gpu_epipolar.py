@@ -84,3 +84,49 @@ def test_edge_cases(ep):
     assert np.array_equal(hb, np.zeros((1, 3))) and hi[0] == 5
     secs, ev = ep.last_timing()
     assert secs > 0 and ev == 5
+
+
+def test_correspondences_on_the_threshold_are_decided_by_the_literal_expression(ep):
+    """`pInlier > threshold` (EpipolarGeometry.cpp:96-100) feeds an integer: the inlier count, through it
+    the adaptive iteration count (:104-106) and the winner (:113).  Correspondences built ON the
+    threshold for hypothesis 0 (p = threshold to a few ulps, either side) must be counted exactly as
+    the reference's own expression -- two square roots and a division, every operation rounded by
+    itself -- decides, not as the scoring kernel's fused reciprocal square root would."""
+    t = epipolar_capi.synthetic_correspondences(2000, seed=321, outlier_fraction=0.3, n_samples=64)
+    thr = float(np.cos(np.deg2rad(4.0)))
+    hb, _, _ = ep.score(t["mhi"], t["mt"], t["samples"], thr)
+    b = hb[0] / np.linalg.norm(hb[0])
+    e1 = np.cross(b, [0.3, -0.5, 0.8])
+    e1 /= np.linalg.norm(e1)
+    e2 = np.cross(b, e1)
+    rng = np.random.default_rng(7)
+    n_on = 4096
+    al = rng.uniform(0, 2 * np.pi, n_on)
+    th = np.arccos(thr)
+    z1, z2 = rng.uniform(-0.5, 0.5, n_on), rng.uniform(-0.5, 0.5, n_on)
+    unit = lambda v: v / np.linalg.norm(v, axis=1, keepdims=True)
+    m1 = unit(np.cos(al)[:, None] * e1 + np.sin(al)[:, None] * e2 + z1[:, None] * b)
+    m2 = unit(np.cos(al + th)[:, None] * e1 + np.sin(al + th)[:, None] * e2 + z2[:, None] * b)
+    mhi = np.ascontiguousarray(np.concatenate([t["mhi"], m1]))
+    mt = np.ascontiguousarray(np.concatenate([t["mt"], m2]))
+    hb2, hi, hp = ep.score(mhi, mt, t["samples"], thr)   # the draws index the first 2000 only: same hypotheses
+    assert np.array_equal(hb2, hb)
+
+    def literal(bv):  # the reference's expression in its operation order, one rounding per operation
+        d = lambda u, v: (u[:, 0] * v[:, 0] + u[:, 1] * v[:, 1]) + u[:, 2] * v[:, 2]
+        bb = np.tile(bv, (len(mhi), 1))
+        m1b, m2b, m12, n1, n2 = d(mhi, bb), d(mt, bb), d(mhi, mt), d(mhi, mhi), d(mt, mt)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            return (m12 - m2b * m1b) / (np.sqrt(n1 - m1b * m1b) * np.sqrt(n2 - m2b * m2b))
+
+    p0 = literal(hb[0])
+    on = p0[2000:]
+    assert np.abs(on - thr).max() < 1e-13                              # they really sit on the threshold ...
+    assert 0.2 * n_on < np.count_nonzero(on > thr) < 0.8 * n_on        # ... on both sides of it
+    for k in range(len(hb)):
+        pk = literal(hb[k])
+        assert hi[k] == np.count_nonzero(pk > thr), k                  # integer outputs: exact
+        assert abs(hp[k] - pk[pk > thr].sum()) <= 1e-9 * max(1.0, hp[k])
+    res, inl = ep.estimate(mhi, mt, t["samples"], 0.99, thr)
+    pw = literal(hb[res.best_hypothesis])
+    assert res.n_inliers == np.count_nonzero(pw > thr) == len(inl)

@@ -212,6 +212,20 @@ def test_zero_iterations_and_out_of_range_lengths(solver, oracle):
     fo, so, _ = oracle.refine(w, oracle.make_options(**FIXED10))
     assert np.abs(refined(fg, 2) - refined(fo, 2)).max() < TOL_FINAL
     assert np.all(refined(fg, 2)[:, 3] >= 0.25) and np.all(refined(fg, 2)[:, 3] <= 2.0)
+    # ... and the summary says which ones, so that the adapter can log what IR.cpp:357,363 log:
+    # frame 0 clamped high (bit 1), frame 1 clamped low (bit 2)
+    assert sg.clamped_scales == (1 << 1) | (1 << 2)
+    assert s.clamped_scales == 0
+    # the exact bounds clamp too (<=, >=), infinities are refused (the reference would recurse forever)
+    w.frames[0, 12], w.frames[1, 12] = 0.25, 2.0
+    _, sb = solver.refine(w, capi.make_options(**FIXED10))
+    assert sb.clamped_scales == (1 << 0) | (1 << 3)
+    w.frames[0, 12] = np.inf
+    with pytest.raises(capi.MvoHipError) as e:
+        solver.refine(w, capi.make_options(**FIXED10))
+    assert e.value.status == capi.ERR_INVALID_ARGUMENT
+    with pytest.raises(capi.MvoHipError):   # an interval of one ulp: the clamp cannot land inside it
+        solver.refine(scene.make_window(5, 2, 30, seed=4), capi.make_options(lowest_length=4.0, highest_length=np.nextafter(4.0, 5.0)))
 
 
 def test_error_behaviour(solver):
@@ -245,6 +259,27 @@ def test_error_behaviour(solver):
 def test_download_before_upload_is_an_error():
     with capi.Solver(0) as s2:
         assert capi.load().mvo_hip_solve(s2._h) == capi.ERR_STATE
+        # uploaded but never solved (or a partitioned solve abandoned half-way): no stale results
+        w = scene.make_window(30, 5, 400, seed=3, span=("sliding", 18))
+        s2.upload([w], capi.make_options(use_loss_function=True, **FIXED10))
+        with pytest.raises(capi.MvoHipError) as e:
+            s2.download()
+        assert e.value.status == capi.ERR_STATE
+        n = C.c_int32(0)
+        assert capi.load().mvo_hip_get_trace(s2._h, None, 0, C.byref(n)) == capi.ERR_STATE
+        lib = capi.load()
+        assert lib.mvo_hip_partial_begin(s2._h) == capi.OK and lib.mvo_hip_partial_pass(s2._h) == capi.OK
+        done = C.c_int32(0)
+        assert lib.mvo_hip_partial_advance(s2._h, C.byref(done)) == capi.OK and done.value == 0
+        with pytest.raises(capi.MvoHipError):
+            s2.download()
+        s2.solve()                                   # the abandoned run's done counter is not trusted
+        fa, sa = s2.download()
+        with capi.Solver(0) as s3:
+            s3.upload([w], capi.make_options(use_loss_function=True, **FIXED10))
+            s3.solve()
+            fb, sb = s3.download()
+        assert np.array_equal(fa, fb) and sa[0].iterations == sb[0].iterations
 
 
 def test_split_phase_is_repeatable(solver):
