@@ -35,29 +35,56 @@ sys.path.insert(0, os.path.join(ROOT, "monocular-visual-odometry_amd"))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 achievable
 
 
-def build_workload(name, rank):
-    from mvo_amd import capi, scene
+def plan(workload, world, weak=False):
+    """Which BASELINE.json configuration a run measures and how it is spread over `world` GPUs.
+    -> (workload, mode); mode: "single" (one GPU), "strong_windows" (the SAME 4096 config-3 windows
+    block-partitioned over the ranks, no collective -- configs[2]), "partitioned" (ONE config-4 window,
+    residual blocks range-partitioned, RCCL all-reduce inside the library -- configs[3]), "weak" (every
+    rank its own copy of the workload; only on request).
+    Default workload: configs[1] (config2) on one GPU -- the configuration the metric is quoted on --
+    and configs[2] (config3), the configuration BASELINE.json names for 1/2/4/8 GPUs, beyond."""
+    if workload is None:
+        workload = "config2" if world == 1 else "config3"
+    if world == 1:
+        return workload, "single"
+    if weak:
+        return workload, "weak"
+    if workload == "config3":
+        return workload, "strong_windows"
+    if workload in ("config4", "config4r"):
+        return workload, "partitioned"
+    return workload, "weak"  # config2 / config5 are single windows sized for one GPU
+
+
+def build_workload(name, rank, world=1, mode="single"):
+    from mvo_amd import capi, scene, sharding
 
     fixed10 = dict(max_num_iterations=10, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
+    seed_rank = rank if mode == "weak" else 0
     if name == "config2":
-        ws = [scene.config2(seed=1002 + rank)]
+        ws = [scene.config2(seed=1002 + seed_rank)]
         opt = capi.make_options(**fixed10)
         desc = "config2: 1 window/GPU, N=30 M=5, 5000 landmarks, fixed 10 LM iterations, no loss"
     elif name == "config5":
-        ws = [scene.config2(seed=1005 + rank, outlier_fraction=0.2)]
+        ws = [scene.config2(seed=1005 + seed_rank, outlier_fraction=0.2)]
         opt = capi.make_options(use_loss_function=True, **fixed10)
         desc = "config5: config2 data with 20% outliers, Cauchy(0.5) IRLS, fixed 10 LM iterations"
     elif name == "config3":
         n = int(os.environ.get("MVO_BENCH_WINDOWS", "4096"))
-        ws = [scene.config3_window(rank * n + i) for i in range(n)]
+        if mode == "strong_windows":   # BASELINE configs[2]: the same n windows sharded over the ranks
+            ids = sharding.shard_windows(n, rank, world)
+            desc = f"config3: {n} independent windows sharded over {world} GPUs, N=10 M=5, 300 landmarks each, fixed 10 LM iterations"
+        else:
+            ids = range(seed_rank * n, seed_rank * n + n)
+            desc = f"config3: {n} independent windows/GPU, N=10 M=5, 300 landmarks each, fixed 10 LM iterations"
+        ws = [scene.config3_window(i) for i in ids]
         opt = capi.make_options(**fixed10)
-        desc = f"config3: {n} independent windows/GPU, N=10 M=5, 300 landmarks each, fixed 10 LM iterations"
     elif name == "config4":
-        ws = [scene.config4(seed=1004 + rank)]
+        ws = [scene.config4(seed=1004 + seed_rank)]
         opt = capi.make_options(**fixed10)
         desc = "config4 (one GPU's worth): N=200 M=5, 985 pairs, ~9.7M residual blocks, fixed 10 LM iterations"
     elif name == "config4r":
-        ws = [scene.config4(seed=1004 + rank, outlier_fraction=0.2)]
+        ws = [scene.config4(seed=1004 + seed_rank, outlier_fraction=0.2)]
         opt = capi.make_options(use_loss_function=True, **fixed10)
         desc = "config4 data with 20% outliers, Cauchy(0.5) IRLS, fixed 10 LM iterations"
     else:
@@ -67,13 +94,19 @@ def build_workload(name, rank):
 
 def measured_traffic(workload, kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/traffic.json,
-    written by scripts/profile.sh on the same workload); None when no such pass was recorded."""
+    written by scripts/profile.sh on the same workload).  None when no such pass was recorded -- or when
+    the kernel's source has changed since (each entry carries the hash of the source files it was
+    measured on): a stale figure is not reported."""
+    from mvo_amd.srchash import source_hash
+
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["per_workload"][workload]
     except (OSError, KeyError, ValueError):
         return None
     for name, rec in t.items():
         if name.startswith(kernel):
+            if rec.get("source_hash") is None or rec.get("source_hash") != source_hash(name):
+                return None
             return int(rec.get("fetch_bytes", 0) + rec.get("write_bytes", 0))
     return None
 
@@ -542,7 +575,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="config2")
+    ap.add_argument("--workload", default=None,
+                    help="default: config2 on one GPU, config3 (the same 4096 windows sharded) on several")
+    ap.add_argument("--weak", action="store_true", help="N > 1: every rank its own copy of the workload")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-large", action="store_true", help="skip the config-4-size roofline leg")
     args = ap.parse_args()
@@ -571,6 +606,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    args.workload, mode = plan(args.workload, world, args.weak)
     if args.workload == "epipolar":
         bench_epipolar(args, rank, local_rank, world, barrier, dist, torch)
         if world > 1:
@@ -593,23 +629,21 @@ def main():
         return
 
     # config4 / config4r with N > 1: ONE window, residual blocks range-partitioned over the ranks,
-    # per-pair sums all-reduced over RCCL before every (identical) LM step -- strong scaling.
-    partitioned = world > 1 and args.workload in ("config4", "config4r")
-    ws, opt, desc = build_workload(args.workload, 0 if partitioned else rank)
+    # per-pair sums all-reduced by RCCL INSIDE the library, on its stream, before every (identical)
+    # LM step (mvo_hip_comm_init / mvo_hip_solve_partitioned) -- strong scaling.
+    # config3 with N > 1: the same 4096 windows block-partitioned over the ranks, no collective.
+    partitioned = mode == "partitioned"
+    ws, opt, desc = build_workload(args.workload, rank, world, mode)
     solver = capi.Solver(local_rank)
     if partitioned:
         from mvo_amd import sharding
 
         full = ws[0]
         ws = [sharding.shard_observations(full, rank, world)]
-        sums = torch.zeros(8 * full.n_pairs, dtype=torch.float64, device="cuda")
-
-        def allreduce(t):
-            dist.all_reduce(t)
-            torch.cuda.synchronize()
-
-        def run_solve():
-            solver.solve_partitioned(allreduce, sums)
+        uid = [capi.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)   # the unique id travels over torch's own process group
+        solver.comm_init(uid[0], rank, world)
+        run_solve = solver.solve_partitioned_rccl
     else:
         run_solve = solver.solve
     t0 = time.perf_counter()
@@ -625,7 +659,7 @@ def main():
     # HIP events (kernel durations for `roofline`) are recorded on every 4th step of the timed
     # region only: the event records themselves cost ~8 us per solve, which is not the library's
     # default (mvo_hip_set_profiling is off unless asked for)
-    every = 1 if partitioned else 4
+    every = 4
     n_prof = 0
     for i in range(args.steps):
         timed = i % every == 0
@@ -655,9 +689,18 @@ def main():
     blocks = sum(w.n_residual_blocks for w in ws)
     bearings = sum(w.bearing_observations for w in ws)
     units = 1 if partitioned else world   # a partitioned window is one job, not `world` jobs
-    total_its = its_per_step * args.steps * units
+    strong = mode in ("partitioned", "strong_windows")
+    if world > 1 and not partitioned:   # the ranks' shares differ in size: whole-job totals
+        tot = torch.tensor([float(its_per_step), float(blocks), float(bearings), float(n_windows)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tot)
+        job_its, job_blocks, job_bearings, job_windows = (float(x) for x in tot.tolist())
+    else:
+        job_its, job_blocks, job_bearings, job_windows = float(its_per_step), float(blocks) * (world if partitioned else 1), float(bearings), float(n_windows)
+    total_its = job_its * args.steps
     tm["assembly_seconds"], tm["assembly_launches"] = asm_s, asm_n
     roof = None if partitioned else roofline_of(tm, args.workload)  # the partitioned path is not event-timed
+    if partitioned:
+        solver.comm_destroy()
 
     out = {
         "metric": "lm_iterations_per_sec",
@@ -668,19 +711,22 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 5),
         "higher_is_better": True,
-        "scaling": "strong" if partitioned else "weak",
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": desc, "windows_per_gpu": n_windows, "residual_blocks_per_gpu": blocks,
+                   "windows_whole_job": int(job_windows), "residual_blocks_whole_job": int(job_blocks),
                    "bearing_observations_per_gpu": bearings, "pairs_per_window": ws[0].n_pairs,
                    "lm_iterations_per_window": its_per_step // n_windows,
-                   "parallelism": (f"1 window range-partitioned over {world} GPUs, RCCL all-reduce of 8 fp64 per pair"
-                                   if partitioned else f"{world} x independent windows, no collective")},
+                   "parallelism": (f"1 window range-partitioned over {world} GPUs, RCCL all-reduce of 8 fp64 per pair on the library's stream"
+                                   if partitioned else
+                                   f"the same {int(job_windows)} windows block-partitioned over {world} GPUs, no collective"
+                                   if mode == "strong_windows" else f"{world} x independent windows, no collective")},
         # every LM iteration evaluates all residual blocks and their Jacobian rows (through the
         # per-pair moments in the no-loss case, through one observation pass otherwise)
-        "residual_jacobian_obs_per_sec": round(blocks * (world if partitioned else 1) * (its_per_step / n_windows) * args.steps * units / elapsed, 1),
-        "windows_per_sec": round(n_windows * args.steps * units / elapsed, 3),
+        "residual_jacobian_obs_per_sec": round(job_blocks * (its_per_step / n_windows) * args.steps / elapsed, 1),
+        "windows_per_sec": round(job_windows * args.steps / elapsed, 3),
         "device_ms_per_step": round(dev_s / n_prof * 1e3, 5),
         "host_solve_ms_per_step": round(host_s / args.steps * 1e3, 5),
         "fold_kernel_us": round(first_s / n_prof * 1e6, 3),
@@ -688,6 +734,35 @@ def main():
         "upload_seconds_pcie_inclusive": round(upload_s, 6),
         "roofline": roof,
     }
+
+    if rank == 0 and not partitioned and len(ws) == 1:
+        # the call the reference would actually make: mvo_hip_refine with HOST buffers in and out
+        # (upload over PCIe + solve + download) -- never part of `value`
+        k = 3 if blocks > 2_000_000 else 20
+        for _ in range(2):
+            solver.refine(ws[0], opt)
+        t1 = time.perf_counter()
+        for _ in range(k):
+            solver.refine(ws[0], opt)
+        out["refine_ms_pcie_inclusive"] = round((time.perf_counter() - t1) / k * 1e3, 5)
+    if mode == "strong_windows":
+        # the efficiency baseline in the same line: ALL windows of the job on rank 0's GPU alone
+        # (the other ranks wait); the driver's own N = 1 run measures config2, a different workload
+        if rank == 0:
+            all_ws, _, _ = build_workload(args.workload, 0, 1, "single")
+            solver.upload(all_ws, opt)
+            for _ in range(2):
+                solver.solve()
+            k = max(3, min(args.steps, 10))
+            t1 = time.perf_counter()
+            for _ in range(k):
+                solver.solve()
+                _, s1 = solver.download(copy=False)
+            e1 = (time.perf_counter() - t1) / k
+            out["same_workload_one_gpu"] = {"value": round(sum(x.iterations for x in s1) / e1, 3), "unit": "LM iterations/s",
+                                            "ms_per_step": round(e1 * 1e3, 5), "windows": len(all_ws)}
+            del all_ws
+        barrier()
 
     if rank == 0 and world == 1 and not args.no_large and args.workload in ("config2", "config5"):
         # the same pass kernels at a size HBM actually sees (config 4, one GPU)

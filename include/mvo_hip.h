@@ -199,6 +199,24 @@ int mvo_hip_partial_pass(mvo_hip_handle h);
 int mvo_hip_partial_advance(mvo_hip_handle h, int32_t *done);
 int mvo_hip_partial_sums(mvo_hip_handle h, void *device_buffer, uint64_t n_doubles, int direction);
 
+/* The same partitioned solve with the collective INSIDE the library (north_star: "partial
+ * normal-equation blocks are combined with an RCCL all-reduce over xGMI"; no reference counterpart).
+ * One process per GPU: rank 0 calls mvo_hip_comm_unique_id and ships the MVO_HIP_COMM_ID_BYTES bytes to
+ * the other ranks by whatever means the application has (MPI, a file, a socket); every rank then calls
+ * mvo_hip_comm_init on its handle (ncclCommInitRank on the handle's device: collective, blocks until
+ * all ranks have arrived).  After mvo_hip_upload of this rank's shard (same frames and options on every
+ * rank), mvo_hip_solve_partitioned runs fold / pass -> per-pair sums -> ncclAllReduce(sum, 8 fp64 per
+ * pair) -> LM step entirely on the handle's stream -- no host round trip per pass; results as after
+ * mvo_hip_solve, identical on every rank (mvo_hip_download).  Every rank must make the same calls in
+ * the same order.  librccl.so.1 is opened on the first of these calls (MVO_HIP_ERR_UNSUPPORTED when it
+ * cannot be found), so single-GPU users never load it.  mvo_hip_comm_destroy (or mvo_hip_destroy)
+ * releases the communicator. */
+#define MVO_HIP_COMM_ID_BYTES 128
+int mvo_hip_comm_unique_id(void *id_out);
+int mvo_hip_comm_init(mvo_hip_handle h, const void *unique_id, int rank, int world);
+int mvo_hip_comm_destroy(mvo_hip_handle h);
+int mvo_hip_solve_partitioned(mvo_hip_handle h);
+
 /* Debug/parity entry point: the raw residual r_i and the raw local Jacobian row of every
  * residual block at the initial point -- what ceres::Problem::Evaluate would return for the
  * problem built at IterativeRefinement.cpp:95-183 with apply_loss_function = false.

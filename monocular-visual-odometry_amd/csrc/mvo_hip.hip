@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include "mvo_alloc.h"
+#include "mvo_rccl.h"
 
 #include <chrono>
 #include <cmath>
@@ -223,6 +224,11 @@ struct mvo_hip_context {
   uint32_t chunk_block_end[kMaxOverlapChunks] = {};      // fold workgroups [.., end)
   uint32_t chunk_win_end[kMaxOverlapChunks] = {};        // windows whose tiles all lie in workgroups < end
   std::vector<uint32_t> v_win_last_wave;
+  // observation-partitioned solve: this rank's RCCL communicator (mvo_hip_comm_init); collectives are
+  // queued on `stream` between the observation pass and the LM step
+  ncclComm_t comm = nullptr;
+  int comm_rank = 0, comm_world = 1;
+  ncclResult_t last_rccl_error = ncclSuccess;
 };
 
 namespace {
@@ -757,6 +763,90 @@ int partial_advance(mvo_hip_context* h, int32_t* done) {
   return MVO_HIP_OK;
 }
 
+// The whole partitioned solve with the collective ON THE STREAM: fold / pass -> per-pair sums ->
+// ncclAllReduce (sum, 8 fp64 per pair) -> the identical LM step on every rank.  No host round trip per
+// pass: the done counter is looked at every 12 evaluations, as in the single-GPU robust path.  Every
+// rank issues the same sequence of collectives: the summed moments are bitwise identical on all ranks,
+// so every rank takes the same decisions and finishes at the same evaluation.
+int do_solve_partitioned(mvo_hip_context* h) {
+  if (!h->uploaded || !h->comm) return MVO_HIP_ERR_STATE;
+  const auto t_begin = std::chrono::steady_clock::now();
+  HIP_TRY(hipSetDevice(h->device));
+  const MvoRccl& rc = mvo_rccl();
+  hipStream_t s = h->stream;
+  const uint32_t n = h->W * h->P;
+  if (h->trace_cap > 0) HIP_TRY(h->d_trace.reserve(sizeof(TraceRec) * (size_t)h->trace_cap));
+  h->lm_started = false;
+  h->solved = false;
+  HIP_TRY(hipMemsetAsync(h->d_status, 0, (size_t)((char*)h->d_done - (char*)h->d_status) + 16, s));
+  h->done_base = 0;
+  h->done_ready = false;
+  SolveParams prm = make_params(h);
+  prm.inline_eval = 0;  // the passes are launches of their own: their sums are what gets all-reduced
+  auto allreduce = [&]() -> int {
+    HIP_TRY(launch_reduce_slots(h));
+    const ncclResult_t r = rc.AllReduce(h->d_pairsum.p, h->d_pairsum.p, 8 * (size_t)n, ncclDouble, ncclSum, h->comm, s);
+    if (r != ncclSuccess) {
+      h->last_rccl_error = r;
+      return MVO_HIP_ERR_DEVICE;
+    }
+    return MVO_HIP_OK;
+  };
+  int lm_launches = 0, asm_launches = 0, collectives = 0;
+  if (!h->pass_mode) {
+    // S_p never changes without a loss: ONE collective per solve, then the whole LM loop in one launch
+    HIP_TRY(launch_fold(h, false));
+    ++asm_launches;
+    int rcode = allreduce();
+    if (rcode != MVO_HIP_OK) return rcode;
+    ++collectives;
+    HIP_TRY(launch_lm_any(h, prm, true));
+    ++lm_launches;
+  } else {
+    HIP_TRY(launch_fold(h, true));
+    ++asm_launches;
+    HIP_TRY(launch_lm_any(h, prm, true));  // PH_START: publishes u(x0)
+    ++lm_launches;
+    const int total_evals = h->opt.max_num_iterations + 1;
+    const int chunk = 12;
+    int issued = 0;
+    while (issued < total_evals) {
+      const int m = (total_evals - issued) < chunk ? (total_evals - issued) : chunk;
+      for (int i = 0; i < m; ++i) {
+        HIP_TRY(launch_pass(h));
+        ++asm_launches;
+        int rcode = allreduce();
+        if (rcode != MVO_HIP_OK) return rcode;
+        ++collectives;
+        HIP_TRY(launch_lm_any(h, prm, true));
+        ++lm_launches;
+      }
+      issued += m;
+      if (issued < total_evals) {
+        HIP_TRY(hipMemcpyAsync(h->h_done, h->d_done, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if ((uint32_t)h->h_done[0] >= h->W) break;  // identical on every rank: the sums were
+      }
+    }
+  }
+  HIP_TRY(hipMemcpyAsync(h->h_ctl, h->d_done, 16 + sizeof(LmResult) * h->W, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  h->copy_pending = false;
+  if ((uint32_t)h->h_done[0] != h->W) return MVO_HIP_ERR_DEVICE;
+  h->done_base = (uint32_t)h->h_done[0];
+  h->done_ready = true;
+  h->solved = true;
+  mvo_hip_timing& tm = h->timing;
+  tm.solve_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+  tm.device_seconds = tm.assembly_seconds = tm.assembly_first_seconds = 0.0;
+  tm.assembly_launches = asm_launches;
+  tm.lm_launches = lm_launches;
+  tm.residual_blocks = h->n_obs;
+  tm.assembly_bytes = 0;
+  (void)collectives;
+  return MVO_HIP_OK;
+}
+
 int do_solve(mvo_hip_context* h) {
   if (!h->uploaded) return MVO_HIP_ERR_STATE;
   const auto t_begin = std::chrono::steady_clock::now();
@@ -1012,6 +1102,8 @@ void mvo_hip_destroy(mvo_hip_handle h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->comm) (void)mvo_rccl().CommDestroy(h->comm);
+  h->comm = nullptr;
   DevBuf* bufs[] = {&h->d_arena, &h->d_m0, &h->d_m1, &h->d_c, &h->d_partial, &h->d_pair_u, &h->d_states,
                     &h->d_ctl, &h->d_trace, &h->d_res, &h->d_jac, &h->d_pairsum};
   for (DevBuf* b : bufs) b->release();
@@ -1169,6 +1261,53 @@ int mvo_hip_partial_sums(mvo_hip_handle h, void* device_buffer, uint64_t n_doubl
     HIP_TRY(hipMemcpyAsync(h->d_pairsum.p, device_buffer, sizeof(double) * n_doubles, hipMemcpyDeviceToDevice, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return MVO_HIP_OK;
+}
+
+int mvo_hip_comm_unique_id(void* id_out) {
+  if (!id_out) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  const MvoRccl& rc = mvo_rccl();
+  if (!rc.ok) return MVO_HIP_ERR_UNSUPPORTED;  // librccl.so.1 not found
+  static_assert(sizeof(ncclUniqueId) == MVO_HIP_COMM_ID_BYTES, "unique id size");
+  ncclUniqueId id;
+  if (rc.GetUniqueId(&id) != ncclSuccess) return MVO_HIP_ERR_DEVICE;
+  std::memcpy(id_out, &id, sizeof id);
+  return MVO_HIP_OK;
+}
+
+int mvo_hip_comm_init(mvo_hip_handle h, const void* unique_id, int rank, int world) {
+  if (!h || !unique_id || world < 1 || rank < 0 || rank >= world) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  if (h->comm) return MVO_HIP_ERR_STATE;  // one communicator per handle: destroy it first
+  const MvoRccl& rc = mvo_rccl();
+  if (!rc.ok) return MVO_HIP_ERR_UNSUPPORTED;
+  HIP_TRY(hipSetDevice(h->device));
+  ncclUniqueId id;
+  std::memcpy(&id, unique_id, sizeof id);
+  const ncclResult_t r = rc.CommInitRank(&h->comm, world, id, rank);
+  if (r != ncclSuccess) {
+    h->last_rccl_error = r;
+    h->comm = nullptr;
+    return MVO_HIP_ERR_DEVICE;
+  }
+  h->comm_rank = rank;
+  h->comm_world = world;
+  return MVO_HIP_OK;
+}
+
+int mvo_hip_comm_destroy(mvo_hip_handle h) {
+  if (!h) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  if (!h->comm) return MVO_HIP_OK;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  const ncclResult_t r = mvo_rccl().CommDestroy(h->comm);
+  h->comm = nullptr;
+  h->comm_world = 1;
+  h->comm_rank = 0;
+  return r == ncclSuccess ? MVO_HIP_OK : MVO_HIP_ERR_DEVICE;
+}
+
+int mvo_hip_solve_partitioned(mvo_hip_handle h) {
+  if (!h) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  return do_solve_partitioned(h);
 }
 
 int mvo_hip_set_profiling(mvo_hip_handle h, int enabled) {

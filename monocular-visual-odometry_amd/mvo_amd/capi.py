@@ -34,6 +34,7 @@ EXPORTED_SYMBOLS = [
     "mvo_hip_num_pairs", "mvo_hip_status_string", "mvo_hip_version", "mvo_hip_partial_begin",
     "mvo_hip_partial_pass", "mvo_hip_partial_advance", "mvo_hip_partial_sums", "mvo_hip_debug_poison_lds",
     "mvo_hip_debug_check_guards", "mvo_hip_refine_noalloc", "mvo_hip_eval_at", "mvo_hip_debug_set_point",
+    "mvo_hip_comm_unique_id", "mvo_hip_comm_init", "mvo_hip_comm_destroy", "mvo_hip_solve_partitioned",
 ]
 
 
@@ -136,6 +137,10 @@ def load():
                                    C.POINTER(Observations), C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
         L.mvo_hip_eval_at.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(Options),
                                       C.POINTER(Observations), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+        L.mvo_hip_comm_unique_id.argtypes = [C.c_void_p]
+        L.mvo_hip_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.mvo_hip_comm_destroy.argtypes = [C.c_void_p]
+        L.mvo_hip_solve_partitioned.argtypes = [C.c_void_p]
         L.mvo_hip_debug_set_point.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         L.mvo_hip_pair_moments.argtypes = [C.c_void_p, C.c_void_p]
         L.mvo_hip_set_trace.argtypes = [C.c_void_p, C.c_int32]
@@ -315,6 +320,23 @@ class Solver:
         if not done.value:
             raise MvoHipError(ERR_DEVICE, "partitioned solve did not terminate")
 
+    # -- the same with the collective inside the library (RCCL on the handle's stream) -------------
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        buf = C.create_string_buffer(bytes(unique_id), COMM_ID_BYTES)
+        rc = self._lib.mvo_hip_comm_init(self._h, buf, int(rank), int(world))
+        if rc != OK:
+            raise MvoHipError(rc, "mvo_hip_comm_init")
+
+    def comm_destroy(self):
+        rc = self._lib.mvo_hip_comm_destroy(self._h)
+        if rc != OK:
+            raise MvoHipError(rc, "mvo_hip_comm_destroy")
+
+    def solve_partitioned_rccl(self):
+        rc = self._lib.mvo_hip_solve_partitioned(self._h)
+        if rc != OK:
+            raise MvoHipError(rc, "mvo_hip_solve_partitioned")
+
     # -- debug / parity -------------------------------------------------------------------
     def evaluate(self, window, options=None, point=None):
         """-> (residuals[n], jacobian[n,3M], cost), raw (no loss), at the initial point or at
@@ -378,6 +400,18 @@ def refine_noalloc(device, stream, frames_ptr, M, N, options, offsets_ptr, m0_pt
     """mvo_hip_refine_noalloc on DEVICE pointers (ints); returns the status code, waits for nothing."""
     return int(load().mvo_hip_refine_noalloc(int(device), stream, frames_ptr, M, N, C.byref(options), offsets_ptr,
                                              m0_ptr, m1_ptr, int(n_blocks), summary_ptr))
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id() -> bytes:
+    """ncclGetUniqueId through the library (rank 0 calls it and ships the bytes to the other ranks)."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    rc = load().mvo_hip_comm_unique_id(buf)
+    if rc != OK:
+        raise MvoHipError(rc, "mvo_hip_comm_unique_id")
+    return buf.raw
 
 
 def num_pairs(M, N):

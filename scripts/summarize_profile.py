@@ -6,6 +6,9 @@ import json
 import os
 import sys
 
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "monocular-visual-odometry_amd"))
+from mvo_amd.srchash import source_hash  # noqa: E402
+
 out = sys.argv[1]
 print(f"# rocprofv3 summary ({os.path.basename(out)})\n")
 print("Each trace is ONE workload (`--no-large` on config 2 / 5; config 4 / 4r traced on their own).\n"
@@ -62,6 +65,9 @@ for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
                 traffic[wl].setdefault(kern, {})["fetch_bytes"] = int(2 * avg_kib * 1024)
             elif c == "WRITE_SIZE":
                 traffic[wl].setdefault(kern, {})["write_bytes"] = int(avg_kib * 1024)
+for wl in traffic:  # bench.py prints `traffic: null` once a kernel's source no longer matches
+    for kern in traffic[wl]:
+        traffic[wl][kern]["source_hash"] = source_hash(kern)
 if len(sys.argv) > 2:
     json.dump({"note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate runs); "
                        "FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction",
