@@ -193,7 +193,6 @@ struct mvo_hip_context {
   // past done_base (one fill less per solve).  done_ready = the counter holds done_base.
   uint32_t done_base = 0;
   bool done_ready = false;
-  size_t lm_dyn_configured[2] = {0, 0};  // dynamic LDS already granted to k_lm<64> / k_lm<256> on this device
   bool profiling = false;  // record HIP events around the launches (mvo_hip_set_profiling)
   // problem description of the last upload
   bool uploaded = false;
@@ -639,17 +638,7 @@ hipError_t launch_pass(mvo_hip_context* h) {
 
 template <int NT>
 hipError_t launch_lm(mvo_hip_context* h, const SolveParams& prm, bool from_pair_sums = false) {
-  const size_t dyn = sizeof(double) * 10 * (size_t)h->P;
-  // the attribute is per device: remembered per handle (a handle is bound to one device), not per
-  // process -- two handles on two GPUs must each configure their own device
-  size_t& configured = h->lm_dyn_configured[NT == 64 ? 0 : 1];
-  if (dyn > configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lm<NT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-    if (e != hipSuccess) return e;
-    configured = dyn;
-  }
-  hipLaunchKernelGGL(k_lm<NT>, dim3(h->W), dim3(NT), dyn, h->stream, prm, from_pair_sums ? 1 : 0,
+  hipLaunchKernelGGL(k_lm<NT>, dim3(h->W), dim3(NT), 0, h->stream, prm, from_pair_sums ? 1 : 0,
                      h->t.wins,
                      h->t.frames, h->t.initx,
                      from_pair_sums ? h->t.pairs_unit : h->t.pairs,
@@ -674,17 +663,9 @@ hipError_t launch_fold_range(mvo_hip_context* h, uint32_t b0, uint32_t b1) {
 // ... and the whole LM loop of windows [win0, win1) on the second stream
 template <int NT>
 hipError_t launch_lm_range(mvo_hip_context* h, SolveParams prm, uint32_t win0, uint32_t win1, hipStream_t stream) {
-  const size_t dyn = sizeof(double) * 10 * (size_t)h->P;
-  size_t& configured = h->lm_dyn_configured[NT == 64 ? 0 : 1];
-  if (dyn > configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lm<NT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-    if (e != hipSuccess) return e;
-    configured = dyn;
-  }
   prm.fresh = 1;
   prm.win_base = (int32_t)win0;
-  hipLaunchKernelGGL(k_lm<NT>, dim3(win1 - win0), dim3(NT), dyn, stream, prm, 0, h->t.wins, h->t.frames,
+  hipLaunchKernelGGL(k_lm<NT>, dim3(win1 - win0), dim3(NT), 0, stream, prm, 0, h->t.wins, h->t.frames,
                      h->t.initx, h->t.pairs, h->d_partial.as<double>(), h->t.m0, h->t.m1, h->d_pairsum.as<double>(),
                      h->d_states.as<LmState>(), h->d_results, h->d_pair_u.as<double>(), h->d_status,
                      h->d_trace.as<TraceRec>(), h->d_done);
@@ -694,7 +675,7 @@ hipError_t launch_lm_range(mvo_hip_context* h, SolveParams prm, uint32_t win0, u
 hipError_t launch_lm_any(mvo_hip_context* h, SolveParams prm, bool from_pair_sums = false) {
   prm.fresh = h->lm_started ? 0 : 1;  // the first launch of a solve starts from a zeroed state
   h->lm_started = true;
-  return h->P <= 64 ? launch_lm<64>(h, prm, from_pair_sums) : launch_lm<256>(h, prm, from_pair_sums);
+  return h->P <= 64 ? launch_lm<64>(h, prm, from_pair_sums) : launch_lm<MVO_LM_NT_LARGE>(h, prm, from_pair_sums);
 }
 
 // ---- observation-partitioned mode: fold / pass -> per-pair sums -> caller's
@@ -908,7 +889,7 @@ int do_solve(mvo_hip_context* h) {
         used[c & 1] = true;
         HIP_TRY(hipEventRecord(h->ev_chunk[c], s));
         HIP_TRY(hipStreamWaitEvent(q, h->ev_chunk[c], 0));
-        HIP_TRY(h->P <= 64 ? launch_lm_range<64>(h, prm, win0, win1, q) : launch_lm_range<256>(h, prm, win0, win1, q));
+        HIP_TRY(h->P <= 64 ? launch_lm_range<64>(h, prm, win0, win1, q) : launch_lm_range<MVO_LM_NT_LARGE>(h, prm, win0, win1, q));
         ++lm_launches;
       }
       b0 = b1;
@@ -928,15 +909,9 @@ int do_solve(mvo_hip_context* h) {
       HIP_TRY(timed_end());
       ++asm_launches;
     }
-    // S_p never changes without a loss.  Up to 256 pairs every k_lm thread owns one pair for the
-    // whole launch: it sums the pair's slots once itself and keeps them in registers.  Beyond that
-    // the slots are summed once by a launch of their own and the LM loop reads 8 doubles per pair.
-    if (h->P <= 256) {
-      HIP_TRY(launch_lm_any(h, prm, false));
-    } else {
-      HIP_TRY(launch_reduce_slots(h));
-      HIP_TRY(launch_lm_any(h, prm, true));
-    }
+    // S_p never changes without a loss: every k_lm lane owns its (up to four) pairs for the whole
+    // launch, sums their slots once itself and keeps the sums in registers.
+    HIP_TRY(launch_lm_any(h, prm, false));
     ++lm_launches;
   } else {
     if (fold_blocks) {
@@ -1433,7 +1408,6 @@ static __device__ __align__(256) unsigned char scratch[MVO_HIP_NOALLOC_SCRATCH_B
 namespace {
 struct NoallocDevice {
   unsigned char* ptr = nullptr;  // this device's copy of `scratch`
-  size_t lm_dyn[2] = {0, 0};     // dynamic LDS already granted to k_lm<64> / k_lm<256> here
 };
 NoallocDevice g_noalloc[kNaMaxDevices];
 std::mutex g_noalloc_mu;
@@ -1600,31 +1574,20 @@ int mvo_hip_refine_noalloc(int device_ordinal, void* stream, mvo_hip_frame* fram
                      prm.max_len, prm.min_len);
   if (hipGetLastError() != hipSuccess) return MVO_HIP_ERR_DEVICE;
 
-  const size_t dyn = sizeof(double) * 10 * (size_t)P;
   const bool small = P <= 64;
-  {
-    std::lock_guard<std::mutex> lock(g_noalloc_mu);
-    size_t& configured = dev->lm_dyn[small ? 0 : 1];
-    if (dyn > configured) {
-      const void* fn = small ? reinterpret_cast<const void*>(&k_lm<64>) : reinterpret_cast<const void*>(&k_lm<256>);
-      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess)
-        return MVO_HIP_ERR_DEVICE;
-      configured = dyn;
-    }
-  }
   const WinDev* wins = reinterpret_cast<const WinDev*>(sc + kNaWin);
   const PairDev* pairs = reinterpret_cast<const PairDev*>(sc + kNaPairs);
   double* sums = reinterpret_cast<double*>(sc + kNaSums);
   int32_t* ctl = reinterpret_cast<int32_t*>(sc + kNaCtl);
   auto launch = [&](auto kernel, int nt) {
-    hipLaunchKernelGGL(kernel, dim3(1), dim3(nt), dyn, s, prm, 1, wins, fr,
+    hipLaunchKernelGGL(kernel, dim3(1), dim3(nt), 0, s, prm, 1, wins, fr,
                        reinterpret_cast<const double*>(sc + kNaInitX), pairs, (const double*)sums, m0_device,
                        m1_device, sums, reinterpret_cast<LmState*>(sc + kNaState),
                        reinterpret_cast<LmResult*>(sc + kNaResult), (double*)nullptr, ctl, (TraceRec*)nullptr,
                        ctl + 16);
   };
   if (small) launch(k_lm<64>, 64);
-  else launch(k_lm<256>, 256);
+  else launch(k_lm<MVO_LM_NT_LARGE>, MVO_LM_NT_LARGE);
   if (hipGetLastError() != hipSuccess) return MVO_HIP_ERR_DEVICE;
 
   hipLaunchKernelGGL(k_noalloc_finish, dim3(1), dim3(64), 0, s, (const unsigned char*)sc,

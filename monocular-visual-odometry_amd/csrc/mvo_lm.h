@@ -4,19 +4,27 @@
 // LEVENBERG_MARQUARDT, use_nonmonotonic_steps, jacobi scaling, Ceres 1.14 defaults for the rest
 // (TrustRegionMinimizer / LevenbergMarquardtStrategy / TrustRegionStepEvaluator rules).
 //
-// Work split inside the workgroup:
-//   all threads : per-pair geometry + projected moments  (thread per frame pair)   -> LDS
-//                 class sums in pair order, 3x3 block products G_k^T W_kl G_l       -> LDS
-//   wavefront 0 : the <= 15 x 15 damped normal equations, one matrix ROW PER LANE held in
-//                 registers: Gauss-Jordan elimination with v_readlane broadcasts (no LDS, no
-//                 barriers), accept/reject logic executed redundantly by all 64 lanes on
-//                 wave-uniform scalars, per-frame retraction on lanes 0..M-1.
-// The state lives in wave 0's registers for the whole loop; it touches HBM only when the
-// launch begins/ends (pass mode re-enters once per observation pass).
+// Two shapes of workgroup:
+//   k_lm<64>   one wavefront, windows of <= 64 frame pairs (the batched case: thousands of windows):
+//              lane per pair -> LDS, class sums by lanes (j, value)
+//   k_lm<384>  six wavefronts with fixed roles, any window: wavefront 1 + a (a < 5) owns the pairs
+//              (a, b >= M) -- the one long class of frame a -- up to four per lane, and reduces their
+//              ten sums with a register butterfly (v_permlane32/16_swap + DPP, no LDS); wavefront 0
+//              owns the <= 15 pairs (a, b < M), each a class of its own, and the LM step.  The two
+//              roles are two separate loops that meet at the workgroup barriers, so that neither
+//              carries the other's registers (per-pair inputs of four rounds vs the solver state).
+// After that, wavefront 0 alone: prefix / suffix sums of the class totals (W_kl, y_k), the 3 x 3
+// block products G_k^T W_kl G_l, and the LM step: the <= 15 x 15 damped normal equations one matrix
+// ROW PER LANE in registers, Gauss-Jordan with DPP row broadcasts and v_readlane pivots, Ceres'
+// accept / reject logic on wave-uniform scalars, per-frame retraction on lanes 0..M-1.  The solver
+// state lives in wavefront 0's registers from the first evaluation to the last; it touches LDS / HBM
+// only when a launch begins or ends (pass mode re-enters once per observation pass).
 #pragma once
 
 #include "mvo_device.h"
 #include "mvo_kernels.h"
+
+#define MVO_LM_NT_LARGE 384
 
 // Diagnostic build only (-DMVO_LM_STAMPS): thread 0 of window 0 accumulates the shader-clock
 // cycles spent in each phase of an LM iteration into a buffer of its own (mvo_lm_stamps).
@@ -101,6 +109,50 @@ __device__ __forceinline__ double row0_max(double v) {
   return bcast_lane(v, 0);
 }
 
+// ---- 64-lane reductions without LDS (gfx950: v_permlane32_swap / v_permlane16_swap) ------------
+// swap32(a, b): a keeps its lanes 0..31 and receives b's lanes 0..31 in its lanes 32..63; b receives
+// a's lanes 32..63 in its lanes 0..31 and keeps its lanes 32..63.  Hence (a + b) after the swap holds,
+// in lanes 0..31, a(l) + a(l + 32) and, in lanes 32..63, b(l - 32) + b(l): the halving step of a
+// butterfly that trades half of the VALUES for half of the LANES.  swap16 does the same with the odd
+// and even 16-lane rows.
+__device__ __forceinline__ double swap_add32(double a, double b) {
+  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ double swap_add16(double a, double b) {
+  const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+
+// 10 values x 64 lanes -> 10 totals.  After the call lane L holds the total of value
+//   v(L) = ((L >> 5) & 1) * 4 + ((L >> 4) & 1) * 2 + ((L >> 3) & 1)        in `t8` (values 0..7) and of
+//   value 8 + ((L >> 5) & 1)                                               in `t2` (values 8, 9),
+// identical within the 8 lanes (t8) / 32 lanes (t2) of a group.  Fixed order => reproducible.
+__device__ __forceinline__ void wave_reduce10(const double (&v)[10], int lane, double& t8, double& t2) {
+  double w4[4], w2[2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) w4[j] = swap_add32(v[j], v[j + 4]);      // lanes < 32: value j, lanes >= 32: value j + 4
+  double u = swap_add32(v[8], v[9]);                                   // lanes < 32: value 8, lanes >= 32: value 9
+#pragma unroll
+  for (int j = 0; j < 2; ++j) w2[j] = swap_add16(w4[j], w4[j + 2]);    // even rows: value j (+4), odd rows: value j + 2 (+4)
+  const bool b3 = lane & 8;
+  {
+    const double keep = b3 ? w2[1] : w2[0], send = b3 ? w2[0] : w2[1];
+    t8 = keep + dpp_mov_f64<0x128>(send);  // row_ror:8 == lane xor 8
+  }
+  t8 += dpp_mov_f64<0xB1>(t8);
+  t8 += dpp_mov_f64<0x4E>(t8);
+  t8 += dpp_mov_f64<0x141>(t8);
+  u = swap_add16(u, u);                    // every lane: own row + the partner row (xor 16)
+  u += dpp_mov_f64<0xB1>(u);
+  u += dpp_mov_f64<0x4E>(u);
+  u += dpp_mov_f64<0x141>(u);
+  u += dpp_mov_f64<0x140>(u);
+  t2 = u;
+}
+
 // s(t) and s'(t) of IR.cpp:298-309 with one exp and one reciprocal
 __device__ __forceinline__ void d_scale_both(double t, double max_len, double min_len, double& s, double& sp) {
   const double e = exp(-1.0 * t);
@@ -122,23 +174,22 @@ __device__ __forceinline__ int fcol(int i, int fix) { return fix ? 3 * (i >> 1) 
 // per-pair index of (a, b) in the reference's loop order
 __device__ __forceinline__ int pair_index(int N, int a, int b) { return a * (N - 1) - (a * (a - 1)) / 2 + (b - a); }
 
-template <int PARTS>
-struct LmSharedT {
-  LmState st;                                   // solver state (HBM copy only at launch begin/end)
+constexpr int MCX = MVO_MAXM + 1;  // classes per frame a: j = min(b, M) in 0..M
+
+struct LmShared {
+  LmState st;                                   // image of the solver state between launches (HBM <-> LDS at begin / end)
   double zvec[MVO_MAXM][3], zt[MVO_MAXM], zs[MVO_MAXM], zsp[MVO_MAXM];
   double G[MVO_MAXM][9];                        // G[k][3*row + col]: columns (s_k jl0, s_k jl1, s'_k v_k)
-  double cls[MVO_MAXM * (MVO_MAXM + 1)][10];    // class (a, j = min(b, M)): T(6) q(3) cost(1)
-  double clsp[PARTS > 1 ? MVO_MAXM * (MVO_MAXM + 1) * 10 : 1][PARTS];  // strided parts of the class sums
-  double C1[MVO_MAXM * (MVO_MAXM + 1)][10];     // prefix of cls over a: C1[k][j] = sum_{a<=k} cls[a][j]
+  double cls[MVO_MAXM * MCX][10];               // class (a, j = min(b, M)): T(6) q(3) cost(1)   (k_lm<384>)
+  double kk[MVO_MAXM][10];                      // the pair (k, k) alone: direction columns only (see below)
+  double C1[MVO_MAXM * MCX][10];                // prefix of the classes over a: C1[k][j] = sum_{a<=k} cls[a][j]
   double W[MVO_MAXM * MVO_MAXM][6], y[MVO_MAXM][3];  // per block (k,l): sum of T; per frame: sum of q
-  double Hz[MVO_MAXC * MVO_MAXC], gz[MVO_MAXC]; // full 3M system at z
+  double Hz[MVO_MAXC * MVO_MAXC], gz[MVO_MAXC]; // second system buffer (st.H is the first) and the gradient at z
   double cost_z;
   int32_t go, phase;
-  int32_t hsel, pad_;  // which of {st.H, Hz} holds the ACCEPTED system (the other receives the next evaluation)
 };
 
-// Working copy of the solver state inside lm_advance (wavefront 0): filled from the LDS LmState on
-// entry, flushed on exit, so nothing is live in registers across the evaluation phases.
+// The solver state in wavefront 0's registers.
 struct LmRegs {
   // lane l < n: gradient, jacobi scale, LM diagonal, H_ll of active column l (row l of H is in LDS)
   double g, js, dg, hdiag;
@@ -151,13 +202,12 @@ struct LmRegs {
       ntrace;
 };
 
-__device__ __forceinline__ void regs_load(LmRegs& r, const LmState& g, const double* __restrict__ Hacc, int fix,
-                                          int n, int lane) {
+__device__ __forceinline__ void regs_load(LmRegs& r, const LmState& g, int fix, int n, int lane) {
   const int l = lane < n ? lane : 0, k = lane < MVO_MAXM ? lane : 0;
   r.g = g.g[l];
   r.js = g.jscale[l];
   r.dg = g.diag[l];
-  r.hdiag = Hacc[fcol(l, fix) * (MVO_MAXC + 1)];
+  r.hdiag = g.H[fcol(l, fix) * (MVO_MAXC + 1)];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     r.xv[j] = g.x_vec[k][j];
@@ -244,8 +294,7 @@ __device__ __forceinline__ void lm_terminate(LmRegs& r, int termination, int rea
 
 // Lanes k < M publish the point to evaluate and everything the evaluation needs per frame:
 // s_k, s'_k and G_k = [s_k J_loc(v_k) | s'_k v_k], J_loc(v) = [[-2vy, 2vz], [2vx, 0], [0, -2vx]].
-template <class SH>
-__device__ __forceinline__ void lm_publish_point(SH& sh, const SolveParams& prm, int M, int lane,
+__device__ __forceinline__ void lm_publish_point(LmShared& sh, const SolveParams& prm, int M, int lane,
                                                  const double v[3], double t) {
   if (lane < M) {
     const int k = lane;
@@ -315,14 +364,13 @@ __device__ __forceinline__ void gj_eliminate(double (&a)[MVO_MAXC], double& rhs,
 
 // Wave-0 control logic: Ceres 1.14 TrustRegionMinimizer::Minimize restated around the evaluation
 // that was just completed at z (= x0 in PH_EVAL_X0, the candidate in PH_EVAL_CAND); the system
-// assembled at z is in sh.Hz / sh.gz / sh.cost_z.  Every lane executes it; scalars are uniform.
+// assembled at z is in the buffer `hsel` does NOT select (hsel ? sh.Hz : st.H holds the ACCEPTED
+// system), gradient in sh.gz, cost in sh.cost_z.  Every lane executes it; scalars are uniform.
 // Returns 1 when a new candidate awaits evaluation (published in sh.zvec/zt), 0 when done.
-template <class SH>
-__device__ int lm_advance_body(LmRegs& r, SH& sh, const SolveParams& prm, int M, int n, int lane,
+__device__ int lm_advance_body(LmRegs& r, LmShared& sh, const SolveParams& prm, int M, int n, int lane,
                                TraceRec* __restrict__ trace, int& hsel MVO_STAMP_PARAM) {
   LmState& st = sh.st;
   const int fix = prm.fix_length;
-  // accepted system: hsel ? sh.Hz : st.H
   const double* __restrict__ Hnew = hsel ? st.H : sh.Hz;  // the system just assembled at z
 #ifdef MVO_LM_STAMPS
   const bool stamp_on = stamp_acc_ != nullptr;
@@ -606,9 +654,8 @@ __device__ __forceinline__ void pair_load(PairIn& in, int p, int N, int M, bool 
 }
 
 // projected moments of one pair at the published point: T = P S P, q = P S u, cost
-template <class SH>
-__device__ __forceinline__ void pair_eval(const PairIn& in, const SH& sh, int M, int pass_mode,
-                                          double* __restrict__ o) {
+__device__ __forceinline__ void pair_eval(const PairIn& in, const LmShared& sh, int M, int pass_mode,
+                                          double (&o)[10]) {
   const int kmax = in.b < M - 1 ? in.b : M - 1;
   double bx = 0.0, by = 0.0, bz = 0.0;
   for (int k = in.a; k <= kmax; ++k) {  // IR.cpp:466-577: s_a v_a + ... left to right
@@ -650,8 +697,8 @@ __device__ __forceinline__ int sym6(int r, int c) {
 // MODE 0: second moments only (no loss; done once per solve)
 // MODE 1: pass at the published point, w = 1      (assembly_mode = PASSES)
 // MODE 2: pass at the published point, Cauchy(0.5)
-template <int MODE, int NT, class SH>
-__device__ __forceinline__ void inline_pass(const SH& sh, const PairDev* __restrict__ wp, int P, int M,
+template <int MODE, int NT>
+__device__ __forceinline__ void inline_pass(const LmShared& sh, const PairDev* __restrict__ wp, int P, int M,
                                             const double* __restrict__ fr, const double* __restrict__ m0,
                                             const double* __restrict__ m1, double* pair_sums) {
   const int lane = threadIdx.x & 63;
@@ -705,6 +752,62 @@ __device__ __forceinline__ void inline_pass(const SH& sh, const PairDev* __restr
   }
 }
 
+// k_lm<384>, wavefronts 1..5: the loop of a class wavefront.  Wavefront 1 + a evaluates the pairs
+// (a, b), b = M + lane + 64 r (r < 4), adds them up and leaves the class total in sh.cls[a][M].  It
+// executes exactly the workgroup barriers wavefront 0 executes (marked B0 / B1 / B2 on both sides).
+template <int NT>
+__device__ __forceinline__ void lm_class_wave(LmShared& sh, const SolveParams& prm, int a, int lane, int M, int N, int P,
+                                              bool& need_pass, int unit_slots, const PairDev* __restrict__ wp,
+                                              const double* partial, uint32_t pair_off, const double* __restrict__ fr,
+                                              const double* __restrict__ m0, const double* __restrict__ m1,
+                                              double* my_sums) {
+  constexpr int ROUNDS = 4;  // class (a, M) has at most MVO_HIP_MAX_FRAMES - 1 - M <= 256 pairs
+  int my_p[ROUNDS];
+  bool my_ok[ROUNDS];
+#pragma unroll
+  for (int rr = 0; rr < ROUNDS; ++rr) {
+    const int b = M + lane + 64 * rr;
+    my_ok[rr] = a < M && b <= N - 2;
+    my_p[rr] = my_ok[rr] ? pair_index(N, a, b) : 0;
+  }
+  PairIn in[ROUNDS];
+  bool have_in = false;
+  while (!need_pass) {
+    if (prm.inline_eval && prm.pass_mode) {
+      if (prm.use_loss) inline_pass<2, NT>(sh, wp, P, M, fr, m0, m1, my_sums);
+      else inline_pass<1, NT>(sh, wp, P, M, fr, m0, m1, my_sums);
+      __syncthreads();  // B0
+    }
+    if (!have_in) {
+#pragma unroll
+      for (int rr = 0; rr < ROUNDS; ++rr)
+        if (rr == 0 || __any(my_ok[rr])) pair_load(in[rr], my_p[rr], N, M, unit_slots != 0, wp, partial, pair_off, fr);
+      have_in = !prm.pass_mode;
+    }
+    double acc[10];
+#pragma unroll
+    for (int v = 0; v < 10; ++v) acc[v] = 0.0;
+#pragma unroll
+    for (int rr = 0; rr < ROUNDS; ++rr)
+      if (rr == 0 || __any(my_ok[rr])) {
+        double o[10];
+        pair_eval(in[rr], sh, M, prm.pass_mode, o);
+#pragma unroll
+        for (int v = 0; v < 10; ++v) acc[v] += my_ok[rr] ? o[v] : 0.0;
+      }
+    double t8, t2;
+    wave_reduce10(acc, lane, t8, t2);
+    if (a < M) {
+      if ((lane & 7) == 0) sh.cls[a * MCX + M][reduce8_value_of_lane(lane)] = t8;
+      if ((lane & 31) == 0) sh.cls[a * MCX + M][8 + (lane >> 5)] = t2;
+    }
+    __syncthreads();  // B1: class totals are in LDS
+    __syncthreads();  // B2: wavefront 0 has taken its step and published the next point
+    if (!sh.go) break;
+    if (prm.pass_mode && !prm.inline_eval) need_pass = true;
+  }
+}
+
 template <int NT>
 __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, const WinDev* __restrict__ wins,
                                            const double* __restrict__ frames, const double* __restrict__ init_x,
@@ -715,13 +818,14 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
                                            LmResult* __restrict__ results,
                                            double* __restrict__ pair_u, int32_t* __restrict__ win_status,
                                            TraceRec* __restrict__ trace, int32_t* __restrict__ done_count) {
-  constexpr int ROUNDS = NT >= 256 ? 4 : 1;  // pairs prefetched per thread (P <= 64 when NT == 64)
-  constexpr int PARTS = NT >= 256 ? 8 : 1;   // strided parts of a long class sum
-  extern __shared__ double pairbuf[];        // P x 10: T(6) q(3) cost(1)
-  __shared__ LmSharedT<PARTS> sh;
+  constexpr bool LARGE = NT > 64;
+  static_assert(NT == 64 || NT == MVO_LM_NT_LARGE, "one wavefront, or five class wavefronts + one for the short pairs");
+  __shared__ LmShared sh;
+  __shared__ double pairbuf[LARGE ? 1 : 64 * 10];  // k_lm<64>: P x 10: T(6) q(3) cost(1)
   const int w = (int)blockIdx.x + prm.win_base, tid = threadIdx.x;
   const int lane = tid & 63;
-  const bool wave0 = tid < 64;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool wave0 = wv == 0;
   LmState* __restrict__ gst = states + w;
   const bool fresh = prm.fresh != 0;
   if (!fresh && gst->status != 0) return;  // uniform: every thread reads the same word
@@ -742,6 +846,8 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
   // are identity rows) -- so the second buffer starts from zero like the first.
   for (int i = tid; i < MVO_MAXC * MVO_MAXC; i += NT) sh.Hz[i] = 0.0;
   __syncthreads();
+  LmRegs r;      // wavefront 0: the solver state, in registers until the launch ends
+  int hsel = 0;  // which of {st.H, Hz} holds the ACCEPTED system; between launches it is st.H
   if (wave0) {
     LmState& st = sh.st;
     const int k = lane < M ? lane : 0;
@@ -754,10 +860,9 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
     }
     if (st.phase != PH_EVAL_CAND) lm_publish_point(sh, prm, M, lane, st.x_vec[k], st.x_t[k]);
     else lm_publish_point(sh, prm, M, lane, st.c_vec[k], st.c_t[k]);
-    if (lane == 0) {
-      sh.phase = st.phase;
-      sh.hsel = 0;  // between launches the accepted system lives in st.H
-    }
+    if (lane == 0) sh.phase = st.phase;
+    wave0_sync();
+    regs_load(r, st, fix, n, lane);
   }
   __syncthreads();
 
@@ -770,9 +875,8 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
 #endif
   bool need_pass = false;
   if (sh.phase == PH_START) {
-    if (tid == 0) sh.st.phase = PH_EVAL_X0;
+    r.phase = PH_EVAL_X0;
     need_pass = prm.pass_mode != 0 && !prm.inline_eval;
-    __syncthreads();
   }
   double* my_sums = pair_sums + (size_t)win.pair_off * 8;
   if (prm.inline_eval && !prm.pass_mode) {  // no loss: the moments are folded once, here
@@ -780,145 +884,132 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
     __syncthreads();
   }
 
+  // ---- who evaluates which frame pair (fixed for the launch) ---------------------------------
+  // k_lm<64>:  lane p evaluates pair p.
+  // k_lm<384>: wavefront 1 + a takes the pairs (a, b >= M) (lm_class_wave); wavefront 0's lane i the
+  //            i-th pair with b < M (a = 0: b = 0..M-1, a = 1: b = 1..M-1, ...), then the LM step.
+  if (LARGE && !wave0) lm_class_wave<NT>(sh, prm, wv - 1, lane, M, N, P, need_pass, unit_slots, wp, partial, win.pair_off, fr, m0, m1, my_sums);
+  int my_p0 = lane < P ? lane : 0;
+  bool my_ok0 = lane < P;
+  int my_a = 0, my_j = 0;  // k_lm<384>: the short pair's (a, b)
+  if (LARGE) {
+    const int nshort = (M * (M + 1)) / 2;
+    upper_block(M, lane < nshort ? lane : 0, my_a, my_j);  // (a, b) with a <= b < M, row-major: the same enumeration
+    my_ok0 = lane < nshort;
+    my_p0 = pair_index(N, my_a, my_j);
+  }
   PairIn in0;
-  in0.a = in0.b = 0;
-  bool have0 = false;
-  while (!need_pass) {
+  bool have_in = false;
+
+  while (!need_pass && (!LARGE || wave0)) {
     MVO_STAMP(0);
     // ---------------- evaluation at z: assemble J^T J, J^T r, cost ----------------
     if (prm.inline_eval && prm.pass_mode) {  // one observation pass per evaluation, in this workgroup
       if (prm.use_loss) inline_pass<2, NT>(sh, wp, P, M, fr, m0, m1, my_sums);
       else inline_pass<1, NT>(sh, wp, P, M, fr, m0, m1, my_sums);
-      __syncthreads();
+      __syncthreads();  // B0
     }
-    // (1) per frame pair: projected moments.  Loads of all rounds are issued before any use.
-    // Without a loss the moments never change: the first round's inputs stay in registers.
+    // (1) per frame pair: projected moments.  Without a loss the moments never change: the inputs are
+    // loaded once and stay in registers.  Loads are unconditional, at a clamped pair index: a load
+    // inside a divergent `if` is waited for on the spot, which would serialise the L2 latencies.
+    if (!have_in) {
+      pair_load(in0, my_p0, N, M, unit_slots != 0, wp, partial, win.pair_off, fr);
+      have_in = !prm.pass_mode;
+    }
     {
-      PairIn in[ROUNDS];
-      if (!have0) {
-        if (tid < P) pair_load(in0, tid, N, M, unit_slots != 0, wp, partial, win.pair_off, fr);
-        have0 = !prm.pass_mode;
-      }
-      // unconditional, at a clamped pair index: a load inside a divergent `if` is waited for on the
-      // spot, which would serialise the rounds' L2 latencies instead of overlapping them
+      double o[10];
+      pair_eval(in0, sh, M, prm.pass_mode, o);
+      if (my_ok0) {
+        double* __restrict__ dst = LARGE ? sh.cls[my_a * MCX + my_j] : pairbuf + lane * 10;
 #pragma unroll
-      for (int rr = 1; rr < ROUNDS; ++rr) {
-        const int p = tid + rr * NT;
-        pair_load(in[rr], p < P ? p : P - 1, N, M, unit_slots != 0, wp, partial, win.pair_off, fr);
-      }
-      if (tid < P) pair_eval(in0, sh, M, prm.pass_mode, pairbuf + (size_t)tid * 10);
+        for (int v = 0; v < 10; ++v) dst[v] = o[v];
+        if (in0.a == in0.b) {
 #pragma unroll
-      for (int rr = 1; rr < ROUNDS; ++rr) {
-        const int p = tid + rr * NT;
-        if (p < P) pair_eval(in[rr], sh, M, prm.pass_mode, pairbuf + (size_t)p * 10);
-      }
-      for (int p = tid + ROUNDS * NT; p < P; p += NT) {
-        PairIn x;
-        pair_load(x, p, N, M, unit_slots != 0, wp, partial, win.pair_off, fr);
-        pair_eval(x, sh, M, prm.pass_mode, pairbuf + (size_t)p * 10);
+          for (int v = 0; v < 10; ++v) sh.kk[in0.a][v] = o[v];
+        }
       }
     }
-    __syncthreads();
+    if (LARGE) __syncthreads();  // B1: the class wavefronts' totals are in LDS
+    else wave0_sync();
     MVO_STAMP(1);
-    // (2) class sums in pair order.  Class (a, j), j = min(b, M): j < M is the single pair b = j,
-    // j = M collects the pairs b = M .. N-2 (those with a fixed-frame offset), summed in PARTS
-    // strided parts.  The free frames of a class are a .. min(j, M-1).
-    constexpr int MCX = MVO_MAXM + 1;  // fixed table stride: index arithmetic with constant divisors
-    for (int item = tid; item < MVO_MAXM * MCX * PARTS; item += NT) {
-      const int part = item % PARTS, c = item / PARTS, a = c / MCX, j = c % MCX;
-      if (a >= M || j > M) continue;
-      double acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-      if (j >= a) {
-        const int b0 = j, b1 = (j == M) ? N - 2 : j;
-        if (b0 <= N - 2) {
-          const double2* __restrict__ src = reinterpret_cast<const double2*>(pairbuf + (size_t)pair_index(N, a, b0) * 10);
-          for (int b = b0 + part; b <= b1; b += PARTS) {
-            const double2* __restrict__ q = src + (b - b0) * 5;
+    {
+      // (2) + (3a) classes in pair order and their prefix over a:  C1[k][j] = sum_{a <= k} cls[a][j].
+      // Class (a, j), j = min(b, M): j < M is the single pair b = j, j = M collects the pairs
+      // b = M .. N-2 (those with a fixed-frame offset).  Lane (j, v) walks a.
+      if (lane < MCX * 10) {
+        const int j = lane / 10, v = lane - 10 * j;
+        double x[MVO_MAXM];
+        if (LARGE) {
 #pragma unroll
-            for (int v = 0; v < 5; ++v) {
-              const double2 t = q[v];
-              acc[2 * v] += t.x;
-              acc[2 * v + 1] += t.y;
+          for (int a = 0; a < MVO_MAXM; ++a) x[a] = sh.cls[a * MCX + j][v];  // reads issue back to back
+        } else {
+          // pairs of class (a, j), a <= j: one for j < M, the N - 1 - M pairs b >= M for j = M; the
+          // five frames' loads of one step are independent (clamped rows for the classes that do not exist)
+          const int cnt = (j < M) ? 1 : (j == M ? N - 1 - M : 0);
+          int row[MVO_MAXM];
+#pragma unroll
+          for (int a = 0; a < MVO_MAXM; ++a) {
+            x[a] = 0.0;
+            row[a] = (a < M && a <= j && j <= M) ? pair_index(N, a, j) : -1;
+          }
+          for (int i = 0; i < cnt; ++i) {
+#pragma unroll
+            for (int a = 0; a < MVO_MAXM; ++a) {
+              const double t = pairbuf[(row[a] >= 0 ? row[a] + i : 0) * 10 + v];
+              x[a] += row[a] >= 0 ? t : 0.0;
             }
           }
         }
-      }
-#pragma unroll
-      for (int v = 0; v < 10; ++v) {
-        if (PARTS == 1) sh.cls[c][v] = acc[v];
-        else sh.clsp[c * 10 + v][part] = acc[v];
-      }
-    }
-    __syncthreads();
-    if (PARTS > 1) {
-      for (int cv = tid; cv < MVO_MAXM * MCX * 10; cv += NT) {
         double acc = 0.0;
 #pragma unroll
-        for (int part = 0; part < PARTS; ++part) acc += sh.clsp[cv][part];
-        sh.cls[cv / 10][cv % 10] = acc;
-      }
-      __syncthreads();
-    }
-    MVO_STAMP(2);
-    // (3) W_kl = sum of T over the pairs whose free frames contain k and l (classes a <= k,
-    // j >= l), y_k = sum of q over those containing k, cost = sum over all classes: a 2-D
-    // prefix/suffix sum, done in two short stages instead of 30-term sums per entry.
-    // Running sums: one thread per (j, value) walks a, one thread per (k, value) walks j.
-    // (3a) prefix over a:  C1[k][j] = sum_{a <= k} cls[a][j]
-    if (tid < MCX * 10) {
-      const int j = tid / 10, v = tid - 10 * j;
-      double x[MVO_MAXM];
-#pragma unroll
-      for (int a = 0; a < MVO_MAXM; ++a) x[a] = sh.cls[a * MCX + j][v];  // reads issue back to back
-      double acc = 0.0;
-#pragma unroll
-      for (int a = 0; a < MVO_MAXM; ++a)
-        if (a < M && j <= M) {
-          acc += x[a];
-          sh.C1[a * MCX + j][v] = acc;
-        }
-    }
-    wave0_sync();  // phases (3a), (3b), (4) and the LM step all run in wavefront 0: no workgroup barrier
-    // (3b) suffix over j:  W_kl = sum_{j >= l} C1[k][j] (l > k).  The pair (k,k) is kept apart:
-    // its baseline is s_k v_k alone, so r does not depend on t_k at all (IR.cpp:466-471 normalises
-    // the scale away) and its scale row/column is exactly zero instead of rounding noise of the
-    // size of S -- the diagonal entries W_kk, y_k leave class (k,k) out:
-    // sum_{j > k} C1[k][j] + C1[k-1][k].
-    if (tid < MVO_MAXM * 10) {
-      const int k = tid / 10, v = tid - 10 * k;
-      if (k < M && v < 9) {
-        double x[MCX];
-#pragma unroll
-        for (int j = 0; j < MCX; ++j) x[j] = sh.C1[k * MCX + j][v];
-        const double xe = sh.C1[(k > 0 ? k - 1 : 0) * MCX + k][v];
-        double acc = 0.0;
-#pragma unroll
-        for (int j = MCX - 1; j >= 1; --j)
-          if (j <= M && j > k) {
-            acc += x[j];
-            if (j < M && v < 6) sh.W[k * MVO_MAXM + j][v] = acc;
+        for (int a = 0; a < MVO_MAXM; ++a)
+          if (a < M && j <= M) {
+            acc += (a <= j) ? x[a] : 0.0;
+            sh.C1[a * MCX + j][v] = acc;
           }
-        if (k > 0) acc += xe;
-        if (v < 6) sh.W[k * MVO_MAXM + k][v] = acc;
-        else sh.y[k][v - 6] = acc;
-      } else if (k == 0 && v == 9) {
-        // cost: all classes; class (a, j) has a <= min(j, M-1)
-        double c = 0.0;
-#pragma unroll
-        for (int j = 0; j < MCX; ++j)
-          if (j <= M) c += sh.C1[(j < M ? j : M - 1) * MCX + j][9];
-        sh.cost_z = c;
       }
-    }
-    wave0_sync();  // phases (3a), (3b), (4) and the LM step all run in wavefront 0: no workgroup barrier
-    MVO_STAMP(3);
-    // (4) 3x3 blocks G_k^T W_kl G_l, one ROW of a block per thread (all of it fits one wavefront
-    // round: 45 rows + 15 gradient entries), and gradient entries G_k^T y_k
-    {
-      const int nkl = (M * (M + 1)) / 2, nB = nkl * 3;
-      for (int item = tid; item < nB + 3 * M; item += NT) {
-        if (item < nB) {
-          const int t = item / 3, i = item - 3 * t;
+      wave0_sync();
+      MVO_STAMP(2);
+      // (3b) suffix over j:  W_kl = sum_{j >= l} C1[k][j] (l > k).  The pair (k,k) is kept apart:
+      // its baseline is s_k v_k alone, so r does not depend on t_k at all (IR.cpp:466-471 normalises
+      // the scale away) and its scale row/column is exactly zero instead of rounding noise of the
+      // size of S -- the diagonal entries W_kk, y_k leave class (k,k) out:
+      // sum_{j > k} C1[k][j] + C1[k-1][k].
+      if (lane < MVO_MAXM * 10) {
+        const int k = lane / 10, v = lane - 10 * k;
+        if (k < M && v < 9) {
+          double x[MCX];
+#pragma unroll
+          for (int j = 0; j < MCX; ++j) x[j] = sh.C1[k * MCX + j][v];
+          const double xe = sh.C1[(k > 0 ? k - 1 : 0) * MCX + k][v];
+          double acc = 0.0;
+#pragma unroll
+          for (int j = MCX - 1; j >= 1; --j)
+            if (j <= M && j > k) {
+              acc += x[j];
+              if (j < M && v < 6) sh.W[k * MVO_MAXM + j][v] = acc;
+            }
+          if (k > 0) acc += xe;
+          if (v < 6) sh.W[k * MVO_MAXM + k][v] = acc;
+          else sh.y[k][v - 6] = acc;
+        } else if (k == 0 && v == 9) {
+          // cost: all classes; class (a, j) has a <= min(j, M-1)
+          double c = 0.0;
+#pragma unroll
+          for (int j = 0; j < MCX; ++j)
+            if (j <= M) c += sh.C1[(j < M ? j : M - 1) * MCX + j][9];
+          sh.cost_z = c;
+        }
+      }
+      wave0_sync();
+      MVO_STAMP(3);
+      // (4) 3x3 blocks G_k^T W_kl G_l, one ROW of a block per lane (45 rows + 15 gradient entries fit
+      // the wavefront), and gradient entries G_k^T y_k
+      {
+        const int nkl = (M * (M + 1)) / 2, nB = nkl * 3;
+        double* __restrict__ Hw = hsel ? sh.st.H : sh.Hz;
+        if (lane < nB) {
+          const int t = lane / 3, i = lane - 3 * t;
           int k, l;
           upper_block(M, t, k, l);
           const int kl = k * MVO_MAXM + l;
@@ -938,46 +1029,36 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
             for (int jj = 0; jj < 3; ++jj) val[jj] = gw[0] * Gl[jj] + gw[1] * Gl[3 + jj] + gw[2] * Gl[6 + jj];
           }
           if (k == l && i < 2) {  // the pair (k,k): direction columns only
-            const double* Ts = sh.cls[k * MCX + k];
+            const double* Ts = sh.kk[k];
             double gw[3];
 #pragma unroll
             for (int m = 0; m < 3; ++m) gw[m] = gk[0] * Ts[sym6(0, m)] + gk[1] * Ts[sym6(1, m)] + gk[2] * Ts[sym6(2, m)];
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) val[jj] += gw[0] * Gl[jj] + gw[1] * Gl[3 + jj] + gw[2] * Gl[6 + jj];
           }
-          double* __restrict__ Hw = sh.hsel ? sh.st.H : sh.Hz;
 #pragma unroll
           for (int jj = 0; jj < 3; ++jj)
             if (k != l || jj >= i) {  // diagonal blocks: the upper entry is mirrored, H stays symmetric
               Hw[(3 * k + i) * MVO_MAXC + 3 * l + jj] = val[jj];
               Hw[(3 * l + jj) * MVO_MAXC + 3 * k + i] = val[jj];
             }
-        } else {
-          const int k = (item - nB) / 3, i = (item - nB) - 3 * k;
+        } else if (lane < nB + 3 * M) {
+          const int k = (lane - nB) / 3, i = (lane - nB) - 3 * k;
           double gi = sh.G[k][i] * sh.y[k][0] + sh.G[k][3 + i] * sh.y[k][1] + sh.G[k][6 + i] * sh.y[k][2];
           if (i < 2) {
-            const double* qs = &sh.cls[k * MCX + k][6];
+            const double* qs = &sh.kk[k][6];
             gi += sh.G[k][i] * qs[0] + sh.G[k][3 + i] * qs[1] + sh.G[k][6 + i] * qs[2];
           }
           sh.gz[3 * k + i] = gi;
         }
       }
-    }
-    wave0_sync();  // phases (3a), (3b), (4) and the LM step all run in wavefront 0: no workgroup barrier
-    MVO_STAMP(4);
-    // ---------------- wavefront 0: accept/reject, damping, next candidate ----------------
-    if (wave0) {
-      LmRegs r;
-      regs_load(r, sh.st, sh.hsel ? sh.Hz : sh.st.H, fix, n, lane);
-      int hsel = sh.hsel;
+      wave0_sync();
+      MVO_STAMP(4);
+      // ---------------- accept/reject, damping, next candidate ----------------
       const int go = lm_advance_body(r, sh, prm, M, n, lane, (w == 0) ? trace : nullptr, hsel MVO_STAMP_ARG);
-      regs_store(r, sh.st, lane);
-      if (lane == 0) {
-        sh.go = go;
-        sh.hsel = hsel;
-      }
+      if (lane == 0) sh.go = go;
     }
-    __syncthreads();
+    __syncthreads();  // B2
     MVO_STAMP(5);
     if (!sh.go) break;
     if (prm.pass_mode && !prm.inline_eval) need_pass = true;
@@ -996,8 +1077,13 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
       o[3] = nb;
     }
   }
+  // the solver state leaves the registers: LDS image, then HBM (pass mode re-enters with it)
+  if (wave0) {
+    regs_store(r, sh.st, lane);
+    if (lane == 0) sh.phase = hsel;
+  }
   __syncthreads();
-  if (sh.hsel) {  // bring the accepted system home before the state leaves LDS
+  if (sh.phase) {  // bring the accepted system home before the state leaves LDS
     for (int i = tid; i < MVO_MAXC * MVO_MAXC; i += NT) sh.st.H[i] = sh.Hz[i];
     __syncthreads();
   }
