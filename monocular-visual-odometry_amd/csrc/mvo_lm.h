@@ -7,12 +7,13 @@
 // Two shapes of workgroup:
 //   k_lm<64>   one wavefront, windows of <= 64 frame pairs (the batched case: thousands of windows):
 //              lane per pair -> LDS, class sums by lanes (j, value)
-//   k_lm<384>  six wavefronts with fixed roles, any window: wavefront 1 + a (a < 5) owns the pairs
-//              (a, b >= M) -- the one long class of frame a -- up to four per lane, and reduces their
-//              ten sums with a register butterfly (v_permlane32/16_swap + DPP, no LDS); wavefront 0
+//   k_lm<256>  four wavefronts with fixed roles (one per SIMD: 512 registers each), any window:
+//              wavefronts 1..3 own the pairs (a, b >= M) -- the one long class of frame a; frames
+//              a = w - 1 and a = w + 2 -- up to four per lane and frame, and reduce their ten sums per
+//              frame with a register butterfly (v_permlane32/16_swap + DPP, no LDS); wavefront 0
 //              owns the <= 15 pairs (a, b < M), each a class of its own, and the LM step.  The two
 //              roles are two separate loops that meet at the workgroup barriers, so that neither
-//              carries the other's registers (per-pair inputs of four rounds vs the solver state).
+//              carries the other's registers (per-pair inputs of eight slots vs the solver state).
 // After that, wavefront 0 alone: prefix / suffix sums of the class totals (W_kl, y_k), the 3 x 3
 // block products G_k^T W_kl G_l, and the LM step: the <= 15 x 15 damped normal equations one matrix
 // ROW PER LANE in registers, Gauss-Jordan with DPP row broadcasts and v_readlane pivots, Ceres'
@@ -24,7 +25,7 @@
 #include "mvo_device.h"
 #include "mvo_kernels.h"
 
-#define MVO_LM_NT_LARGE 384
+#define MVO_LM_NT_LARGE 256
 
 // Diagnostic build only (-DMVO_LM_STAMPS): thread 0 of window 0 accumulates the shader-clock
 // cycles spent in each phase of an LM iteration into a buffer of its own (mvo_lm_stamps).
@@ -180,12 +181,11 @@ struct LmShared {
   LmState st;                                   // image of the solver state between launches (HBM <-> LDS at begin / end)
   double zvec[MVO_MAXM][3], zt[MVO_MAXM], zs[MVO_MAXM], zsp[MVO_MAXM];
   double G[MVO_MAXM][9];                        // G[k][3*row + col]: columns (s_k jl0, s_k jl1, s'_k v_k)
-  double cls[MVO_MAXM * MCX][10];               // class (a, j = min(b, M)): T(6) q(3) cost(1)   (k_lm<384>)
+  double cls[MVO_MAXM * MCX][10];               // class (a, j = min(b, M)): T(6) q(3) cost(1)   (k_lm<256>)
   double kk[MVO_MAXM][10];                      // the pair (k, k) alone: direction columns only (see below)
   double C1[MVO_MAXM * MCX][10];                // prefix of the classes over a: C1[k][j] = sum_{a<=k} cls[a][j]
-  double W[MVO_MAXM * MVO_MAXM][6], y[MVO_MAXM][3];  // per block (k,l): sum of T; per frame: sum of q
+  double D[MVO_MAXM * MCX][10];                 // ... and suffix over j: D[k][j] = sum_{j'>=j} C1[k][j']
   double Hz[MVO_MAXC * MVO_MAXC], gz[MVO_MAXC]; // second system buffer (st.H is the first) and the gradient at z
-  double cost_z;
   int32_t go, phase;
 };
 
@@ -365,7 +365,7 @@ __device__ __forceinline__ void gj_eliminate(double (&a)[MVO_MAXC], double& rhs,
 // Wave-0 control logic: Ceres 1.14 TrustRegionMinimizer::Minimize restated around the evaluation
 // that was just completed at z (= x0 in PH_EVAL_X0, the candidate in PH_EVAL_CAND); the system
 // assembled at z is in the buffer `hsel` does NOT select (hsel ? sh.Hz : st.H holds the ACCEPTED
-// system), gradient in sh.gz, cost in sh.cost_z.  Every lane executes it; scalars are uniform.
+// system), gradient in sh.gz, cost in sh.D.  Every lane executes it; scalars are uniform.
 // Returns 1 when a new candidate awaits evaluation (published in sh.zvec/zt), 0 when done.
 __device__ int lm_advance_body(LmRegs& r, LmShared& sh, const SolveParams& prm, int M, int n, int lane,
                                TraceRec* __restrict__ trace, int& hsel MVO_STAMP_PARAM) {
@@ -386,7 +386,8 @@ __device__ int lm_advance_body(LmRegs& r, LmShared& sh, const SolveParams& prm, 
   // Ceres 1.14 rejects non-finite residuals (ResidualBlock::Evaluate / IsEvaluationValid): at the
   // initial point the minimizer fails before any step; a candidate that "failed to evaluate" gets
   // cost = max and is rejected.  A NaN/Inf residual makes the summed cost non-finite.
-  const double cost_z = (first || isfinite(sh.cost_z)) ? sh.cost_z : DBL_MAX;
+  const double cost_raw = sh.D[(MVO_MAXM - 1) * MCX][9];  // all classes: prefix over every a, suffix from j = 0
+  const double cost_z = (first || isfinite(cost_raw)) ? cost_raw : DBL_MAX;
   if (first && !isfinite(cost_z)) {
     r.iteration = 0;
     r.ntrace = 1;  // iteration 0 is the one (failed) record: summary.iterations = 0
@@ -653,18 +654,34 @@ __device__ __forceinline__ void pair_load(PairIn& in, int p, int N, int M, bool 
   }
 }
 
-// projected moments of one pair at the published point: T = P S P, q = P S u, cost
-__device__ __forceinline__ void pair_eval(const PairIn& in, const LmShared& sh, int M, int pass_mode,
-                                          double (&o)[10]) {
-  const int kmax = in.b < M - 1 ? in.b : M - 1;
-  double bx = 0.0, by = 0.0, bz = 0.0;
-  for (int k = in.a; k <= kmax; ++k) {  // IR.cpp:466-577: s_a v_a + ... left to right
-    const double tx = sh.zs[k] * sh.zvec[k][0], ty = sh.zs[k] * sh.zvec[k][1], tz = sh.zs[k] * sh.zvec[k][2];
-    if (k == in.a) { bx = tx; by = ty; bz = tz; } else { bx += tx; by += ty; bz += tz; }
+// s_a v_a + ... + s_kmax v_kmax of the published point, summed left to right (IR.cpp:466-577).  All
+// five frames are loaded up front (independent LDS reads, one wait) instead of one dependent LDS
+// round trip per term.
+__device__ __forceinline__ void free_baseline(const LmShared& sh, int a, int kmax, double (&beta)[3]) {
+  double zs[MVO_MAXM], zv[MVO_MAXM][3];
+#pragma unroll
+  for (int k = 0; k < MVO_MAXM; ++k) {
+    zs[k] = sh.zs[k];
+    zv[k][0] = sh.zvec[k][0];
+    zv[k][1] = sh.zvec[k][1];
+    zv[k][2] = sh.zvec[k][2];
   }
-  bx += in.off[0];
-  by += in.off[1];
-  bz += in.off[2];
+  beta[0] = beta[1] = beta[2] = 0.0;
+#pragma unroll
+  for (int k = 0; k < MVO_MAXM; ++k) {
+    const bool first = k == a, on = k > a && k <= kmax;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const double t = zs[k] * zv[k][j];
+      beta[j] = first ? t : (on ? beta[j] + t : beta[j]);
+    }
+  }
+}
+
+// projected moments of one pair at the published point: T = P S P, q = P S u, cost.
+// beta = the free frames' part of the pair's baseline (free_baseline); the fixed-frame offset is added here.
+__device__ __forceinline__ void pair_eval(const PairIn& in, const double (&beta)[3], int pass_mode, double (&o)[10]) {
+  const double bx = beta[0] + in.off[0], by = beta[1] + in.off[1], bz = beta[2] + in.off[2];
   const double nb = sqrt(bx * bx + by * by + bz * bz);
   const double inb = fast_rcp(nb), inb2 = inb * inb;
   const double u0 = bx * inb, u1 = by * inb, u2 = bz * inb;
@@ -752,25 +769,32 @@ __device__ __forceinline__ void inline_pass(const LmShared& sh, const PairDev* _
   }
 }
 
-// k_lm<384>, wavefronts 1..5: the loop of a class wavefront.  Wavefront 1 + a evaluates the pairs
-// (a, b), b = M + lane + 64 r (r < 4), adds them up and leaves the class total in sh.cls[a][M].  It
-// executes exactly the workgroup barriers wavefront 0 executes (marked B0 / B1 / B2 on both sides).
+// k_lm<256>, wavefronts 1..3: the loop of a class wavefront.  Wavefront w evaluates the pairs
+// (a, b), a in {w - 1, w + 2}, b = M + lane + 64 r (r < 4), adds them up per frame and leaves the class
+// totals in sh.cls[a][M].  It executes exactly the workgroup barriers wavefront 0 executes (marked
+// B0 / B1 / B2 on both sides).
 template <int NT>
-__device__ __forceinline__ void lm_class_wave(LmShared& sh, const SolveParams& prm, int a, int lane, int M, int N, int P,
+__device__ __forceinline__ void lm_class_wave(LmShared& sh, const SolveParams& prm, int cw, int lane, int M, int N, int P,
                                               bool& need_pass, int unit_slots, const PairDev* __restrict__ wp,
                                               const double* partial, uint32_t pair_off, const double* __restrict__ fr,
                                               const double* __restrict__ m0, const double* __restrict__ m1,
                                               double* my_sums) {
   constexpr int ROUNDS = 4;  // class (a, M) has at most MVO_HIP_MAX_FRAMES - 1 - M <= 256 pairs
-  int my_p[ROUNDS];
-  bool my_ok[ROUNDS];
+  constexpr int NA = 2;      // frames per class wavefront: cw and cw + 3
+  int my_p[NA][ROUNDS];
+  bool my_ok[NA][ROUNDS];
 #pragma unroll
-  for (int rr = 0; rr < ROUNDS; ++rr) {
-    const int b = M + lane + 64 * rr;
-    my_ok[rr] = a < M && b <= N - 2;
-    my_p[rr] = my_ok[rr] ? pair_index(N, a, b) : 0;
-  }
-  PairIn in[ROUNDS];
+  for (int q = 0; q < NA; ++q)
+#pragma unroll
+    for (int rr = 0; rr < ROUNDS; ++rr) {
+      const int a = cw + 3 * q, b = M + lane + 64 * rr;
+      my_ok[q][rr] = a < M && b <= N - 2;
+      my_p[q][rr] = my_ok[q][rr] ? pair_index(N, a, b) : 0;
+    }
+  const int n_pairs_a = N - 1 > M ? N - 1 - M : 0;
+  const int n_rounds = (n_pairs_a + 63) >> 6;  // wave-uniform
+  const bool two = cw + 3 < M;                 // wave-uniform: a second frame to serve
+  PairIn in[NA][ROUNDS];
   bool have_in = false;
   while (!need_pass) {
     if (prm.inline_eval && prm.pass_mode) {
@@ -780,27 +804,58 @@ __device__ __forceinline__ void lm_class_wave(LmShared& sh, const SolveParams& p
     }
     if (!have_in) {
 #pragma unroll
-      for (int rr = 0; rr < ROUNDS; ++rr)
-        if (rr == 0 || __any(my_ok[rr])) pair_load(in[rr], my_p[rr], N, M, unit_slots != 0, wp, partial, pair_off, fr);
+      for (int q = 0; q < NA; ++q)
+        if (q == 0 || two) {
+          if (n_rounds <= 1) {
+            pair_load(in[q][0], my_p[q][0], N, M, unit_slots != 0, wp, partial, pair_off, fr);
+          } else {
+#pragma unroll
+            for (int rr = 0; rr < ROUNDS; ++rr)
+              pair_load(in[q][rr], my_p[q][rr], N, M, unit_slots != 0, wp, partial, pair_off, fr);
+          }
+        }
       have_in = !prm.pass_mode;
     }
-    double acc[10];
+    // every pair of frame a has the free frames a .. M-1: one baseline per frame and evaluation; the
+    // slots of one lane are independent chains (sqrt, reciprocal, ~100 flops), issued interleaved
+    double acc[NA][10];
 #pragma unroll
-    for (int v = 0; v < 10; ++v) acc[v] = 0.0;
+    for (int q = 0; q < NA; ++q) {
 #pragma unroll
-    for (int rr = 0; rr < ROUNDS; ++rr)
-      if (rr == 0 || __any(my_ok[rr])) {
-        double o[10];
-        pair_eval(in[rr], sh, M, prm.pass_mode, o);
+      for (int v = 0; v < 10; ++v) acc[q][v] = 0.0;
+      if (q == 0 || two) {
+        const int a = cw + 3 * q;
+        double beta[3];
+        free_baseline(sh, a < M ? a : 0, M - 1, beta);
+        if (n_rounds <= 1) {
+          double o[10];
+          pair_eval(in[q][0], beta, prm.pass_mode, o);
 #pragma unroll
-        for (int v = 0; v < 10; ++v) acc[v] += my_ok[rr] ? o[v] : 0.0;
+          for (int v = 0; v < 10; ++v) acc[q][v] = my_ok[q][0] ? o[v] : 0.0;
+        } else {
+          double o[ROUNDS][10];
+#pragma unroll
+          for (int rr = 0; rr < ROUNDS; ++rr) pair_eval(in[q][rr], beta, prm.pass_mode, o[rr]);
+#pragma unroll
+          for (int v = 0; v < 10; ++v) {
+            acc[q][v] = my_ok[q][0] ? o[0][v] : 0.0;
+#pragma unroll
+            for (int rr = 1; rr < ROUNDS; ++rr) acc[q][v] += my_ok[q][rr] ? o[rr][v] : 0.0;
+          }
+        }
       }
-    double t8, t2;
-    wave_reduce10(acc, lane, t8, t2);
-    if (a < M) {
-      if ((lane & 7) == 0) sh.cls[a * MCX + M][reduce8_value_of_lane(lane)] = t8;
-      if ((lane & 31) == 0) sh.cls[a * MCX + M][8 + (lane >> 5)] = t2;
     }
+#pragma unroll
+    for (int q = 0; q < NA; ++q)
+      if (q == 0 || two) {
+        const int a = cw + 3 * q;
+        double t8, t2;
+        wave_reduce10(acc[q], lane, t8, t2);
+        if (a < M) {
+          if ((lane & 7) == 0) sh.cls[a * MCX + M][reduce8_value_of_lane(lane)] = t8;
+          if ((lane & 31) == 0) sh.cls[a * MCX + M][8 + (lane >> 5)] = t2;
+        }
+      }
     __syncthreads();  // B1: class totals are in LDS
     __syncthreads();  // B2: wavefront 0 has taken its step and published the next point
     if (!sh.go) break;
@@ -819,7 +874,7 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
                                            double* __restrict__ pair_u, int32_t* __restrict__ win_status,
                                            TraceRec* __restrict__ trace, int32_t* __restrict__ done_count) {
   constexpr bool LARGE = NT > 64;
-  static_assert(NT == 64 || NT == MVO_LM_NT_LARGE, "one wavefront, or five class wavefronts + one for the short pairs");
+  static_assert(NT == 64 || NT == MVO_LM_NT_LARGE, "one wavefront, or three class wavefronts + one for the short pairs and the LM step");
   __shared__ LmShared sh;
   __shared__ double pairbuf[LARGE ? 1 : 64 * 10];  // k_lm<64>: P x 10: T(6) q(3) cost(1)
   const int w = (int)blockIdx.x + prm.win_base, tid = threadIdx.x;
@@ -886,12 +941,12 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
 
   // ---- who evaluates which frame pair (fixed for the launch) ---------------------------------
   // k_lm<64>:  lane p evaluates pair p.
-  // k_lm<384>: wavefront 1 + a takes the pairs (a, b >= M) (lm_class_wave); wavefront 0's lane i the
+  // k_lm<256>: wavefronts 1..3 take the pairs (a, b >= M) (lm_class_wave); wavefront 0's lane i the
   //            i-th pair with b < M (a = 0: b = 0..M-1, a = 1: b = 1..M-1, ...), then the LM step.
   if (LARGE && !wave0) lm_class_wave<NT>(sh, prm, wv - 1, lane, M, N, P, need_pass, unit_slots, wp, partial, win.pair_off, fr, m0, m1, my_sums);
   int my_p0 = lane < P ? lane : 0;
   bool my_ok0 = lane < P;
-  int my_a = 0, my_j = 0;  // k_lm<384>: the short pair's (a, b)
+  int my_a = 0, my_j = 0;  // k_lm<256>: the short pair's (a, b)
   if (LARGE) {
     const int nshort = (M * (M + 1)) / 2;
     upper_block(M, lane < nshort ? lane : 0, my_a, my_j);  // (a, b) with a <= b < M, row-major: the same enumeration
@@ -900,6 +955,20 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
   }
   PairIn in0;
   bool have_in = false;
+  // lane roles of the three assembly stages (fixed): (j, v) of the prefix stage, (k, v) of the suffix
+  // stage, block row (k, l, i) / gradient entry (k, i) of the product stage
+  const int jA = lane / 10, vA = lane - 10 * jA;
+  const int kB = lane < MVO_MAXM * 10 ? jA : 0, vB = vA;
+  const int nB4 = 3 * ((M * (M + 1)) / 2);  // block rows of the upper triangle; then 3M gradient entries
+  int k4, l4, i4;
+  if (lane < nB4) {
+    i4 = lane % 3;
+    upper_block(M, lane / 3, k4, l4);
+  } else {
+    const int e = lane - nB4 < 3 * M ? lane - nB4 : 0;
+    k4 = l4 = e / 3;
+    i4 = e - 3 * k4;
+  }
 
   while (!need_pass && (!LARGE || wave0)) {
     MVO_STAMP(0);
@@ -917,8 +986,9 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
       have_in = !prm.pass_mode;
     }
     {
-      double o[10];
-      pair_eval(in0, sh, M, prm.pass_mode, o);
+      double o[10], beta[3];
+      free_baseline(sh, in0.a, in0.b < M - 1 ? in0.b : M - 1, beta);
+      pair_eval(in0, beta, prm.pass_mode, o);
       if (my_ok0) {
         double* __restrict__ dst = LARGE ? sh.cls[my_a * MCX + my_j] : pairbuf + lane * 10;
 #pragma unroll
@@ -933,93 +1003,74 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
     else wave0_sync();
     MVO_STAMP(1);
     {
-      // (2) + (3a) classes in pair order and their prefix over a:  C1[k][j] = sum_{a <= k} cls[a][j].
+      // (2) classes in pair order and their prefix over a:  C1[k][j] = sum_{a <= k} cls[a][j].
       // Class (a, j), j = min(b, M): j < M is the single pair b = j, j = M collects the pairs
-      // b = M .. N-2 (those with a fixed-frame offset).  Lane (j, v) walks a.
+      // b = M .. N-2 (those with a fixed-frame offset).  Lane (j, v) walks a; classes that do not
+      // exist (a > j, a >= M, j > M) count as zero, so every entry of C1 is defined.
       if (lane < MCX * 10) {
-        const int j = lane / 10, v = lane - 10 * j;
         double x[MVO_MAXM];
         if (LARGE) {
 #pragma unroll
-          for (int a = 0; a < MVO_MAXM; ++a) x[a] = sh.cls[a * MCX + j][v];  // reads issue back to back
+          for (int a = 0; a < MVO_MAXM; ++a) x[a] = sh.cls[a * MCX + jA][vA];  // reads issue back to back
         } else {
           // pairs of class (a, j), a <= j: one for j < M, the N - 1 - M pairs b >= M for j = M; the
           // five frames' loads of one step are independent (clamped rows for the classes that do not exist)
-          const int cnt = (j < M) ? 1 : (j == M ? N - 1 - M : 0);
+          const int cnt = (jA < M) ? 1 : (jA == M ? N - 1 - M : 0);
           int row[MVO_MAXM];
 #pragma unroll
           for (int a = 0; a < MVO_MAXM; ++a) {
             x[a] = 0.0;
-            row[a] = (a < M && a <= j && j <= M) ? pair_index(N, a, j) : -1;
+            row[a] = (a < M && a <= jA && jA <= M) ? pair_index(N, a, jA) : -1;
           }
           for (int i = 0; i < cnt; ++i) {
 #pragma unroll
             for (int a = 0; a < MVO_MAXM; ++a) {
-              const double t = pairbuf[(row[a] >= 0 ? row[a] + i : 0) * 10 + v];
+              const double t = pairbuf[(row[a] >= 0 ? row[a] + i : 0) * 10 + vA];
               x[a] += row[a] >= 0 ? t : 0.0;
             }
           }
         }
         double acc = 0.0;
 #pragma unroll
-        for (int a = 0; a < MVO_MAXM; ++a)
-          if (a < M && j <= M) {
-            acc += (a <= j) ? x[a] : 0.0;
-            sh.C1[a * MCX + j][v] = acc;
-          }
+        for (int a = 0; a < MVO_MAXM; ++a) {
+          acc += (a < M && a <= jA && jA <= M) ? x[a] : 0.0;
+          sh.C1[a * MCX + jA][vA] = acc;
+        }
       }
       wave0_sync();
       MVO_STAMP(2);
-      // (3b) suffix over j:  W_kl = sum_{j >= l} C1[k][j] (l > k).  The pair (k,k) is kept apart:
-      // its baseline is s_k v_k alone, so r does not depend on t_k at all (IR.cpp:466-471 normalises
-      // the scale away) and its scale row/column is exactly zero instead of rounding noise of the
-      // size of S -- the diagonal entries W_kk, y_k leave class (k,k) out:
-      // sum_{j > k} C1[k][j] + C1[k-1][k].
+      // (3) suffix over j:  D[k][j] = sum_{j' >= j} C1[k][j'], lane (k, v).  W_kl = D[k][l] for l > k.
       if (lane < MVO_MAXM * 10) {
-        const int k = lane / 10, v = lane - 10 * k;
-        if (k < M && v < 9) {
-          double x[MCX];
+        double x[MCX];
 #pragma unroll
-          for (int j = 0; j < MCX; ++j) x[j] = sh.C1[k * MCX + j][v];
-          const double xe = sh.C1[(k > 0 ? k - 1 : 0) * MCX + k][v];
-          double acc = 0.0;
+        for (int j = 0; j < MCX; ++j) x[j] = sh.C1[kB * MCX + j][vB];
+        double acc = 0.0;
 #pragma unroll
-          for (int j = MCX - 1; j >= 1; --j)
-            if (j <= M && j > k) {
-              acc += x[j];
-              if (j < M && v < 6) sh.W[k * MVO_MAXM + j][v] = acc;
-            }
-          if (k > 0) acc += xe;
-          if (v < 6) sh.W[k * MVO_MAXM + k][v] = acc;
-          else sh.y[k][v - 6] = acc;
-        } else if (k == 0 && v == 9) {
-          // cost: all classes; class (a, j) has a <= min(j, M-1)
-          double c = 0.0;
-#pragma unroll
-          for (int j = 0; j < MCX; ++j)
-            if (j <= M) c += sh.C1[(j < M ? j : M - 1) * MCX + j][9];
-          sh.cost_z = c;
+        for (int j = MCX - 1; j >= 0; --j) {
+          acc += x[j];
+          sh.D[kB * MCX + j][vB] = acc;
         }
       }
       wave0_sync();
       MVO_STAMP(3);
       // (4) 3x3 blocks G_k^T W_kl G_l, one ROW of a block per lane (45 rows + 15 gradient entries fit
-      // the wavefront), and gradient entries G_k^T y_k
+      // the wavefront), and gradient entries G_k^T y_k.  W_kl = D[k][l] for l > k.  The pair (k, k) is
+      // kept apart: its baseline is s_k v_k alone, so r does not depend on t_k at all (IR.cpp:466-471
+      // normalises the scale away) and its scale row / column is exactly zero instead of rounding noise
+      // of the size of S -- the diagonal W_kk, y_k leave class (k, k) out: D[k][k+1] + C1[k-1][k].
       {
-        const int nkl = (M * (M + 1)) / 2, nB = nkl * 3;
         double* __restrict__ Hw = hsel ? sh.st.H : sh.Hz;
-        if (lane < nB) {
-          const int t = lane / 3, i = lane - 3 * t;
-          int k, l;
-          upper_block(M, t, k, l);
-          const int kl = k * MVO_MAXM + l;
+        if (lane < nB4) {
+          const double* __restrict__ wsrc = sh.D[k4 * MCX + (k4 == l4 ? k4 + 1 : l4)];
+          const double* __restrict__ csrc = sh.C1[(k4 > 0 ? k4 - 1 : 0) * MCX + k4];
+          const bool diag = k4 == l4;
           double Wv[6], gk[3], Gl[9];
 #pragma unroll
-          for (int v = 0; v < 6; ++v) Wv[v] = sh.W[kl][v];
+          for (int v = 0; v < 6; ++v) Wv[v] = wsrc[v] + ((diag && k4 > 0) ? csrc[v] : 0.0);
 #pragma unroll
-          for (int rr = 0; rr < 3; ++rr) gk[rr] = sh.G[k][3 * rr + i];
+          for (int rr = 0; rr < 3; ++rr) gk[rr] = sh.G[k4][3 * rr + i4];
 #pragma unroll
-          for (int e = 0; e < 9; ++e) Gl[e] = sh.G[l][e];
+          for (int e = 0; e < 9; ++e) Gl[e] = sh.G[l4][e];
           double val[3];
           {
             double gw[3];  // (G_k^T W)[i][m]
@@ -1028,8 +1079,8 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
 #pragma unroll
             for (int jj = 0; jj < 3; ++jj) val[jj] = gw[0] * Gl[jj] + gw[1] * Gl[3 + jj] + gw[2] * Gl[6 + jj];
           }
-          if (k == l && i < 2) {  // the pair (k,k): direction columns only
-            const double* Ts = sh.kk[k];
+          if (diag && i4 < 2) {  // the pair (k,k): direction columns only
+            const double* Ts = sh.kk[k4];
             double gw[3];
 #pragma unroll
             for (int m = 0; m < 3; ++m) gw[m] = gk[0] * Ts[sym6(0, m)] + gk[1] * Ts[sym6(1, m)] + gk[2] * Ts[sym6(2, m)];
@@ -1038,18 +1089,20 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
           }
 #pragma unroll
           for (int jj = 0; jj < 3; ++jj)
-            if (k != l || jj >= i) {  // diagonal blocks: the upper entry is mirrored, H stays symmetric
-              Hw[(3 * k + i) * MVO_MAXC + 3 * l + jj] = val[jj];
-              Hw[(3 * l + jj) * MVO_MAXC + 3 * k + i] = val[jj];
+            if (!diag || jj >= i4) {  // diagonal blocks: the upper entry is mirrored, H stays symmetric
+              Hw[(3 * k4 + i4) * MVO_MAXC + 3 * l4 + jj] = val[jj];
+              Hw[(3 * l4 + jj) * MVO_MAXC + 3 * k4 + i4] = val[jj];
             }
-        } else if (lane < nB + 3 * M) {
-          const int k = (lane - nB) / 3, i = (lane - nB) - 3 * k;
-          double gi = sh.G[k][i] * sh.y[k][0] + sh.G[k][3 + i] * sh.y[k][1] + sh.G[k][6 + i] * sh.y[k][2];
-          if (i < 2) {
-            const double* qs = &sh.kk[k][6];
-            gi += sh.G[k][i] * qs[0] + sh.G[k][3 + i] * qs[1] + sh.G[k][6 + i] * qs[2];
+        } else if (lane < nB4 + 3 * M) {
+          const double* __restrict__ dk = sh.D[k4 * MCX + k4 + 1];
+          const double* __restrict__ ck = sh.C1[(k4 > 0 ? k4 - 1 : 0) * MCX + k4];
+          double gi = 0.0;
+#pragma unroll
+          for (int v = 0; v < 3; ++v) {
+            const double yv = dk[6 + v] + (k4 > 0 ? ck[6 + v] : 0.0) + (i4 < 2 ? sh.kk[k4][6 + v] : 0.0);
+            gi += sh.G[k4][3 * v + i4] * yv;
           }
-          sh.gz[3 * k + i] = gi;
+          sh.gz[3 * k4 + i4] = gi;
         }
       }
       wave0_sync();
