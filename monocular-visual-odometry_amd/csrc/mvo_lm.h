@@ -256,25 +256,6 @@ __device__ __forceinline__ void regs_store(const LmRegs& r, LmState& g, int lane
   }
 }
 
-// || a - b || over the program's parameters (vec always, t unless fix_length); lanes k < M
-// hold frame k.  inf_norm: max |.|, else Euclidean.
-__device__ __forceinline__ double frames_diff_norm(int lane, int M, int fix, const double av[3], double at,
-                                                   const double bv[3], double bt, bool inf_norm) {
-  double acc = 0.0;
-  if (lane < M) {
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const double d = fabs(av[j] - bv[j]);
-      acc = inf_norm ? fmax(acc, d) : acc + d * d;
-    }
-    if (!fix) {
-      const double d = fabs(at - bt);
-      acc = inf_norm ? fmax(acc, d) : acc + d * d;
-    }
-  }
-  return inf_norm ? row0_max(acc) : sqrt(row0_sum(acc));
-}
-
 // x (+) sign*delta for frame `lane`: delta lives one component per lane (compact columns)
 __device__ __forceinline__ void frames_plus(int lane, int M, int fix, const double xv[3], double xt,
                                             double delta_lane, double sign, double ov[3], double& ot) {
@@ -312,22 +293,14 @@ __device__ __forceinline__ void lm_publish_point(LmShared& sh, const SolveParams
   }
 }
 
-// a[j] = js_l H_lj js_j for matrix row l = lane (zero rows for lanes >= n)
+// a[j] = js_l H_lj js_j for matrix row l = lane.  jsm = the jacobi scale on active lanes and 0 on the
+// others: inactive rows and columns come out as zeros without a select.
 template <int J>
-__device__ __forceinline__ void gj_setup(double (&a)[MVO_MAXC], const double* __restrict__ hrow, double js,
-                                         int lane, int n) {
+__device__ __forceinline__ void gj_setup(double (&a)[MVO_MAXC], const double (&hrow)[MVO_MAXC], double jsm) {
   if constexpr (J < MVO_MAXC) {
-    const double jsj = row_bcast<J>(js);
-    a[J] = (lane < n) ? js * hrow[J] * jsj : 0.0;
-    gj_setup<J + 1>(a, hrow, js, lane, n);
+    a[J] = (jsm * hrow[J]) * row_bcast<J>(jsm);
+    gj_setup<J + 1>(a, hrow, jsm);
   }
-}
-
-// diagonal: active rows get the LM damping D^2 = diag / radius, padding rows become identity
-__device__ __forceinline__ void a_diag_fix(double (&a)[MVO_MAXC], int lane, bool active, double dd) {
-#pragma unroll
-  for (int j = 0; j < MVO_MAXC; ++j)
-    if (j == lane) a[j] = active ? a[j] + dd : 1.0;
 }
 
 template <int J, int K>
@@ -339,27 +312,47 @@ __device__ __forceinline__ void gj_row_update(double (&a)[MVO_MAXC], double f) {
 }
 
 // Gauss-Jordan elimination without pivoting (the matrix is SPD): after column J every other row
-// has a zero in that column.  Pivots <= 0 (or non-finite) flag the solve as failed.
+// has a zero in that column.  The LM damping D^2 = diag / radius is never written into the matrix: a
+// row's diagonal entry is not touched by the steps before its own, so the damping is added when the
+// entry becomes the pivot (ddl = the lane's damping on active rows, 1 on the all-zero padding rows).  Each lane
+// keeps the reciprocal of its own pivot (myrinv); pmin / pmax collect the pivots for the validity test.
 // Look-ahead order: step J updates column J+1 first and starts the reciprocal of the NEXT pivot
 // (readlane -> v_rcp -> two Newton steps, a ~100-cycle dependent chain) before it touches the
 // remaining columns, whose independent updates then fill that latency.
 template <int J>
-__device__ __forceinline__ void gj_eliminate(double (&a)[MVO_MAXC], double& rhs, double& mydiag, bool& ok,
-                                             int lane, double piv, double rinv) {
+__device__ __forceinline__ void gj_eliminate(double (&a)[MVO_MAXC], double& rhs, double& myrinv, double& pmin,
+                                             double& pmax, int lane, double ddl, double piv, double rinv) {
   if constexpr (J < MVO_MAXC) {
-    if (!(piv > 0.0) || isinf(piv)) ok = false;
-    const double f = (lane == J) ? 0.0 : a[J] * rinv;
-    if (lane == J) mydiag = piv;
+    pmin = fmin(pmin, piv);
+    pmax = fmax(pmax, piv);
+    const bool me = lane == J;
+    const double f = me ? 0.0 : a[J] * rinv;
+    myrinv = me ? rinv : myrinv;
     double piv_next = 1.0, rinv_next = 1.0;
     if constexpr (J + 1 < MVO_MAXC) {
       a[J + 1] -= f * row_bcast<J>(a[J + 1]);
-      piv_next = bcast_lane(a[J + 1], J + 1);
+      piv_next = bcast_lane(a[J + 1] + ddl, J + 1);
       rinv_next = fast_rcp(piv_next);
       gj_row_update<J, J + 2>(a, f);
     }
     rhs -= f * row_bcast<J>(rhs);
-    gj_eliminate<J + 1>(a, rhs, mydiag, ok, lane, piv_next, rinv_next);
+    gj_eliminate<J + 1>(a, rhs, myrinv, pmin, pmax, lane, ddl, piv_next, rinv_next);
   }
+}
+
+// sum of squares of (a - b) over the program's parameters (vec always, t unless fix_length) /
+// largest |a - b|; lanes k < M hold frame k
+__device__ __forceinline__ double frames_diff_sq(int lane, int M, int fix, const double av[3], double at,
+                                                 const double bv[3], double bt) {
+  const double d0 = av[0] - bv[0], d1 = av[1] - bv[1], d2 = av[2] - bv[2], d3 = fix ? 0.0 : at - bt;
+  const double acc = ((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3;
+  return row0_sum(lane < M ? acc : 0.0);
+}
+__device__ __forceinline__ double frames_diff_max(int lane, int M, int fix, const double av[3], double at,
+                                                  const double bv[3], double bt) {
+  const double d3 = fix ? 0.0 : fabs(at - bt);
+  const double acc = fmax(fmax(fabs(av[0] - bv[0]), fabs(av[1] - bv[1])), fmax(fabs(av[2] - bv[2]), d3));
+  return row0_max(lane < M ? acc : 0.0);
 }
 
 // Wave-0 control logic: Ceres 1.14 TrustRegionMinimizer::Minimize restated around the evaluation
@@ -367,6 +360,9 @@ __device__ __forceinline__ void gj_eliminate(double (&a)[MVO_MAXC], double& rhs,
 // assembled at z is in the buffer `hsel` does NOT select (hsel ? sh.Hz : st.H holds the ACCEPTED
 // system), gradient in sh.gz, cost in sh.D.  Every lane executes it; scalars are uniform.
 // Returns 1 when a new candidate awaits evaluation (published in sh.zvec/zt), 0 when done.
+// Written for a short instruction stream (one wavefront issues an instruction per ~4.4 cycles whatever
+// the dependences): one exit, the per-iteration record only as scalars, square roots only where a
+// tolerance or the trace asks for them.
 __device__ int lm_advance_body(LmRegs& r, LmShared& sh, const SolveParams& prm, int M, int n, int lane,
                                TraceRec* __restrict__ trace, int& hsel MVO_STAMP_PARAM) {
   LmState& st = sh.st;
@@ -376,12 +372,20 @@ __device__ int lm_advance_body(LmRegs& r, LmShared& sh, const SolveParams& prm, 
   const bool stamp_on = stamp_acc_ != nullptr;
   unsigned long long astamp_prev_ = __builtin_amdgcn_s_memtime();
 #endif
-  TraceRec it;
-  it.cost = it.cost_change = it.gradient_max_norm = it.step_norm = it.relative_decrease = 0.0;
-  it.trust_region_radius = 0.0;
-  it.step_is_valid = it.step_is_successful = 0;
+  const bool tracing = trace != nullptr && prm.trace_cap > 0;
+  // the current ceres::IterationSummary, as scalars
+  double it_cost = 0.0, it_cost_change = 0.0, it_gmn = 0.0, it_step_norm = 0.0, it_rel = 0.0;
+  int it_valid = 0, it_succ = 0;
+  auto write_trace = [&](int row) {
+    if (tracing && lane == 0 && row < prm.trace_cap) {
+      TraceRec t;
+      t.cost = it_cost; t.cost_change = it_cost_change; t.gradient_max_norm = it_gmn; t.step_norm = it_step_norm;
+      t.relative_decrease = it_rel; t.trust_region_radius = r.radius; t.step_is_valid = it_valid;
+      t.step_is_successful = it_succ;
+      trace[row] = t;
+    }
+  };
 
-  bool take_z = false;
   const bool first = (r.phase == PH_EVAL_X0);
   // Ceres 1.14 rejects non-finite residuals (ResidualBlock::Evaluate / IsEvaluationValid): at the
   // initial point the minimizer fails before any step; a candidate that "failed to evaluate" gets
@@ -391,17 +395,19 @@ __device__ int lm_advance_body(LmRegs& r, LmShared& sh, const SolveParams& prm, 
   if (first && !isfinite(cost_z)) {
     r.iteration = 0;
     r.ntrace = 1;  // iteration 0 is the one (failed) record: summary.iterations = 0
-    it.cost = cost_z;
-    if (trace && lane == 0 && prm.trace_cap > 0) trace[0] = it;
+    it_cost = cost_z;
+    r.radius = 0.0;
+    write_trace(0);
     r.nsucc = r.nunsucc = 0;
     r.initial_cost = r.final_cost = cost_z;
     r.bv[0] = r.xv[0]; r.bv[1] = r.xv[1]; r.bv[2] = r.xv[2]; r.bt = r.xt;  // written back untouched
     lm_terminate(r, 2, 8);
     return 0;
   }
+  bool take_z = first;
+  int done = 0;
   if (first) {
     // IterationZero
-    take_z = true;
     r.iteration = 0;
     r.min_cost = DBL_MAX;
     r.radius = 1e4;  // initial_trust_region_radius
@@ -413,59 +419,59 @@ __device__ int lm_advance_body(LmRegs& r, LmShared& sh, const SolveParams& prm, 
     r.mcc = 0.0;
     r.cv[0] = r.xv[0]; r.cv[1] = r.xv[1]; r.cv[2] = r.xv[2]; r.ct = r.xt;  // z == x0
   } else {
-    // ParameterToleranceReached
-    it.step_norm = frames_diff_norm(lane, M, fix, r.xv, r.xt, r.cv, r.ct, false);
-    if (it.step_norm <= prm.ptol * (r.x_norm + prm.ptol)) {
-      lm_terminate(r, 0, 3);
-      return 0;
-    }
+    // ParameterToleranceReached: ||x - z|| <= ptol (||x|| + ptol).  With ptol == 0 that is "the step
+    // vanished", no square root needed (sqrt is > 0 for every positive argument).
+    const double sn2 = frames_diff_sq(lane, M, fix, r.xv, r.xt, r.cv, r.ct);
+    if (tracing || prm.ptol > 0.0) it_step_norm = sqrt(sn2);
+    const bool ptol_hit = prm.ptol > 0.0 ? it_step_norm <= prm.ptol * (r.x_norm + prm.ptol) : sn2 <= 0.0;
     // FunctionToleranceReached
-    it.cost_change = r.x_cost - cost_z;
-    if (fabs(it.cost_change) <= prm.ftol * r.x_cost) {
-      lm_terminate(r, 0, 4);
-      return 0;
-    }
-    // TrustRegionStepEvaluator::StepQuality
-    const double rel = (r.se_cur - cost_z) * fast_rcp(r.mcc);
-    const double hist = (r.se_ref - cost_z) * fast_rcp(r.se_acc_ref + r.mcc);
-    it.relative_decrease = fmax(rel, hist);
-    it.step_is_valid = 1;
-    if (it.relative_decrease > 1e-3) {  // min_relative_decrease
-      take_z = true;
-      it.step_is_successful = 1;
-      // LevenbergMarquardtStrategy::StepAccepted
-      const double q = 2.0 * it.relative_decrease - 1.0;
-      r.radius = r.radius * fast_rcp(fmax(1.0 / 3.0, 1.0 - q * q * q));
-      r.radius = fmin(1e16, r.radius);
-      r.decf = 2.0;
-      r.reuse_diag = 0;
-      // TrustRegionStepEvaluator::StepAccepted
-      r.se_cur = cost_z;
-      r.se_acc_cand += r.mcc;
-      r.se_acc_ref += r.mcc;
-      if (r.se_cur < r.se_min) {
-        r.se_min = r.se_cur;
-        r.se_nonmono = 0;
-        r.se_cand = r.se_cur;
-        r.se_acc_cand = 0.0;
-      } else {
-        ++r.se_nonmono;
-        if (r.se_cur > r.se_cand) {
+    it_cost_change = r.x_cost - cost_z;
+    const bool ftol_hit = fabs(it_cost_change) <= prm.ftol * r.x_cost;
+    if (ptol_hit || ftol_hit) {
+      lm_terminate(r, 0, ptol_hit ? 3 : 4);
+      done = 1;
+    } else {
+      // TrustRegionStepEvaluator::StepQuality
+      const double rel = (r.se_cur - cost_z) * fast_rcp(r.mcc);
+      const double hist = (r.se_ref - cost_z) * fast_rcp(r.se_acc_ref + r.mcc);
+      it_rel = fmax(rel, hist);
+      it_valid = 1;
+      take_z = it_rel > 1e-3;  // min_relative_decrease
+      if (take_z) {
+        it_succ = 1;
+        // LevenbergMarquardtStrategy::StepAccepted
+        const double q = 2.0 * it_rel - 1.0;
+        r.radius = fmin(1e16, r.radius * fast_rcp(fmax(1.0 / 3.0, 1.0 - q * q * q)));
+        r.decf = 2.0;
+        r.reuse_diag = 0;
+        // TrustRegionStepEvaluator::StepAccepted
+        r.se_cur = cost_z;
+        r.se_acc_cand += r.mcc;
+        r.se_acc_ref += r.mcc;
+        if (r.se_cur < r.se_min) {
+          r.se_min = r.se_cur;
+          r.se_nonmono = 0;
           r.se_cand = r.se_cur;
           r.se_acc_cand = 0.0;
+        } else {
+          ++r.se_nonmono;
+          if (r.se_cur > r.se_cand) {
+            r.se_cand = r.se_cur;
+            r.se_acc_cand = 0.0;
+          }
         }
+        if (r.se_nonmono == 5) {  // max_consecutive_nonmonotonic_steps
+          r.se_ref = r.se_cand;
+          r.se_acc_ref = r.se_acc_cand;
+        }
+      } else {
+        // HandleUnsuccessfulStep + StepRejected
+        r.radius = r.radius * fast_rcp(r.decf);  // a power of two: exact
+        r.decf *= 2.0;
+        r.reuse_diag = 1;
+        it_cost = cost_z;
+        it_gmn = r.gmn;
       }
-      if (r.se_nonmono == 5) {  // max_consecutive_nonmonotonic_steps
-        r.se_ref = r.se_cand;
-        r.se_acc_ref = r.se_acc_cand;
-      }
-    } else {
-      // HandleUnsuccessfulStep + StepRejected
-      r.radius = r.radius * fast_rcp(r.decf);  // a power of two: exact
-      r.decf *= 2.0;
-      r.reuse_diag = 1;
-      it.cost = cost_z;
-      it.gradient_max_norm = r.gmn;
     }
   }
 
@@ -473,12 +479,11 @@ __device__ int lm_advance_body(LmRegs& r, LmShared& sh, const SolveParams& prm, 
     // x <- z; EvaluateGradientAndJacobian = the system assembled at z
     r.xv[0] = r.cv[0]; r.xv[1] = r.cv[1]; r.xv[2] = r.cv[2]; r.xt = r.ct;
     r.x_cost = cost_z;
-    {
+    if (prm.ptol > 0.0) {  // ||x|| is only ever read by the parameter-tolerance test
       const double zero3[3] = {0.0, 0.0, 0.0};
-      r.x_norm = frames_diff_norm(lane, M, fix, r.xv, r.xt, zero3, 0.0, false);
+      r.x_norm = sqrt(frames_diff_sq(lane, M, fix, r.xv, r.xt, zero3, 0.0));
     }
-    const int l = lane < n ? lane : 0;
-    const int fl = fcol(l, fix);
+    const int fl = fcol(lane < n ? lane : 0, fix);
     hsel ^= 1;  // the buffers swap roles: no copy of the 15 x 15 system
     r.g = lane < n ? sh.gz[fl] : 0.0;
     r.hdiag = lane < n ? Hnew[fl * MVO_MAXC + fl] : 0.0;
@@ -491,21 +496,22 @@ __device__ int lm_advance_body(LmRegs& r, LmShared& sh, const SolveParams& prm, 
       r.se_min = r.se_cur = r.se_ref = r.se_cand = r.x_cost;
       r.se_acc_ref = r.se_acc_cand = 0.0;
       r.se_nonmono = 0;
-      it.step_is_valid = 1;
-      it.step_is_successful = 1;
+      it_valid = 1;
+      it_succ = 1;
     }
     // gradient_max_norm = || x - Plus(x, -g) ||_inf
     double pv[3], pt;
     frames_plus(lane, M, fix, r.xv, r.xt, r.g, -1.0, pv, pt);
-    r.gmn = frames_diff_norm(lane, M, fix, r.xv, r.xt, pv, pt, true);
-    it.cost = r.x_cost;
-    it.gradient_max_norm = r.gmn;
+    r.gmn = frames_diff_max(lane, M, fix, r.xv, r.xt, pv, pt);
+    it_cost = r.x_cost;
+    it_gmn = r.gmn;
   }
 
   MVO_ASTAMP(8);
-  for (;;) {
+  int go = 0;
+  while (!done) {
     // ---- FinalizeIterationAndCheckIfMinimizerCanContinue ----
-    if (it.step_is_successful) {
+    if (it_succ) {
       ++r.nsucc;
       if (r.x_cost < r.min_cost) {
         r.min_cost = r.x_cost;
@@ -514,35 +520,35 @@ __device__ int lm_advance_body(LmRegs& r, LmShared& sh, const SolveParams& prm, 
     } else {
       ++r.nunsucc;
     }
-    it.trust_region_radius = r.radius;
-    if (trace && lane == 0 && r.ntrace < prm.trace_cap) trace[r.ntrace] = it;
+    write_trace(r.ntrace);
     ++r.ntrace;
-    if (it.cost < r.final_cost) r.final_cost = it.cost;
+    r.final_cost = fmin(r.final_cost, it_cost);
 
     if (r.iteration >= prm.max_it) {
       lm_terminate(r, 1, 1);
-      return 0;
+      break;
     }
-    if (it.step_is_successful && it.gradient_max_norm <= prm.gtol) {
+    if (it_succ && it_gmn <= prm.gtol) {
       lm_terminate(r, 0, 2);
-      return 0;
+      break;
     }
     if (r.radius <= 1e-32) {  // min_trust_region_radius
       lm_terminate(r, 0, 5);
-      return 0;
+      break;
     }
 
     MVO_ASTAMP(9);
     // ---- next iteration: ComputeTrustRegionStep ----
     ++r.iteration;
-    it.cost = it.cost_change = it.gradient_max_norm = it.step_norm = it.relative_decrease = 0.0;
-    it.step_is_valid = it.step_is_successful = 0;
+    it_cost = it_cost_change = it_gmn = it_step_norm = it_rel = 0.0;
+    it_valid = it_succ = 0;
 
     if (!r.reuse_diag) r.dg = fmin(fmax(r.js * r.js * r.hdiag, 1e-6), 1e32);  // min/max_lm_diagonal
     r.reuse_diag = 1;
     // (Js^T Js + D^2) y = Js^T r with Js = J diag(jscale), D^2 = diag / radius; step = -y.
     // Ceres solves the equivalent least-squares problem by dense QR; here the reduced system is
     // eliminated in registers, one row per lane (Gauss-Jordan, no pivoting: the matrix is SPD).
+    const double jsm = lane < n ? r.js : 0.0;
     double a[MVO_MAXC];
     {
       const double* __restrict__ Hacc = hsel ? sh.Hz : st.H;
@@ -550,42 +556,37 @@ __device__ int lm_advance_body(LmRegs& r, LmShared& sh, const SolveParams& prm, 
       double hrow[MVO_MAXC];
 #pragma unroll
       for (int j = 0; j < MVO_MAXC; ++j) hrow[j] = Hacc[fl * MVO_MAXC + (fix ? 3 * (j >> 1) + (j & 1) : j)];  // loads first
-      gj_setup<0>(a, hrow, r.js, lane, n);
+      gj_setup<0>(a, hrow, jsm);
     }
     const double dd = r.dg * fast_rcp(r.radius);
-    if (lane < MVO_MAXC) a_diag_fix(a, lane, (lane < n), dd);
-    const double rhs0 = (lane < n) ? r.js * r.g : 0.0;
+    const double ddl = lane < n ? dd : 1.0;  // added to a row's diagonal entry when it becomes the pivot
+    const double rhs0 = jsm * r.g;
     MVO_ASTAMP(10);
-    double rhs = rhs0, mydiag = 1.0;
-    bool ok = true;
+    double rhs = rhs0, myrinv = 1.0, pmin = DBL_MAX, pmax = 0.0;
     {
-      const double piv0 = bcast_lane(a[0], 0);
-      gj_eliminate<0>(a, rhs, mydiag, ok, lane, piv0, fast_rcp(piv0));
+      const double piv0 = bcast_lane(a[0] + ddl, 0);
+      gj_eliminate<0>(a, rhs, myrinv, pmin, pmax, lane, ddl, piv0, fast_rcp(piv0));
     }
     MVO_ASTAMP(11);
-    double step = -(rhs * fast_rcp(mydiag));
-    if (lane >= n) step = 0.0;
-    if (__any(!isfinite(step))) ok = false;
-    double mcc = 0.0;
-    if (ok) {
-      // model_cost_change = -(Js step)^T (r + Js step / 2) = -step^T b - step^T As step / 2 with
-      // b = Js^T r, As = Js^T Js.  The step solves (As + D^2) step = -b, so As step = -b - D^2 step
-      // and the change is (-step^T b + step^T D^2 step) / 2 -- no second pass over the matrix.
-      mcc = 0.5 * row0_sum(step * (dd * step - rhs0));
-    }
+    const double step = lane < n ? -(rhs * myrinv) : 0.0;
+    // pivots <= 0 or infinite, or a non-finite step: the linear solver failed
+    const bool ok = pmin > 0.0 && pmax <= DBL_MAX && !__any(!isfinite(step));
+    // model_cost_change = -(Js step)^T (r + Js step / 2) = -step^T b - step^T As step / 2 with
+    // b = Js^T r, As = Js^T Js.  The step solves (As + D^2) step = -b, so As step = -b - D^2 step
+    // and the change is (-step^T b + step^T D^2 step) / 2 -- no second pass over the matrix.
+    const double mcc = ok ? 0.5 * row0_sum(step * (dd * step - rhs0)) : 0.0;
     MVO_ASTAMP(12);
     r.mcc = mcc;
-    const bool valid = ok && mcc > 0.0;
-    if (!valid) {
+    if (!(ok && mcc > 0.0)) {
       // ---- HandleInvalidStep ----
       if (++r.num_invalid >= 5) {  // max_num_consecutive_invalid_steps
         lm_terminate(r, 2, 6);
-        return 0;
+        break;
       }
       r.radius *= 0.5;  // StepIsInvalid
       r.reuse_diag = 1;
-      it.cost = r.x_cost;
-      it.gradient_max_norm = r.gmn;
+      it_cost = r.x_cost;
+      it_gmn = r.gmn;
       continue;
     }
     r.num_invalid = 0;
@@ -595,8 +596,10 @@ __device__ int lm_advance_body(LmRegs& r, LmShared& sh, const SolveParams& prm, 
     lm_publish_point(sh, prm, M, lane, r.cv, r.ct);
     MVO_ASTAMP(14);
     r.phase = PH_EVAL_CAND;
-    return 1;
+    go = 1;
+    break;
   }
+  return go;
 }
 
 // t-th block (k, l), k <= l < M, of the upper triangle in row-major order

