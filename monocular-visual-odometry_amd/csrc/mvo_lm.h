@@ -186,7 +186,8 @@ struct LmShared {
   double C1[MVO_MAXM * MCX][10];                // prefix of the classes over a: C1[k][j] = sum_{a<=k} cls[a][j]
   double D[MVO_MAXM * MCX][10];                 // ... and suffix over j: D[k][j] = sum_{j'>=j} C1[k][j']
   double Hz[MVO_MAXC * MVO_MAXC], gz[MVO_MAXC]; // second system buffer (st.H is the first) and the gradient at z
-  int32_t go, phase;
+  double gmn_z;                                 // k_lm<256>: gradient max norm at z (helper wavefront)
+  int32_t go, phase, hsel, pad_;
 };
 
 // The solver state in wavefront 0's registers.
@@ -315,17 +316,21 @@ __device__ __forceinline__ void gj_row_update(double (&a)[MVO_MAXC], double f) {
 // has a zero in that column.  The LM damping D^2 = diag / radius is never written into the matrix: a
 // row's diagonal entry is not touched by the steps before its own, so the damping is added when the
 // entry becomes the pivot (ddl = the lane's damping on active rows, 1 on the all-zero padding rows).  Each lane
-// keeps the reciprocal of its own pivot (myrinv); pmin / pmax collect the pivots for the validity test.
+// keeps the reciprocal of its own pivot (myrinv); psign / psum collect the pivots for the validity test.
 // Look-ahead order: step J updates column J+1 first and starts the reciprocal of the NEXT pivot
 // (readlane -> v_rcp -> two Newton steps, a ~100-cycle dependent chain) before it touches the
 // remaining columns, whose independent updates then fill that latency.
 template <int J>
-__device__ __forceinline__ void gj_eliminate(double (&a)[MVO_MAXC], double& rhs, double& myrinv, double& pmin,
-                                             double& pmax, int lane, double ddl, double piv, double rinv) {
+__device__ __forceinline__ void gj_eliminate(double (&a)[MVO_MAXC], double& rhs, double& myrinv, int& psign,
+                                             double& psum, int lane, double ddl, double piv, double rinv) {
   if constexpr (J < MVO_MAXC) {
-    pmin = fmin(pmin, piv);
-    pmax = fmax(pmax, piv);
-    const bool me = lane == J;
+    psign |= __double2hiint(piv);  // a negative pivot leaves its sign bit here (scalar or)
+    psum += piv;                   // an infinite or NaN pivot makes the sum non-finite
+    // `lane == J` is recomputed at every step: left to itself the compiler hoists the fifteen lane
+    // masks out of the solver loop, 30 scalar registers that it then spills and reloads one by one
+    int lane_here = lane;
+    asm volatile("" : "+v"(lane_here));
+    const bool me = lane_here == J;
     const double f = me ? 0.0 : a[J] * rinv;
     myrinv = me ? rinv : myrinv;
     double piv_next = 1.0, rinv_next = 1.0;
@@ -336,7 +341,7 @@ __device__ __forceinline__ void gj_eliminate(double (&a)[MVO_MAXC], double& rhs,
       gj_row_update<J, J + 2>(a, f);
     }
     rhs -= f * row_bcast<J>(rhs);
-    gj_eliminate<J + 1>(a, rhs, myrinv, pmin, pmax, lane, ddl, piv_next, rinv_next);
+    gj_eliminate<J + 1>(a, rhs, myrinv, psign, psum, lane, ddl, piv_next, rinv_next);
   }
 }
 
@@ -355,92 +360,103 @@ __device__ __forceinline__ double frames_diff_max(int lane, int M, int fix, cons
   return row0_max(lane < M ? acc : 0.0);
 }
 
+// The current ceres::IterationSummary and the verdict on the evaluation just completed, handed from
+// lm_decide to lm_step.
+struct LmDecision {
+  double cost_z, it_cost, it_cost_change, it_gmn, it_step_norm, it_rel;
+  int it_valid, it_succ;
+  bool first, take_z, done;
+};
+
+__device__ __forceinline__ void lm_trace_row(TraceRec* __restrict__ trace, const SolveParams& prm, int lane, int row,
+                                             const LmDecision& d, double radius) {
+  if (trace != nullptr && lane == 0 && row < prm.trace_cap) {
+    TraceRec t;
+    t.cost = d.it_cost; t.cost_change = d.it_cost_change; t.gradient_max_norm = d.it_gmn; t.step_norm = d.it_step_norm;
+    t.relative_decrease = d.it_rel; t.trust_region_radius = radius; t.step_is_valid = d.it_valid;
+    t.step_is_successful = d.it_succ;
+    trace[row] = t;
+  }
+}
+
 // Wave-0 control logic: Ceres 1.14 TrustRegionMinimizer::Minimize restated around the evaluation
-// that was just completed at z (= x0 in PH_EVAL_X0, the candidate in PH_EVAL_CAND); the system
-// assembled at z is in the buffer `hsel` does NOT select (hsel ? sh.Hz : st.H holds the ACCEPTED
-// system), gradient in sh.gz, cost in sh.D.  Every lane executes it; scalars are uniform.
-// Returns 1 when a new candidate awaits evaluation (published in sh.zvec/zt), 0 when done.
+// that was just completed at z (= x0 in PH_EVAL_X0, the candidate in PH_EVAL_CAND).  Two halves:
+//   lm_decide  needs the COST at z only (sh.D): tolerances, step quality, accept / reject, radius.  In
+//              k_lm<256> it runs while two other wavefronts multiply out the blocks of the system at z.
+//   lm_step    needs the system: x <- z, gradient norm, termination tests, the damped solve, the next
+//              candidate.  Returns 1 when a new candidate awaits evaluation (published in sh.zvec/zt).
+// The system assembled at z is in the buffer `hsel` does NOT select (hsel ? sh.Hz : st.H holds the
+// ACCEPTED system), gradient in sh.gz.  Every lane executes both; scalars are uniform.
 // Written for a short instruction stream (one wavefront issues an instruction per ~4.4 cycles whatever
 // the dependences): one exit, the per-iteration record only as scalars, square roots only where a
 // tolerance or the trace asks for them.
-__device__ int lm_advance_body(LmRegs& r, LmShared& sh, const SolveParams& prm, int M, int n, int lane,
-                               TraceRec* __restrict__ trace, int& hsel MVO_STAMP_PARAM) {
-  LmState& st = sh.st;
+__device__ __forceinline__ void lm_decide(LmRegs& r, LmShared& sh, const SolveParams& prm, int M, int lane,
+                                          TraceRec* __restrict__ trace, LmDecision& d MVO_STAMP_PARAM) {
   const int fix = prm.fix_length;
-  const double* __restrict__ Hnew = hsel ? st.H : sh.Hz;  // the system just assembled at z
 #ifdef MVO_LM_STAMPS
   const bool stamp_on = stamp_acc_ != nullptr;
   unsigned long long astamp_prev_ = __builtin_amdgcn_s_memtime();
 #endif
   const bool tracing = trace != nullptr && prm.trace_cap > 0;
-  // the current ceres::IterationSummary, as scalars
-  double it_cost = 0.0, it_cost_change = 0.0, it_gmn = 0.0, it_step_norm = 0.0, it_rel = 0.0;
-  int it_valid = 0, it_succ = 0;
-  auto write_trace = [&](int row) {
-    if (tracing && lane == 0 && row < prm.trace_cap) {
-      TraceRec t;
-      t.cost = it_cost; t.cost_change = it_cost_change; t.gradient_max_norm = it_gmn; t.step_norm = it_step_norm;
-      t.relative_decrease = it_rel; t.trust_region_radius = r.radius; t.step_is_valid = it_valid;
-      t.step_is_successful = it_succ;
-      trace[row] = t;
-    }
-  };
-
-  const bool first = (r.phase == PH_EVAL_X0);
+  d.it_cost = d.it_cost_change = d.it_gmn = d.it_step_norm = d.it_rel = 0.0;
+  d.it_valid = d.it_succ = 0;
+  d.first = (r.phase == PH_EVAL_X0);
+  d.done = false;
   // Ceres 1.14 rejects non-finite residuals (ResidualBlock::Evaluate / IsEvaluationValid): at the
   // initial point the minimizer fails before any step; a candidate that "failed to evaluate" gets
   // cost = max and is rejected.  A NaN/Inf residual makes the summed cost non-finite.
   const double cost_raw = sh.D[(MVO_MAXM - 1) * MCX][9];  // all classes: prefix over every a, suffix from j = 0
-  const double cost_z = (first || isfinite(cost_raw)) ? cost_raw : DBL_MAX;
-  if (first && !isfinite(cost_z)) {
-    r.iteration = 0;
-    r.ntrace = 1;  // iteration 0 is the one (failed) record: summary.iterations = 0
-    it_cost = cost_z;
-    r.radius = 0.0;
-    write_trace(0);
-    r.nsucc = r.nunsucc = 0;
-    r.initial_cost = r.final_cost = cost_z;
-    r.bv[0] = r.xv[0]; r.bv[1] = r.xv[1]; r.bv[2] = r.xv[2]; r.bt = r.xt;  // written back untouched
-    lm_terminate(r, 2, 8);
-    return 0;
-  }
-  bool take_z = first;
-  int done = 0;
-  if (first) {
-    // IterationZero
-    r.iteration = 0;
-    r.min_cost = DBL_MAX;
-    r.radius = 1e4;  // initial_trust_region_radius
-    r.decf = 2.0;
-    r.reuse_diag = 0;
-    r.num_invalid = 0;
-    r.nsucc = r.nunsucc = 0;
-    r.ntrace = 0;
-    r.mcc = 0.0;
-    r.cv[0] = r.xv[0]; r.cv[1] = r.xv[1]; r.cv[2] = r.xv[2]; r.ct = r.xt;  // z == x0
+  const double cost_z = (d.first || isfinite(cost_raw)) ? cost_raw : DBL_MAX;
+  d.cost_z = cost_z;
+  d.take_z = d.first;
+  if (d.first) {
+    if (!isfinite(cost_z)) {
+      r.iteration = 0;
+      r.ntrace = 1;  // iteration 0 is the one (failed) record: summary.iterations = 0
+      d.it_cost = cost_z;
+      lm_trace_row(trace, prm, lane, 0, d, 0.0);
+      r.nsucc = r.nunsucc = 0;
+      r.initial_cost = r.final_cost = cost_z;
+      r.bv[0] = r.xv[0]; r.bv[1] = r.xv[1]; r.bv[2] = r.xv[2]; r.bt = r.xt;  // written back untouched
+      lm_terminate(r, 2, 8);
+      d.take_z = false;
+      d.done = true;
+    } else {
+      // IterationZero
+      r.iteration = 0;
+      r.min_cost = DBL_MAX;
+      r.radius = 1e4;  // initial_trust_region_radius
+      r.decf = 2.0;
+      r.reuse_diag = 0;
+      r.num_invalid = 0;
+      r.nsucc = r.nunsucc = 0;
+      r.ntrace = 0;
+      r.mcc = 0.0;
+      r.cv[0] = r.xv[0]; r.cv[1] = r.xv[1]; r.cv[2] = r.xv[2]; r.ct = r.xt;  // z == x0
+    }
   } else {
     // ParameterToleranceReached: ||x - z|| <= ptol (||x|| + ptol).  With ptol == 0 that is "the step
     // vanished", no square root needed (sqrt is > 0 for every positive argument).
     const double sn2 = frames_diff_sq(lane, M, fix, r.xv, r.xt, r.cv, r.ct);
-    if (tracing || prm.ptol > 0.0) it_step_norm = sqrt(sn2);
-    const bool ptol_hit = prm.ptol > 0.0 ? it_step_norm <= prm.ptol * (r.x_norm + prm.ptol) : sn2 <= 0.0;
+    if (tracing || prm.ptol > 0.0) d.it_step_norm = sqrt(sn2);
+    const bool ptol_hit = prm.ptol > 0.0 ? d.it_step_norm <= prm.ptol * (r.x_norm + prm.ptol) : sn2 <= 0.0;
     // FunctionToleranceReached
-    it_cost_change = r.x_cost - cost_z;
-    const bool ftol_hit = fabs(it_cost_change) <= prm.ftol * r.x_cost;
+    d.it_cost_change = r.x_cost - cost_z;
+    const bool ftol_hit = fabs(d.it_cost_change) <= prm.ftol * r.x_cost;
     if (ptol_hit || ftol_hit) {
       lm_terminate(r, 0, ptol_hit ? 3 : 4);
-      done = 1;
+      d.done = true;
     } else {
       // TrustRegionStepEvaluator::StepQuality
       const double rel = (r.se_cur - cost_z) * fast_rcp(r.mcc);
       const double hist = (r.se_ref - cost_z) * fast_rcp(r.se_acc_ref + r.mcc);
-      it_rel = fmax(rel, hist);
-      it_valid = 1;
-      take_z = it_rel > 1e-3;  // min_relative_decrease
-      if (take_z) {
-        it_succ = 1;
+      d.it_rel = fmax(rel, hist);
+      d.it_valid = 1;
+      d.take_z = d.it_rel > 1e-3;  // min_relative_decrease
+      if (d.take_z) {
+        d.it_succ = 1;
         // LevenbergMarquardtStrategy::StepAccepted
-        const double q = 2.0 * it_rel - 1.0;
+        const double q = 2.0 * d.it_rel - 1.0;
         r.radius = fmin(1e16, r.radius * fast_rcp(fmax(1.0 / 3.0, 1.0 - q * q * q)));
         r.decf = 2.0;
         r.reuse_diag = 0;
@@ -469,49 +485,71 @@ __device__ int lm_advance_body(LmRegs& r, LmShared& sh, const SolveParams& prm, 
         r.radius = r.radius * fast_rcp(r.decf);  // a power of two: exact
         r.decf *= 2.0;
         r.reuse_diag = 1;
-        it_cost = cost_z;
-        it_gmn = r.gmn;
+        d.it_cost = cost_z;
+        d.it_gmn = r.gmn;
       }
     }
   }
-
-  if (take_z) {
-    // x <- z; EvaluateGradientAndJacobian = the system assembled at z
+  if (d.take_z) {
+    // x <- z (the system at z is taken over in lm_step)
     r.xv[0] = r.cv[0]; r.xv[1] = r.cv[1]; r.xv[2] = r.cv[2]; r.xt = r.ct;
     r.x_cost = cost_z;
     if (prm.ptol > 0.0) {  // ||x|| is only ever read by the parameter-tolerance test
       const double zero3[3] = {0.0, 0.0, 0.0};
       r.x_norm = sqrt(frames_diff_sq(lane, M, fix, r.xv, r.xt, zero3, 0.0));
     }
-    const int fl = fcol(lane < n ? lane : 0, fix);
-    hsel ^= 1;  // the buffers swap roles: no copy of the 15 x 15 system
-    r.g = lane < n ? sh.gz[fl] : 0.0;
-    r.hdiag = lane < n ? Hnew[fl * MVO_MAXC + fl] : 0.0;
-    if (first) {
-      // jacobi_scaling, fixed at iteration 0.  Ceres takes the column norm of J, a sum of squares; here
-      // H_ll = G^T W G can come out as -1e-37 for a column the data do not constrain at all (every
-      // baseline parallel to u: P v = 0 up to rounding) -- the square root of that must not be NaN.
-      r.js = 1.0 / (1.0 + sqrt(fmax(r.hdiag, 0.0)));
+    if (d.first) {
       r.initial_cost = r.final_cost = r.x_cost;
       r.se_min = r.se_cur = r.se_ref = r.se_cand = r.x_cost;
       r.se_acc_ref = r.se_acc_cand = 0.0;
       r.se_nonmono = 0;
-      it_valid = 1;
-      it_succ = 1;
+      d.it_valid = 1;
+      d.it_succ = 1;
+    }
+    d.it_cost = r.x_cost;
+  }
+  MVO_ASTAMP(8);
+}
+
+// GMN_READY: the gradient max norm at z was left in sh.gmn_z by a helper wavefront (k_lm<256>).
+template <bool GMN_READY>
+__device__ __forceinline__ int lm_step(LmRegs& r, LmShared& sh, const SolveParams& prm, int M, int n, int lane,
+                                       TraceRec* __restrict__ trace, int& hsel, LmDecision& d MVO_STAMP_PARAM) {
+  LmState& st = sh.st;
+  const int fix = prm.fix_length;
+#ifdef MVO_LM_STAMPS
+  const bool stamp_on = stamp_acc_ != nullptr;
+  unsigned long long astamp_prev_ = __builtin_amdgcn_s_memtime();
+#endif
+  if (d.take_z) {
+    // EvaluateGradientAndJacobian = the system assembled at z
+    const double* __restrict__ Hnew = hsel ? st.H : sh.Hz;
+    const int fl = fcol(lane < n ? lane : 0, fix);
+    hsel ^= 1;  // the buffers swap roles: no copy of the 15 x 15 system
+    r.g = lane < n ? sh.gz[fl] : 0.0;
+    r.hdiag = lane < n ? Hnew[fl * MVO_MAXC + fl] : 0.0;
+    if (d.first) {
+      // jacobi_scaling, fixed at iteration 0.  Ceres takes the column norm of J, a sum of squares; here
+      // H_ll = G^T W G can come out as -1e-37 for a column the data do not constrain at all (every
+      // baseline parallel to u: P v = 0 up to rounding) -- the square root of that must not be NaN.
+      r.js = 1.0 / (1.0 + sqrt(fmax(r.hdiag, 0.0)));
     }
     // gradient_max_norm = || x - Plus(x, -g) ||_inf
-    double pv[3], pt;
-    frames_plus(lane, M, fix, r.xv, r.xt, r.g, -1.0, pv, pt);
-    r.gmn = frames_diff_max(lane, M, fix, r.xv, r.xt, pv, pt);
-    it_cost = r.x_cost;
-    it_gmn = r.gmn;
+    if (GMN_READY) {
+      r.gmn = sh.gmn_z;
+    } else {
+      double pv[3], pt;
+      frames_plus(lane, M, fix, r.xv, r.xt, r.g, -1.0, pv, pt);
+      r.gmn = frames_diff_max(lane, M, fix, r.xv, r.xt, pv, pt);
+    }
+    d.it_gmn = r.gmn;
   }
-
-  MVO_ASTAMP(8);
+  MVO_ASTAMP(15);
+  bool done = d.done;
   int go = 0;
   while (!done) {
     // ---- FinalizeIterationAndCheckIfMinimizerCanContinue ----
-    if (it_succ) {
+    if (d.it_succ) {
       ++r.nsucc;
       if (r.x_cost < r.min_cost) {
         r.min_cost = r.x_cost;
@@ -520,15 +558,15 @@ __device__ int lm_advance_body(LmRegs& r, LmShared& sh, const SolveParams& prm, 
     } else {
       ++r.nunsucc;
     }
-    write_trace(r.ntrace);
+    lm_trace_row(trace, prm, lane, r.ntrace, d, r.radius);
     ++r.ntrace;
-    r.final_cost = fmin(r.final_cost, it_cost);
+    r.final_cost = fmin(r.final_cost, d.it_cost);
 
     if (r.iteration >= prm.max_it) {
       lm_terminate(r, 1, 1);
       break;
     }
-    if (it_succ && it_gmn <= prm.gtol) {
+    if (d.it_succ && d.it_gmn <= prm.gtol) {
       lm_terminate(r, 0, 2);
       break;
     }
@@ -540,8 +578,8 @@ __device__ int lm_advance_body(LmRegs& r, LmShared& sh, const SolveParams& prm, 
     MVO_ASTAMP(9);
     // ---- next iteration: ComputeTrustRegionStep ----
     ++r.iteration;
-    it_cost = it_cost_change = it_gmn = it_step_norm = it_rel = 0.0;
-    it_valid = it_succ = 0;
+    d.it_cost = d.it_cost_change = d.it_gmn = d.it_step_norm = d.it_rel = 0.0;
+    d.it_valid = d.it_succ = 0;
 
     if (!r.reuse_diag) r.dg = fmin(fmax(r.js * r.js * r.hdiag, 1e-6), 1e32);  // min/max_lm_diagonal
     r.reuse_diag = 1;
@@ -562,15 +600,16 @@ __device__ int lm_advance_body(LmRegs& r, LmShared& sh, const SolveParams& prm, 
     const double ddl = lane < n ? dd : 1.0;  // added to a row's diagonal entry when it becomes the pivot
     const double rhs0 = jsm * r.g;
     MVO_ASTAMP(10);
-    double rhs = rhs0, myrinv = 1.0, pmin = DBL_MAX, pmax = 0.0;
+    double rhs = rhs0, myrinv = 1.0, psum = 0.0;
+    int psign = 0;
     {
       const double piv0 = bcast_lane(a[0] + ddl, 0);
-      gj_eliminate<0>(a, rhs, myrinv, pmin, pmax, lane, ddl, piv0, fast_rcp(piv0));
+      gj_eliminate<0>(a, rhs, myrinv, psign, psum, lane, ddl, piv0, fast_rcp(piv0));
     }
     MVO_ASTAMP(11);
     const double step = lane < n ? -(rhs * myrinv) : 0.0;
-    // pivots <= 0 or infinite, or a non-finite step: the linear solver failed
-    const bool ok = pmin > 0.0 && pmax <= DBL_MAX && !__any(!isfinite(step));
+    // a pivot < 0 or infinite, or a non-finite step (a zero pivot gives one): the linear solver failed
+    const bool ok = psign >= 0 && isfinite(psum) && !__any(!isfinite(step));
     // model_cost_change = -(Js step)^T (r + Js step / 2) = -step^T b - step^T As step / 2 with
     // b = Js^T r, As = Js^T Js.  The step solves (As + D^2) step = -b, so As step = -b - D^2 step
     // and the change is (-step^T b + step^T D^2 step) / 2 -- no second pass over the matrix.
@@ -585,8 +624,8 @@ __device__ int lm_advance_body(LmRegs& r, LmShared& sh, const SolveParams& prm, 
       }
       r.radius *= 0.5;  // StepIsInvalid
       r.reuse_diag = 1;
-      it_cost = r.x_cost;
-      it_gmn = r.gmn;
+      d.it_cost = r.x_cost;
+      d.it_gmn = r.gmn;
       continue;
     }
     r.num_invalid = 0;
@@ -600,6 +639,102 @@ __device__ int lm_advance_body(LmRegs& r, LmShared& sh, const SolveParams& prm, 
     break;
   }
   return go;
+}
+
+// ---- stage (4) of an evaluation: the blocks of the system at z ---------------------------------
+// 3x3 blocks G_k^T W_kl G_l, one ROW of a block per lane (45 rows fit a wavefront), and the gradient
+// entries G_k^T y_k.  W_kl = D[k][l] for l > k.  The pair (k, k) is kept apart: its baseline is s_k v_k
+// alone, so r does not depend on t_k at all (IR.cpp:466-471 normalises the scale away) and its scale
+// row / column is exactly zero instead of rounding noise of the size of S -- the diagonal W_kk, y_k
+// leave class (k, k) out: D[k][k+1] + C1[k-1][k].
+struct BlockRole {
+  int nB4, k4, l4, i4;  // lane < nB4: row i4 of block (k4, l4); then 3M gradient entries (k4, i4)
+};
+__device__ __forceinline__ void upper_block(int M, int t, int& k, int& l);
+__device__ __forceinline__ int sym6(int r, int c);
+__device__ __forceinline__ BlockRole block_role(int M, int lane) {
+  BlockRole b;
+  b.nB4 = 3 * ((M * (M + 1)) / 2);
+  if (lane < b.nB4) {
+    b.i4 = lane % 3;
+    upper_block(M, lane / 3, b.k4, b.l4);
+  } else {
+    const int e = lane - b.nB4 < 3 * M ? lane - b.nB4 : 0;
+    b.k4 = b.l4 = e / 3;
+    b.i4 = e - 3 * b.k4;
+  }
+  return b;
+}
+
+__device__ __forceinline__ void lm_block_rows(LmShared& sh, const BlockRole& br, int lane, int hsel) {
+  double* __restrict__ Hw = hsel ? sh.st.H : sh.Hz;
+  const int k4 = br.k4, l4 = br.l4, i4 = br.i4;
+  if (lane < br.nB4) {
+    const double* __restrict__ wsrc = sh.D[k4 * MCX + (k4 == l4 ? k4 + 1 : l4)];
+    const double* __restrict__ csrc = sh.C1[(k4 > 0 ? k4 - 1 : 0) * MCX + k4];
+    const bool diag = k4 == l4;
+    double Wv[6], gk[3], Gl[9];
+#pragma unroll
+    for (int v = 0; v < 6; ++v) Wv[v] = wsrc[v] + ((diag && k4 > 0) ? csrc[v] : 0.0);
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr) gk[rr] = sh.G[k4][3 * rr + i4];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) Gl[e] = sh.G[l4][e];
+    double val[3];
+    {
+      double gw[3];  // (G_k^T W)[i][m]
+#pragma unroll
+      for (int m = 0; m < 3; ++m) gw[m] = gk[0] * Wv[sym6(0, m)] + gk[1] * Wv[sym6(1, m)] + gk[2] * Wv[sym6(2, m)];
+#pragma unroll
+      for (int jj = 0; jj < 3; ++jj) val[jj] = gw[0] * Gl[jj] + gw[1] * Gl[3 + jj] + gw[2] * Gl[6 + jj];
+    }
+    if (diag && i4 < 2) {  // the pair (k,k): direction columns only
+      const double* Ts = sh.kk[k4];
+      double gw[3];
+#pragma unroll
+      for (int m = 0; m < 3; ++m) gw[m] = gk[0] * Ts[sym6(0, m)] + gk[1] * Ts[sym6(1, m)] + gk[2] * Ts[sym6(2, m)];
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) val[jj] += gw[0] * Gl[jj] + gw[1] * Gl[3 + jj] + gw[2] * Gl[6 + jj];
+    }
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj)
+      if (!diag || jj >= i4) {  // diagonal blocks: the upper entry is mirrored, H stays symmetric
+        Hw[(3 * k4 + i4) * MVO_MAXC + 3 * l4 + jj] = val[jj];
+        Hw[(3 * l4 + jj) * MVO_MAXC + 3 * k4 + i4] = val[jj];
+      }
+  }
+}
+
+// gradient entry (k, i) = G_k^T y_k, for the lanes `on`
+__device__ __forceinline__ void lm_gradient_entry(LmShared& sh, bool on, int k4, int i4) {
+  if (on) {
+    const double* __restrict__ dk = sh.D[k4 * MCX + k4 + 1];
+    const double* __restrict__ ck = sh.C1[(k4 > 0 ? k4 - 1 : 0) * MCX + k4];
+    double gi = 0.0;
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+      const double yv = dk[6 + v] + (k4 > 0 ? ck[6 + v] : 0.0) + (i4 < 2 ? sh.kk[k4][6 + v] : 0.0);
+      gi += sh.G[k4][3 * v + i4] * yv;
+    }
+    sh.gz[3 * k4 + i4] = gi;
+  }
+}
+
+// k_lm<256>, a helper wavefront: the gradient at z and its max norm || z - Plus(z, -g) ||_inf, the
+// same arithmetic lm_step performs in k_lm<64> (frames_plus with sign = -1, frames_diff_max).
+__device__ __forceinline__ void lm_gradient_and_norm(LmShared& sh, int M, int fix, int lane) {
+  const int e = lane < 3 * M ? lane : 0;
+  lm_gradient_entry(sh, lane < 3 * M, e / 3, e % 3);
+  wave0_sync();  // this wavefront's own LDS writes, read back below
+  const int k = lane < M ? lane : 0;
+  const double xv[3] = {sh.zvec[k][0], sh.zvec[k][1], sh.zvec[k][2]};
+  const double xt = sh.zt[k];
+  const double ga = sh.gz[3 * k], gb = sh.gz[3 * k + 1], gt = sh.gz[3 * k + 2];
+  double pv[3];
+  d_plus(xv, -1.0 * ga, -1.0 * gb, pv);
+  const double pt = fix ? xt : xt + -1.0 * gt;
+  const double gmn = frames_diff_max(lane, M, fix, xv, xt, pv, pt);
+  if (lane == 0) sh.gmn_z = gmn;
 }
 
 // t-th block (k, l), k <= l < M, of the upper triangle in row-major order
@@ -772,10 +907,45 @@ __device__ __forceinline__ void inline_pass(const LmShared& sh, const PairDev* _
   }
 }
 
-// k_lm<256>, wavefronts 1..3: the loop of a class wavefront.  Wavefront w evaluates the pairs
-// (a, b), a in {w - 1, w + 2}, b = M + lane + 64 r (r < 4), adds them up per frame and leaves the class
-// totals in sh.cls[a][M].  It executes exactly the workgroup barriers wavefront 0 executes (marked
-// B0 / B1 / B2 on both sides).
+// 10 values x 32 lanes -> 10 totals, separately in the two halves of the wavefront (which hold the
+// pairs of two different frames).  After the call lane L holds, with rp = (L >> 4) & 1,
+//   y  = the total of value 5 rp + 2 ((L >> 2) & 1) + ((L >> 3) & 1)   (identical within 4 lanes)
+//   x4 = the total of value 5 rp + 4                                   (identical within 16 lanes)
+// of its half.  Same idea as wave_reduce10: every level trades half of the values for half of the lanes.
+__device__ __forceinline__ void half_reduce10(const double (&v)[10], int lane, double& y, double& x4) {
+  double w5[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) w5[j] = swap_add16(v[j], v[j + 5]);  // even rows: value j, odd rows: value j + 5
+  const bool b3 = lane & 8, b2 = lane & 4;
+  double x01, x23;
+  {
+    const double keep = b3 ? w5[1] : w5[0], send = b3 ? w5[0] : w5[1];
+    x01 = keep + dpp_mov_f64<0x128>(send);  // row_ror:8 == lane xor 8
+  }
+  {
+    const double keep = b3 ? w5[3] : w5[2], send = b3 ? w5[2] : w5[3];
+    x23 = keep + dpp_mov_f64<0x128>(send);
+  }
+  x4 = w5[4] + dpp_mov_f64<0x128>(w5[4]);
+  {
+    const double keep = b2 ? x23 : x01, send = b2 ? x01 : x23;
+    y = keep + dpp_mov_f64<0x141>(send);  // row_half_mirror: lane i <- lane i ^ 7, the other value of b2
+  }
+  y += dpp_mov_f64<0xB1>(y);
+  y += dpp_mov_f64<0x4E>(y);
+  x4 += dpp_mov_f64<0xB1>(x4);
+  x4 += dpp_mov_f64<0x4E>(x4);
+  x4 += dpp_mov_f64<0x141>(x4);
+}
+
+// k_lm<256>, wavefronts 1..3: the loop of a class wavefront.  Two layouts, chosen per window:
+//   N - 1 - M <= 32 (HALF): wavefront w evaluates the pairs (a, b), a = 2 (w - 1) + (lane >> 5),
+//                   b = M + (lane & 31): one pair per lane, one evaluation, one reduction per half;
+//   otherwise:      a in {w - 1, w + 2}, b = M + lane + 64 r (r < 4), added up per frame.
+// Either way the class totals end up in sh.cls[a][M].  Then, while wavefront 0 decides on the point
+// (lm_decide), wavefront 1 multiplies out the blocks of the system and wavefront 2 the gradient and
+// its norm.  A class wavefront executes exactly the workgroup barriers wavefront 0 executes (marked
+// B0 / B1 / B1b / B1c / B2 on both sides).
 template <int NT>
 __device__ __forceinline__ void lm_class_wave(LmShared& sh, const SolveParams& prm, int cw, int lane, int M, int N, int P,
                                               bool& need_pass, int unit_slots, const PairDev* __restrict__ wp,
@@ -784,6 +954,10 @@ __device__ __forceinline__ void lm_class_wave(LmShared& sh, const SolveParams& p
                                               double* my_sums) {
   constexpr int ROUNDS = 4;  // class (a, M) has at most MVO_HIP_MAX_FRAMES - 1 - M <= 256 pairs
   constexpr int NA = 2;      // frames per class wavefront: cw and cw + 3
+  const int n_pairs_a = N - 1 > M ? N - 1 - M : 0;
+  const bool half = n_pairs_a <= 32;           // wave-uniform
+  const int n_rounds = (n_pairs_a + 63) >> 6;  // wave-uniform
+  const bool two = cw + 3 < M;                 // wave-uniform: a second frame to serve
   int my_p[NA][ROUNDS];
   bool my_ok[NA][ROUNDS];
 #pragma unroll
@@ -794,9 +968,12 @@ __device__ __forceinline__ void lm_class_wave(LmShared& sh, const SolveParams& p
       my_ok[q][rr] = a < M && b <= N - 2;
       my_p[q][rr] = my_ok[q][rr] ? pair_index(N, a, b) : 0;
     }
-  const int n_pairs_a = N - 1 > M ? N - 1 - M : 0;
-  const int n_rounds = (n_pairs_a + 63) >> 6;  // wave-uniform
-  const bool two = cw + 3 < M;                 // wave-uniform: a second frame to serve
+  const int a_h = 2 * cw + (lane >> 5), b_h = M + (lane & 31);
+  if (half) {
+    my_ok[0][0] = a_h < M && b_h <= N - 2;
+    my_p[0][0] = my_ok[0][0] ? pair_index(N, a_h, b_h) : 0;
+  }
+  const BlockRole br = block_role(M, lane);
   PairIn in[NA][ROUNDS];
   bool have_in = false;
   while (!need_pass) {
@@ -808,7 +985,7 @@ __device__ __forceinline__ void lm_class_wave(LmShared& sh, const SolveParams& p
     if (!have_in) {
 #pragma unroll
       for (int q = 0; q < NA; ++q)
-        if (q == 0 || two) {
+        if (q == 0 || (two && !half)) {
           if (n_rounds <= 1) {
             pair_load(in[q][0], my_p[q][0], N, M, unit_slots != 0, wp, partial, pair_off, fr);
           } else {
@@ -819,47 +996,66 @@ __device__ __forceinline__ void lm_class_wave(LmShared& sh, const SolveParams& p
         }
       have_in = !prm.pass_mode;
     }
-    // every pair of frame a has the free frames a .. M-1: one baseline per frame and evaluation; the
-    // slots of one lane are independent chains (sqrt, reciprocal, ~100 flops), issued interleaved
-    double acc[NA][10];
+    if (half) {
+      double beta[3], o[10];
+      free_baseline(sh, a_h < M ? a_h : 0, M - 1, beta);
+      pair_eval(in[0][0], beta, prm.pass_mode, o);
 #pragma unroll
-    for (int q = 0; q < NA; ++q) {
+      for (int v = 0; v < 10; ++v) o[v] = my_ok[0][0] ? o[v] : 0.0;
+      double y, x4;
+      half_reduce10(o, lane, y, x4);
+      if (a_h < M) {
+        const int rp5 = 5 * ((lane >> 4) & 1);
+        if ((lane & 3) == 0) sh.cls[a_h * MCX + M][rp5 + ((lane >> 1) & 2) + ((lane >> 3) & 1)] = y;
+        if ((lane & 15) == 0) sh.cls[a_h * MCX + M][rp5 + 4] = x4;
+      }
+    } else {
+      // every pair of frame a has the free frames a .. M-1: one baseline per frame and evaluation; the
+      // slots of one lane are independent chains (sqrt, reciprocal, ~100 flops), issued interleaved
+      double acc[NA][10];
 #pragma unroll
-      for (int v = 0; v < 10; ++v) acc[q][v] = 0.0;
-      if (q == 0 || two) {
-        const int a = cw + 3 * q;
-        double beta[3];
-        free_baseline(sh, a < M ? a : 0, M - 1, beta);
-        if (n_rounds <= 1) {
-          double o[10];
-          pair_eval(in[q][0], beta, prm.pass_mode, o);
+      for (int q = 0; q < NA; ++q) {
 #pragma unroll
-          for (int v = 0; v < 10; ++v) acc[q][v] = my_ok[q][0] ? o[v] : 0.0;
-        } else {
-          double o[ROUNDS][10];
+        for (int v = 0; v < 10; ++v) acc[q][v] = 0.0;
+        if (q == 0 || two) {
+          const int a = cw + 3 * q;
+          double beta[3];
+          free_baseline(sh, a < M ? a : 0, M - 1, beta);
+          if (n_rounds <= 1) {
+            double o[10];
+            pair_eval(in[q][0], beta, prm.pass_mode, o);
 #pragma unroll
-          for (int rr = 0; rr < ROUNDS; ++rr) pair_eval(in[q][rr], beta, prm.pass_mode, o[rr]);
+            for (int v = 0; v < 10; ++v) acc[q][v] = my_ok[q][0] ? o[v] : 0.0;
+          } else {
+            double o[ROUNDS][10];
 #pragma unroll
-          for (int v = 0; v < 10; ++v) {
-            acc[q][v] = my_ok[q][0] ? o[0][v] : 0.0;
+            for (int rr = 0; rr < ROUNDS; ++rr) pair_eval(in[q][rr], beta, prm.pass_mode, o[rr]);
 #pragma unroll
-            for (int rr = 1; rr < ROUNDS; ++rr) acc[q][v] += my_ok[q][rr] ? o[rr][v] : 0.0;
+            for (int v = 0; v < 10; ++v) {
+              acc[q][v] = my_ok[q][0] ? o[0][v] : 0.0;
+#pragma unroll
+              for (int rr = 1; rr < ROUNDS; ++rr) acc[q][v] += my_ok[q][rr] ? o[rr][v] : 0.0;
+            }
           }
         }
       }
-    }
 #pragma unroll
-    for (int q = 0; q < NA; ++q)
-      if (q == 0 || two) {
-        const int a = cw + 3 * q;
-        double t8, t2;
-        wave_reduce10(acc[q], lane, t8, t2);
-        if (a < M) {
-          if ((lane & 7) == 0) sh.cls[a * MCX + M][reduce8_value_of_lane(lane)] = t8;
-          if ((lane & 31) == 0) sh.cls[a * MCX + M][8 + (lane >> 5)] = t2;
+      for (int q = 0; q < NA; ++q)
+        if (q == 0 || two) {
+          const int a = cw + 3 * q;
+          double t8, t2;
+          wave_reduce10(acc[q], lane, t8, t2);
+          if (a < M) {
+            if ((lane & 7) == 0) sh.cls[a * MCX + M][reduce8_value_of_lane(lane)] = t8;
+            if ((lane & 31) == 0) sh.cls[a * MCX + M][8 + (lane >> 5)] = t2;
+          }
         }
-      }
+    }
     __syncthreads();  // B1: class totals are in LDS
+    __syncthreads();  // B1b: wavefront 0 has formed C1 and D
+    if (cw == 0) lm_block_rows(sh, br, lane, sh.hsel);
+    else if (cw == 1) lm_gradient_and_norm(sh, M, prm.fix_length, lane);
+    __syncthreads();  // B1c: the system at z is in LDS
     __syncthreads();  // B2: wavefront 0 has taken its step and published the next point
     if (!sh.go) break;
     if (prm.pass_mode && !prm.inline_eval) need_pass = true;
@@ -903,6 +1099,7 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
   // an unused column would poison the right-hand side (finite leftovers are harmless: padding rows
   // are identity rows) -- so the second buffer starts from zero like the first.
   for (int i = tid; i < MVO_MAXC * MVO_MAXC; i += NT) sh.Hz[i] = 0.0;
+  if (tid == 0) sh.hsel = 0;
   __syncthreads();
   LmRegs r;      // wavefront 0: the solver state, in registers until the launch ends
   int hsel = 0;  // which of {st.H, Hz} holds the ACCEPTED system; between launches it is st.H
@@ -962,16 +1159,7 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
   // stage, block row (k, l, i) / gradient entry (k, i) of the product stage
   const int jA = lane / 10, vA = lane - 10 * jA;
   const int kB = lane < MVO_MAXM * 10 ? jA : 0, vB = vA;
-  const int nB4 = 3 * ((M * (M + 1)) / 2);  // block rows of the upper triangle; then 3M gradient entries
-  int k4, l4, i4;
-  if (lane < nB4) {
-    i4 = lane % 3;
-    upper_block(M, lane / 3, k4, l4);
-  } else {
-    const int e = lane - nB4 < 3 * M ? lane - nB4 : 0;
-    k4 = l4 = e / 3;
-    i4 = e - 3 * k4;
-  }
+  const BlockRole br = block_role(M, lane);  // block rows of the upper triangle; then 3M gradient entries
 
   while (!need_pass && (!LARGE || wave0)) {
     MVO_STAMP(0);
@@ -1056,62 +1244,24 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
       }
       wave0_sync();
       MVO_STAMP(3);
-      // (4) 3x3 blocks G_k^T W_kl G_l, one ROW of a block per lane (45 rows + 15 gradient entries fit
-      // the wavefront), and gradient entries G_k^T y_k.  W_kl = D[k][l] for l > k.  The pair (k, k) is
-      // kept apart: its baseline is s_k v_k alone, so r does not depend on t_k at all (IR.cpp:466-471
-      // normalises the scale away) and its scale row / column is exactly zero instead of rounding noise
-      // of the size of S -- the diagonal W_kk, y_k leave class (k, k) out: D[k][k+1] + C1[k-1][k].
-      {
-        double* __restrict__ Hw = hsel ? sh.st.H : sh.Hz;
-        if (lane < nB4) {
-          const double* __restrict__ wsrc = sh.D[k4 * MCX + (k4 == l4 ? k4 + 1 : l4)];
-          const double* __restrict__ csrc = sh.C1[(k4 > 0 ? k4 - 1 : 0) * MCX + k4];
-          const bool diag = k4 == l4;
-          double Wv[6], gk[3], Gl[9];
-#pragma unroll
-          for (int v = 0; v < 6; ++v) Wv[v] = wsrc[v] + ((diag && k4 > 0) ? csrc[v] : 0.0);
-#pragma unroll
-          for (int rr = 0; rr < 3; ++rr) gk[rr] = sh.G[k4][3 * rr + i4];
-#pragma unroll
-          for (int e = 0; e < 9; ++e) Gl[e] = sh.G[l4][e];
-          double val[3];
-          {
-            double gw[3];  // (G_k^T W)[i][m]
-#pragma unroll
-            for (int m = 0; m < 3; ++m) gw[m] = gk[0] * Wv[sym6(0, m)] + gk[1] * Wv[sym6(1, m)] + gk[2] * Wv[sym6(2, m)];
-#pragma unroll
-            for (int jj = 0; jj < 3; ++jj) val[jj] = gw[0] * Gl[jj] + gw[1] * Gl[3 + jj] + gw[2] * Gl[6 + jj];
-          }
-          if (diag && i4 < 2) {  // the pair (k,k): direction columns only
-            const double* Ts = sh.kk[k4];
-            double gw[3];
-#pragma unroll
-            for (int m = 0; m < 3; ++m) gw[m] = gk[0] * Ts[sym6(0, m)] + gk[1] * Ts[sym6(1, m)] + gk[2] * Ts[sym6(2, m)];
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) val[jj] += gw[0] * Gl[jj] + gw[1] * Gl[3 + jj] + gw[2] * Gl[6 + jj];
-          }
-#pragma unroll
-          for (int jj = 0; jj < 3; ++jj)
-            if (!diag || jj >= i4) {  // diagonal blocks: the upper entry is mirrored, H stays symmetric
-              Hw[(3 * k4 + i4) * MVO_MAXC + 3 * l4 + jj] = val[jj];
-              Hw[(3 * l4 + jj) * MVO_MAXC + 3 * k4 + i4] = val[jj];
-            }
-        } else if (lane < nB4 + 3 * M) {
-          const double* __restrict__ dk = sh.D[k4 * MCX + k4 + 1];
-          const double* __restrict__ ck = sh.C1[(k4 > 0 ? k4 - 1 : 0) * MCX + k4];
-          double gi = 0.0;
-#pragma unroll
-          for (int v = 0; v < 3; ++v) {
-            const double yv = dk[6 + v] + (k4 > 0 ? ck[6 + v] : 0.0) + (i4 < 2 ? sh.kk[k4][6 + v] : 0.0);
-            gi += sh.G[k4][3 * v + i4] * yv;
-          }
-          sh.gz[3 * k4 + i4] = gi;
-        }
+      // (4) the blocks of the system at z and the verdict on z.  k_lm<256>: two helper wavefronts multiply
+      // out the blocks and the gradient (lm_class_wave) while this one decides -- the verdict needs the
+      // cost only; k_lm<64>: one after the other.
+      LmDecision dec;
+      if (LARGE) {
+        __syncthreads();  // B1b: C1 and D are complete
+        lm_decide(r, sh, prm, M, lane, (w == 0) ? trace : nullptr, dec MVO_STAMP_ARG);
+        __syncthreads();  // B1c: the system at z and its gradient norm are complete
+      } else {
+        lm_block_rows(sh, br, lane, hsel);
+        lm_gradient_entry(sh, lane >= br.nB4 && lane < br.nB4 + 3 * M, br.k4, br.i4);
+        wave0_sync();
+        lm_decide(r, sh, prm, M, lane, (w == 0) ? trace : nullptr, dec MVO_STAMP_ARG);
       }
-      wave0_sync();
       MVO_STAMP(4);
-      // ---------------- accept/reject, damping, next candidate ----------------
-      const int go = lm_advance_body(r, sh, prm, M, n, lane, (w == 0) ? trace : nullptr, hsel MVO_STAMP_ARG);
+      // ---------------- damping, next candidate ----------------
+      const int go = lm_step<LARGE>(r, sh, prm, M, n, lane, (w == 0) ? trace : nullptr, hsel, dec MVO_STAMP_ARG);
+      if (lane == 0) sh.hsel = hsel;
       if (lane == 0) sh.go = go;
     }
     __syncthreads();  // B2
