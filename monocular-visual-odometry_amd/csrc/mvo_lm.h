@@ -316,16 +316,18 @@ __device__ __forceinline__ void gj_row_update(double (&a)[MVO_MAXC], double f) {
 // has a zero in that column.  The LM damping D^2 = diag / radius is never written into the matrix: a
 // row's diagonal entry is not touched by the steps before its own, so the damping is added when the
 // entry becomes the pivot (ddl = the lane's damping on active rows, 1 on the all-zero padding rows).  Each lane
-// keeps the reciprocal of its own pivot (myrinv); psign / psum collect the pivots for the validity test.
+// keeps the reciprocal of its own pivot (myrinv); phimax collects the pivots for the validity test.
 // Look-ahead order: step J updates column J+1 first and starts the reciprocal of the NEXT pivot
 // (readlane -> v_rcp -> two Newton steps, a ~100-cycle dependent chain) before it touches the
 // remaining columns, whose independent updates then fill that latency.
 template <int J>
-__device__ __forceinline__ void gj_eliminate(double (&a)[MVO_MAXC], double& rhs, double& myrinv, int& psign,
-                                             double& psum, int lane, double ddl, double piv, double rinv) {
+__device__ __forceinline__ void gj_eliminate(double (&a)[MVO_MAXC], double& rhs, double& myrinv, unsigned& phimax,
+                                             int lane, double ddl, double piv, double rinv) {
   if constexpr (J < MVO_MAXC) {
-    psign |= __double2hiint(piv);  // a negative pivot leaves its sign bit here (scalar or)
-    psum += piv;                   // an infinite or NaN pivot makes the sum non-finite
+    // largest high word of the pivots, as unsigned: a negative pivot (sign bit), an infinite one or a NaN
+    // (exponent 0x7ff) all end up >= 0x7ff00000 -- one scalar max per step
+    const unsigned hi = (unsigned)__double2hiint(piv);
+    phimax = hi > phimax ? hi : phimax;
     // `lane == J` is recomputed at every step: left to itself the compiler hoists the fifteen lane
     // masks out of the solver loop, 30 scalar registers that it then spills and reloads one by one
     int lane_here = lane;
@@ -341,7 +343,7 @@ __device__ __forceinline__ void gj_eliminate(double (&a)[MVO_MAXC], double& rhs,
       gj_row_update<J, J + 2>(a, f);
     }
     rhs -= f * row_bcast<J>(rhs);
-    gj_eliminate<J + 1>(a, rhs, myrinv, psign, psum, lane, ddl, piv_next, rinv_next);
+    gj_eliminate<J + 1>(a, rhs, myrinv, phimax, lane, ddl, piv_next, rinv_next);
   }
 }
 
@@ -600,16 +602,16 @@ __device__ __forceinline__ int lm_step(LmRegs& r, LmShared& sh, const SolveParam
     const double ddl = lane < n ? dd : 1.0;  // added to a row's diagonal entry when it becomes the pivot
     const double rhs0 = jsm * r.g;
     MVO_ASTAMP(10);
-    double rhs = rhs0, myrinv = 1.0, psum = 0.0;
-    int psign = 0;
+    double rhs = rhs0, myrinv = 1.0;
+    unsigned phimax = 0;
     {
       const double piv0 = bcast_lane(a[0] + ddl, 0);
-      gj_eliminate<0>(a, rhs, myrinv, psign, psum, lane, ddl, piv0, fast_rcp(piv0));
+      gj_eliminate<0>(a, rhs, myrinv, phimax, lane, ddl, piv0, fast_rcp(piv0));
     }
     MVO_ASTAMP(11);
     const double step = lane < n ? -(rhs * myrinv) : 0.0;
     // a pivot < 0 or infinite, or a non-finite step (a zero pivot gives one): the linear solver failed
-    const bool ok = psign >= 0 && isfinite(psum) && !__any(!isfinite(step));
+    const bool ok = phimax < 0x7ff00000u && !__any(!isfinite(step));
     // model_cost_change = -(Js step)^T (r + Js step / 2) = -step^T b - step^T As step / 2 with
     // b = Js^T r, As = Js^T Js.  The step solves (As + D^2) step = -b, so As step = -b - D^2 step
     // and the change is (-step^T b + step^T D^2 step) / 2 -- no second pass over the matrix.
@@ -666,13 +668,16 @@ __device__ __forceinline__ BlockRole block_role(int M, int lane) {
   return b;
 }
 
+// WHICH: 0 = every block row, 1 = the rows of the diagonal blocks only, 2 = the others only (k_lm<256>
+// gives the two kinds to two wavefronts: each then runs a stream without the other's special cases)
+template <int WHICH>
 __device__ __forceinline__ void lm_block_rows(LmShared& sh, const BlockRole& br, int lane, int hsel) {
   double* __restrict__ Hw = hsel ? sh.st.H : sh.Hz;
   const int k4 = br.k4, l4 = br.l4, i4 = br.i4;
-  if (lane < br.nB4) {
-    const double* __restrict__ wsrc = sh.D[k4 * MCX + (k4 == l4 ? k4 + 1 : l4)];
+  if (lane < br.nB4 && (WHICH == 0 || (WHICH == 1) == (k4 == l4))) {
+    const bool diag = WHICH == 0 ? k4 == l4 : WHICH == 1;
+    const double* __restrict__ wsrc = sh.D[k4 * MCX + (diag ? k4 + 1 : l4)];
     const double* __restrict__ csrc = sh.C1[(k4 > 0 ? k4 - 1 : 0) * MCX + k4];
-    const bool diag = k4 == l4;
     double Wv[6], gk[3], Gl[9];
 #pragma unroll
     for (int v = 0; v < 6; ++v) Wv[v] = wsrc[v] + ((diag && k4 > 0) ? csrc[v] : 0.0);
@@ -943,8 +948,8 @@ __device__ __forceinline__ void half_reduce10(const double (&v)[10], int lane, d
 //                   b = M + (lane & 31): one pair per lane, one evaluation, one reduction per half;
 //   otherwise:      a in {w - 1, w + 2}, b = M + lane + 64 r (r < 4), added up per frame.
 // Either way the class totals end up in sh.cls[a][M].  Then, while wavefront 0 decides on the point
-// (lm_decide), wavefront 1 multiplies out the blocks of the system and wavefront 2 the gradient and
-// its norm.  A class wavefront executes exactly the workgroup barriers wavefront 0 executes (marked
+// (lm_decide), wavefronts 1 and 3 multiply out the diagonal / the other blocks of the system and
+// wavefront 2 the gradient and its norm.  A class wavefront executes exactly the workgroup barriers wavefront 0 executes (marked
 // B0 / B1 / B1b / B1c / B2 on both sides).
 template <int NT>
 __device__ __forceinline__ void lm_class_wave(LmShared& sh, const SolveParams& prm, int cw, int lane, int M, int N, int P,
@@ -1053,8 +1058,9 @@ __device__ __forceinline__ void lm_class_wave(LmShared& sh, const SolveParams& p
     }
     __syncthreads();  // B1: class totals are in LDS
     __syncthreads();  // B1b: wavefront 0 has formed C1 and D
-    if (cw == 0) lm_block_rows(sh, br, lane, sh.hsel);
+    if (cw == 0) lm_block_rows<1>(sh, br, lane, sh.hsel);
     else if (cw == 1) lm_gradient_and_norm(sh, M, prm.fix_length, lane);
+    else lm_block_rows<2>(sh, br, lane, sh.hsel);
     __syncthreads();  // B1c: the system at z is in LDS
     __syncthreads();  // B2: wavefront 0 has taken its step and published the next point
     if (!sh.go) break;
@@ -1253,7 +1259,7 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
         lm_decide(r, sh, prm, M, lane, (w == 0) ? trace : nullptr, dec MVO_STAMP_ARG);
         __syncthreads();  // B1c: the system at z and its gradient norm are complete
       } else {
-        lm_block_rows(sh, br, lane, hsel);
+        lm_block_rows<0>(sh, br, lane, hsel);
         lm_gradient_entry(sh, lane >= br.nB4 && lane < br.nB4 + 3 * M, br.k4, br.i4);
         wave0_sync();
         lm_decide(r, sh, prm, M, lane, (w == 0) ? trace : nullptr, dec MVO_STAMP_ARG);
