@@ -47,6 +47,8 @@ struct SolveParams {
   int32_t inline_eval;  // 1: k_lm evaluates the observations itself (small / many windows)
   int32_t fresh;        // 1: first launch of a solve -- the stored state is stale, start from zeros
   int32_t win_base;     // k_lm: window of workgroup 0 (launches over a range of the windows)
+  int32_t M, N, P;      // every window of an upload has the same shape
+  int32_t x0_ready;     // pass mode: the sums of the evaluation at x0 exist already (fused fold)
 };
 
 struct TraceRec {  // == mvo_hip_iteration

@@ -155,7 +155,7 @@ struct mvo_hip_context {
   hipStream_t stream = nullptr;
   hipError_t last_hip_error = hipSuccess;
   // device buffers
-  DevBuf d_arena, d_m0, d_m1, d_c, d_partial, d_pair_u, d_states, d_ctl, d_trace, d_res, d_jac, d_pairsum;
+  DevBuf d_arena, d_m0, d_m1, d_c, d_partial, d_pair_u, d_states, d_ctl, d_trace, d_res, d_jac, d_pairsum, d_pticket;
   // The tables of one upload (and the rays of a small one) are staged in ONE pinned block and
   // reach the device in ONE copy into d_arena; these point into it (rays: or into d_m0 / d_m1).
   struct {
@@ -166,6 +166,7 @@ struct mvo_hip_context {
     PairDev* pairs_unit = nullptr;
     TileDev* tiles = nullptr;
     uint32_t* wave_tiles = nullptr;
+    double* pair_u0 = nullptr;  // pass mode: unit baselines at the starting point (host_pair_u0)
     double* m0 = nullptr;
     double* m1 = nullptr;
   } t;
@@ -206,6 +207,7 @@ struct mvo_hip_context {
   mvo_hip_options opt{};
   bool pass_mode = false;
   bool inline_eval = false;  // k_lm runs the observation passes itself (small or many windows)
+  bool tickets_clean = false;  // d_pticket is all zero (it is after every completed launch)
   std::vector<mvo_hip_frame> h_frames;  // copy of the uploaded frames (write-back base)
   std::vector<PairDev> h_pairs;
   // trace
@@ -312,6 +314,9 @@ SolveParams make_params(const mvo_hip_context* h) {
   prm.pass_mode = h->pass_mode ? 1 : 0;
   prm.trace_cap = h->trace_cap;
   prm.inline_eval = h->inline_eval ? 1 : 0;
+  prm.M = (int32_t)h->M;
+  prm.N = (int32_t)h->N;
+  prm.P = (int32_t)h->P;
   return prm;
 }
 
@@ -320,6 +325,43 @@ int ensure_events(mvo_hip_context* h) {
   for (auto& e : h->ev) HIP_TRY(hipEventCreate(&e));
   h->events_ready = true;
   return MVO_HIP_OK;
+}
+
+// Unit baselines of window w's pairs at the starting point (v_initx): what k_lm publishes for a
+// candidate (pair_unit_baseline, IR.cpp:137-144, 254-255, 298-309, 466-577), here on the host so that the
+// fold can be the evaluation pass at x0 as well.  out: 4 doubles per pair (u, |baseline|).
+void host_pair_u0(const mvo_hip_context* h, uint32_t w, double* out) {
+  const uint32_t M = h->M, N = h->N;
+  const double max_len = h->opt.highest_length, min_len = h->opt.lowest_length;
+  double sv[MVO_MAXM][3];
+  for (uint32_t k = 0; k < M; ++k) {
+    const double* x = &h->v_initx[((size_t)w * MVO_MAXM + k) * 4];
+    const double e = std::exp(-1.0 * x[3]);  // scaleTemplated, IR.cpp:298-309
+    const double sk = std::isinf(e) ? min_len : min_len + ((max_len - min_len) / (1.0 + e));
+    for (int j = 0; j < 3; ++j) sv[k][j] = sk * x[j];
+  }
+  uint32_t p = 0;
+  for (uint32_t a = 0; a < M; ++a)
+    for (uint32_t b = a; b < N - 1; ++b, ++p) {
+      const uint32_t kmax = b < M - 1 ? b : M - 1;
+      double bx = sv[a][0], by = sv[a][1], bz = sv[a][2];
+      for (uint32_t k = a + 1; k <= kmax; ++k) {
+        bx += sv[k][0];
+        by += sv[k][1];
+        bz += sv[k][2];
+      }
+      if (b >= M) {  // IR.cpp:137-144: only frame b itself
+        const mvo_hip_frame& f = h->h_frames[(size_t)w * N + b];
+        bx += f.scale * f.vec[0];
+        by += f.scale * f.vec[1];
+        bz += f.scale * f.vec[2];
+      }
+      const double nb = std::sqrt(bx * bx + by * by + bz * bz);
+      out[4 * p + 0] = bx / nb;
+      out[4 * p + 1] = by / nb;
+      out[4 * p + 2] = bz / nb;
+      out[4 * p + 3] = nb;
+    }
 }
 
 // rays_on_device: obs[w].m0 / m1 are not read; the caller fills h->t.m0 / m1 itself with work it queues
@@ -506,6 +548,7 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
   const size_t o_unit = place(sizeof(PairDev) * unit.size());
   const size_t o_tiles = place(sizeof(TileDev) * (tiles.size() + 1));
   const size_t o_wave = place(sizeof(uint32_t) * (wave_tiles.size() + 1));
+  const size_t o_pu0 = place(h->pass_mode ? sizeof(double) * 4 * pairs.size() : 0);
   const size_t o_m0 = rays_in_arena ? place(sizeof(double) * 3 * (n_obs + 1)) : 0;
   const size_t o_m1 = rays_in_arena ? place(sizeof(double) * 3 * (n_obs + 1)) : 0;
   const size_t arena_bytes = off;
@@ -532,13 +575,23 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
   HIP_TRY(h->d_partial.reserve(sizeof(double) * 8 * ((size_t)slot + 1)));
   HIP_TRY(h->d_pair_u.reserve(sizeof(double) * 4 * pairs.size()));
   HIP_TRY(h->d_pairsum.reserve(sizeof(double) * 8 * pairs.size()));
+  {
+    // one ticket per pair for the passes' tails; every completed launch leaves them at zero
+    const size_t cap_before = h->d_pticket.cap;  // (not the pointer: a new block may get the old address)
+    HIP_TRY(h->d_pticket.reserve(sizeof(int32_t) * pairs.size()));
+    if (h->d_pticket.cap != cap_before) h->tickets_clean = false;
+    // a pair without residual blocks has no slot and no tail: its sums are zero from here on
+    bool empty_pair = false;
+    for (const PairDev& pd : pairs) empty_pair |= pd.count == 0;
+    if (empty_pair) HIP_TRY(hipMemsetAsync(h->d_pairsum.p, 0, sizeof(double) * 8 * pairs.size(), h->stream));
+  }
   HIP_TRY(h->d_states.reserve(sizeof(LmState) * W));
   {
     const size_t status_bytes = (sizeof(int32_t) * W + 15) & ~(size_t)15;
     const size_t mirror_bytes = 16 + sizeof(LmResult) * W;
-    const void* ctl_before = h->d_ctl.p;
+    const size_t ctl_cap_before = h->d_ctl.cap;  // (not the pointer: a new block may get the old address)
     HIP_TRY(h->d_ctl.reserve(status_bytes + mirror_bytes));
-    if (h->d_ctl.p != ctl_before) h->done_ready = false;  // fresh memory: the counter is garbage
+    if (h->d_ctl.cap != ctl_cap_before) h->done_ready = false;  // fresh memory: the counter is garbage
     char* base = h->d_ctl.as<char>();
     if (reinterpret_cast<int32_t*>(base + status_bytes) != h->d_done) h->done_ready = false;  // W changed: it moved
     h->d_status = reinterpret_cast<int32_t*>(base);
@@ -564,6 +617,9 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
   std::memcpy(ha + o_unit, unit.data(), sizeof(PairDev) * unit.size());
   if (!tiles.empty()) std::memcpy(ha + o_tiles, tiles.data(), sizeof(TileDev) * tiles.size());
   std::memcpy(ha + o_wave, wave_tiles.data(), sizeof(uint32_t) * wave_tiles.size());
+  h->t.pair_u0 = reinterpret_cast<double*>(da + o_pu0);
+  if (h->pass_mode)
+    for (uint32_t w = 0; w < W; ++w) host_pair_u0(h, w, reinterpret_cast<double*>(ha + o_pu0) + 4 * (size_t)w * P);
   h->t.frames = reinterpret_cast<double*>(da + o_frames);
   h->t.initx = reinterpret_cast<double*>(da + o_initx);
   h->t.wins = reinterpret_cast<WinDev*>(da + o_wins);
@@ -602,37 +658,48 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
 uint32_t pass_blocks(const mvo_hip_context* h) { return (h->n_waves + FOLD_WAVES - 1) / FOLD_WAVES; }
 size_t pass_lds(const mvo_hip_context* h) { return sizeof(double) * 8 * (size_t)h->max_block_tiles; }
 
-// observation pass #0: c = (R0 m0) x (R1 m1); stores c (pass mode) or sums the moments (no loss)
-hipError_t launch_fold(mvo_hip_context* h, bool write_c) {
+// observation pass #0: c = (R0 m0) x (R1 m1); stores c (pass mode) or sums the moments (no loss).
+// fused: the last workgroup leaves the per-pair sums in d_pairsum (k_lm then runs from_pair_sums), and
+// in pass mode the fold is the evaluation pass at the starting point as well (pair_u0).
+hipError_t launch_fold(mvo_hip_context* h, bool write_c, bool fused = false) {
   const uint32_t blocks = pass_blocks(h);
   if (!blocks) return hipSuccess;
-  if (write_c)
-    hipLaunchKernelGGL((k_fold<true, false>), dim3(blocks), dim3(FOLD_THREADS), 0, h->stream,
-                       h->t.tiles, h->t.wave_tiles, h->n_waves,
-                       h->t.frames, h->t.m0, h->t.m1, h->d_c.as<double>(),
-                       (size_t)h->c_elems, h->d_partial.as<double>());
+  int32_t* ticket = fused ? h->d_pticket.as<int32_t>() : nullptr;
+  double* pairsum = h->d_pairsum.as<double>();
+#define MVO_FOLD_ARGS(cbuf, celems) \
+  h->t.tiles, h->t.wave_tiles, h->n_waves, h->t.frames, h->t.m0, h->t.m1, cbuf, celems, h->d_partial.as<double>(), \
+      h->t.pair_u0, ticket, h->t.pairs, pairsum
+  if (write_c && fused && h->opt.use_loss_function)
+    hipLaunchKernelGGL((k_fold<true, false, 2>), dim3(blocks), dim3(FOLD_THREADS), pass_lds(h), h->stream,
+                       MVO_FOLD_ARGS(h->d_c.as<double>(), (size_t)h->c_elems));
+  else if (write_c && fused)
+    hipLaunchKernelGGL((k_fold<true, false, 1>), dim3(blocks), dim3(FOLD_THREADS), pass_lds(h), h->stream,
+                       MVO_FOLD_ARGS(h->d_c.as<double>(), (size_t)h->c_elems));
+  else if (write_c)
+    hipLaunchKernelGGL((k_fold<true, false, 0>), dim3(blocks), dim3(FOLD_THREADS), 0, h->stream,
+                       MVO_FOLD_ARGS(h->d_c.as<double>(), (size_t)h->c_elems));
   else
-    hipLaunchKernelGGL((k_fold<false, true>), dim3(blocks), dim3(FOLD_THREADS), pass_lds(h), h->stream,
-                       h->t.tiles, h->t.wave_tiles, h->n_waves,
-                       h->t.frames, h->t.m0, h->t.m1, (double*)nullptr,
-                       (size_t)0, h->d_partial.as<double>());
+    hipLaunchKernelGGL((k_fold<false, true, 0>), dim3(blocks), dim3(FOLD_THREADS), pass_lds(h), h->stream,
+                       MVO_FOLD_ARGS((double*)nullptr, (size_t)0));
+#undef MVO_FOLD_ARGS
   return hipGetLastError();
 }
 
 // one evaluation pass over the folded c at the unit baselines in d_pair_u
-hipError_t launch_pass(mvo_hip_context* h) {
+hipError_t launch_pass(mvo_hip_context* h, bool fused = false) {
   const uint32_t blocks = pass_blocks(h);
   if (!blocks) return hipSuccess;
+  int32_t* ticket = fused ? h->d_pticket.as<int32_t>() : nullptr;
   if (h->opt.use_loss_function)
     hipLaunchKernelGGL((k_pass<true>), dim3(blocks), dim3(FOLD_THREADS), pass_lds(h), h->stream,
                        h->t.tiles, h->t.wave_tiles, h->n_waves, h->d_c.as<double>(),
                        (size_t)h->c_elems, h->d_pair_u.as<double>(), h->d_status,
-                       h->d_partial.as<double>());
+                       h->d_partial.as<double>(), ticket, h->t.pairs, h->d_pairsum.as<double>());
   else
     hipLaunchKernelGGL((k_pass<false>), dim3(blocks), dim3(FOLD_THREADS), pass_lds(h), h->stream,
                        h->t.tiles, h->t.wave_tiles, h->n_waves, h->d_c.as<double>(),
                        (size_t)h->c_elems, h->d_pair_u.as<double>(), h->d_status,
-                       h->d_partial.as<double>());
+                       h->d_partial.as<double>(), ticket, h->t.pairs, h->d_pairsum.as<double>());
   return hipGetLastError();
 }
 
@@ -654,9 +721,10 @@ hipError_t launch_lm(mvo_hip_context* h, const SolveParams& prm, bool from_pair_
 hipError_t launch_fold_range(mvo_hip_context* h, uint32_t b0, uint32_t b1) {
   const uint32_t w0 = b0 * FOLD_WAVES, w1 = std::min<uint32_t>(h->n_waves, b1 * FOLD_WAVES);
   if (w1 <= w0) return hipSuccess;
-  hipLaunchKernelGGL((k_fold<false, true>), dim3(b1 - b0), dim3(FOLD_THREADS), pass_lds(h), h->stream, h->t.tiles,
+  hipLaunchKernelGGL((k_fold<false, true, 0>), dim3(b1 - b0), dim3(FOLD_THREADS), pass_lds(h), h->stream, h->t.tiles,
                      h->t.wave_tiles + w0, w1 - w0, h->t.frames, h->t.m0, h->t.m1, (double*)nullptr, (size_t)0,
-                     h->d_partial.as<double>());
+                     h->d_partial.as<double>(), (const double*)nullptr, (int32_t*)nullptr, (const PairDev*)nullptr,
+                     (double*)nullptr);
   return hipGetLastError();
 }
 
@@ -847,6 +915,11 @@ int do_solve(mvo_hip_context* h) {
   if (!h->done_ready) {
     HIP_TRY(hipMemsetAsync(h->d_status, 0, (size_t)((char*)h->d_done - (char*)h->d_status) + 16, s));
     h->done_base = 0;
+    h->tickets_clean = false;  // an abandoned solve may have left a pass half counted
+  }
+  if (!h->tickets_clean) {
+    HIP_TRY(hipMemsetAsync(h->d_pticket.p, 0, h->d_pticket.cap, s));  // the whole block: later uploads may use more of it
+    h->tickets_clean = true;
   }
   h->done_ready = false;  // until this solve has been seen to complete
   h->solved = false;
@@ -902,29 +975,34 @@ int do_solve(mvo_hip_context* h) {
         HIP_TRY(hipStreamWaitEvent(s, h->ev_chunk[kMaxOverlapChunks + q], 0));
       }
   } else if (!h->pass_mode) {
-    // one fold+moment pass, then the whole LM loop in a single launch
+    // one fold+moment pass, then the whole LM loop in a single launch.  S_p never changes without a
+    // loss: the fold's last workgroup adds the slots up per pair, every k_lm lane loads the sums of its
+    // (up to four) pairs once and keeps them in registers.
     if (fold_blocks) {
       HIP_TRY(timed_begin());
-      HIP_TRY(launch_fold(h, false));
+      HIP_TRY(launch_fold(h, false, true));
       HIP_TRY(timed_end());
       ++asm_launches;
     }
-    // S_p never changes without a loss: every k_lm lane owns its (up to four) pairs for the whole
-    // launch, sums their slots once itself and keeps the sums in registers.
-    HIP_TRY(launch_lm_any(h, prm, false));
+    HIP_TRY(launch_lm_any(h, prm, fold_blocks != 0));
     ++lm_launches;
   } else {
-    if (fold_blocks) {
+    // robust / pass mode: max_it + 1 evaluations (x0 and one candidate per iteration), each one pass over
+    // c and one k_lm launch that reads the pass's per-pair sums.  The fold is the pass at x0.
+    SolveParams pp = prm;
+    const bool fused = fold_blocks != 0;
+    if (fused) {
       HIP_TRY(timed_begin());
-      HIP_TRY(launch_fold(h, true));
+      HIP_TRY(launch_fold(h, true, true));
       HIP_TRY(timed_end());
       ++asm_launches;
+      pp.x0_ready = 1;
     }
-    HIP_TRY(launch_lm_any(h, prm));  // PH_START: publishes u(x0)
+    HIP_TRY(launch_lm_any(h, pp, fused));  // fused: evaluates x0 and takes the first step; else publishes u(x0)
     ++lm_launches;
-    // at most max_it + 1 evaluations (x0 and one candidate per iteration); enqueue them in
-    // chunks without any host round-trip inside a chunk, and look at the done counter between
-    const int total_evals = h->opt.max_num_iterations + 1;
+    // enqueue the evaluations in chunks without any host round-trip inside a chunk, and look at the done
+    // counter between
+    const int total_evals = h->opt.max_num_iterations + (fused ? 0 : 1);
     const int chunk = 12;
     int issued = 0;
     while (issued < total_evals) {
@@ -932,11 +1010,11 @@ int do_solve(mvo_hip_context* h) {
       for (int i = 0; i < n; ++i) {
         if (fold_blocks) {
           HIP_TRY(timed_begin());
-          HIP_TRY(launch_pass(h));
+          HIP_TRY(launch_pass(h, true));
           HIP_TRY(timed_end());
           ++asm_launches;
         }
-        HIP_TRY(launch_lm_any(h, prm));
+        HIP_TRY(launch_lm_any(h, pp, fused));
         ++lm_launches;
       }
       issued += n;
@@ -1080,7 +1158,7 @@ void mvo_hip_destroy(mvo_hip_handle h) {
   if (h->comm) (void)mvo_rccl().CommDestroy(h->comm);
   h->comm = nullptr;
   DevBuf* bufs[] = {&h->d_arena, &h->d_m0, &h->d_m1, &h->d_c, &h->d_partial, &h->d_pair_u, &h->d_states,
-                    &h->d_ctl, &h->d_trace, &h->d_res, &h->d_jac, &h->d_pairsum};
+                    &h->d_ctl, &h->d_trace, &h->d_res, &h->d_jac, &h->d_pairsum, &h->d_pticket};
   for (DevBuf* b : bufs) b->release();
   if (h->h_arena) (void)hipHostFree(h->h_arena);
   if (h->h_ctl) (void)hipHostFree(h->h_ctl);
@@ -1194,6 +1272,14 @@ int mvo_hip_debug_set_point(mvo_hip_handle h, uint32_t window, const double* poi
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipMemcpyAsync(h->t.initx + (size_t)window * MVO_MAXM * 4, point, sizeof(double) * 4 * h->M,
                          hipMemcpyHostToDevice, h->stream));
+  std::memcpy(&h->v_initx[(size_t)window * MVO_MAXM * 4], point, sizeof(double) * 4 * h->M);
+  std::vector<double> u0;
+  if (h->pass_mode) {  // the fused fold evaluates at the starting point: its unit baselines follow
+    u0.resize(4 * (size_t)h->P);
+    host_pair_u0(h, window, u0.data());
+    HIP_TRY(hipMemcpyAsync(h->t.pair_u0 + 4 * (size_t)window * h->P, u0.data(), sizeof(double) * u0.size(),
+                           hipMemcpyHostToDevice, h->stream));
+  }
   HIP_TRY(hipStreamSynchronize(h->stream));  // the caller's array may change once this call returns
   return MVO_HIP_OK;
 }
@@ -1568,6 +1654,9 @@ int mvo_hip_refine_noalloc(int device_ordinal, void* stream, mvo_hip_frame* fram
   prm.inline_eval = 1;  // the window's workgroup runs its own observation passes: one launch
   prm.fresh = 1;        // k_lm starts from a zero state of its own: nothing of the last call is read
   prm.win_base = 0;
+  prm.M = (int32_t)M;
+  prm.N = (int32_t)N;
+  prm.P = (int32_t)P;
 
   const double* fr = reinterpret_cast<const double*>(frames_device);
   hipLaunchKernelGGL(k_noalloc_prep, dim3(1), dim3(256), 0, s, sc, fr, pair_offsets_device, M, N, P, n_blocks,

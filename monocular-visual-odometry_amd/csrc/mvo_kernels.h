@@ -29,7 +29,7 @@
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ void block_store_partials(const TileDev* __restrict__ tiles, uint32_t bt0, uint32_t bt1,
                                                      const double* __restrict__ red,
-                                                     double* __restrict__ partial) {
+                                                     double* __restrict__ partial, bool coherent) {
   __syncthreads();
   const uint32_t nt = bt1 - bt0;
   for (uint32_t item = threadIdx.x; item < nt * 8; item += FOLD_THREADS) {
@@ -38,87 +38,16 @@ __device__ __forceinline__ void block_store_partials(const TileDev* __restrict__
     if (lt == 0 || tiles[bt0 + lt - 1].slot != slot) {  // first tile of its run (runs are <= 4 long)
       double acc = red[lt * 8 + v];
       for (uint32_t q = lt + 1; q < nt && tiles[bt0 + q].slot == slot; ++q) acc += red[q * 8 + v];
-      partial[(size_t)slot * 8 + v] = acc;
+      // coherent (a tail follows): device-coherent store, written through this XCD's L2 -- the workgroup
+      // that adds the slots up (block_finish_pairs) may run on another XCD, and a release fence would
+      // write back every dirty line of the L2, the c planes among them, once per workgroup.  Otherwise
+      // a plain store: the next kernel finds the slots in the L2.
+      if (coherent) __hip_atomic_store(partial + (size_t)slot * 8 + v, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else partial[(size_t)slot * 8 + v] = acc;
     }
   }
 }
 
-// ---------------------------------------------------------------------------------------
-// k_fold: reads m0, m1 (48 B / residual block, caller's interleaved layout), optionally writes
-// c (24 B / block) and/or accumulates S = sum c c^T.
-// ---------------------------------------------------------------------------------------
-template <bool WRITE_C, bool MOMENTS>
-__global__ __launch_bounds__(FOLD_THREADS) void k_fold(const TileDev* __restrict__ tiles,
-                                                       const uint32_t* __restrict__ wave_tiles, uint32_t n_waves,
-                                                       const double* __restrict__ frames,
-                                                       const double* __restrict__ m0,
-                                                       const double* __restrict__ m1,
-                                                       double* __restrict__ cbuf, size_t cstride,
-                                                       double* __restrict__ partial) {
-  extern __shared__ double red[];  // [tiles of this workgroup][8]
-  const int lane = threadIdx.x & 63;
-  const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const uint32_t bw0 = blockIdx.x * FOLD_WAVES;
-  const uint32_t bw1 = bw0 + FOLD_WAVES < n_waves ? bw0 + FOLD_WAVES : n_waves;
-  const uint32_t bt0 = wave_tiles[bw0], bt1 = wave_tiles[bw1];
-  const uint32_t gw = bw0 + wv;
-  if (gw < n_waves) {
-    const uint32_t t0 = wave_tiles[gw], t1 = wave_tiles[gw + 1];
-    for (uint32_t t = t0; t < t1; ++t) {
-      const TileDev tl = tiles[t];
-      const double* __restrict__ R0 = frames + (size_t)MVO_FRAME_DOUBLES * tl.f0;
-      const double* __restrict__ R1 = frames + (size_t)MVO_FRAME_DOUBLES * tl.f1;
-      const double a0 = R0[0], a1 = R0[1], a2 = R0[2], a3 = R0[3], a4 = R0[4], a5 = R0[5], a6 = R0[6],
-                   a7 = R0[7], a8 = R0[8];
-      const double b0 = R1[0], b1 = R1[1], b2 = R1[2], b3 = R1[3], b4 = R1[4], b5 = R1[5], b6 = R1[6],
-                   b7 = R1[7], b8 = R1[8];
-      const double* __restrict__ p0 = m0 + 3 * (size_t)tl.src_start;
-      const double* __restrict__ p1 = m1 + 3 * (size_t)tl.src_start;
-      double* __restrict__ cx = cbuf + tl.c_start;
-      double* __restrict__ cy = cx + cstride;
-      double* __restrict__ cz = cy + cstride;
-      double S[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll 4
-      for (uint32_t i = lane; i < tl.count; i += 64) {
-        const double x0 = p0[3 * i], y0 = p0[3 * i + 1], z0 = p0[3 * i + 2];
-        const double x1 = p1[3 * i], y1 = p1[3 * i + 1], z1 = p1[3 * i + 2];
-        const double px = a0 * x0 + a1 * y0 + a2 * z0;  // R0 * m0
-        const double py = a3 * x0 + a4 * y0 + a5 * z0;
-        const double pz = a6 * x0 + a7 * y0 + a8 * z0;
-        const double qx = b0 * x1 + b1 * y1 + b2 * z1;  // R1 * m1
-        const double qy = b3 * x1 + b4 * y1 + b5 * z1;
-        const double qz = b6 * x1 + b7 * y1 + b8 * z1;
-        const double vx = py * qz - pz * qy;  // c = p x q
-        const double vy = pz * qx - px * qz;
-        const double vz = px * qy - py * qx;
-        if (WRITE_C) {
-          cx[i] = vx;
-          cy[i] = vy;
-          cz[i] = vz;
-        }
-        if (MOMENTS) {
-          S[0] += vx * vx;
-          S[1] += vx * vy;
-          S[2] += vx * vz;
-          S[3] += vy * vy;
-          S[4] += vy * vz;
-          S[5] += vz * vz;
-        }
-      }
-      if (MOMENTS) {
-        const double tot = wave_reduce8(S, lane);
-        if ((lane & 7) == 0) red[(t - bt0) * 8 + reduce8_value_of_lane(lane)] = tot;
-      }
-    }
-  }
-  if (MOMENTS) block_store_partials(tiles, bt0, bt1, red, partial);
-}
-
-// ---------------------------------------------------------------------------------------
-// k_pass: one evaluation of all residual blocks at the unit baselines in pair_u.
-// reads c (24 B / block) as 16-byte loads from three SoA planes.
-// partial[slot] = { S (6, weighted), sum rho(r^2) or sum r^2, sum w r^2 }
-// ---------------------------------------------------------------------------------------
 // One residual block of the evaluation pass.  ROBUST = ceres::CauchyLoss(0.5): b = 0.25, c = 4,
 // rho(s) = b log(1 + c s), rho'(s) = 1 / (1 + c s); rho'' < 0 always, so Ceres' Corrector scales
 // residual and Jacobian row by sqrt(rho') -- i.e. the moments are weighted by w = rho'.
@@ -148,13 +77,160 @@ __device__ __forceinline__ void pass_accum(double cx, double cy, double cz, doub
   S[5] = fma(wz, cz, S[5]);
 }
 
+// The workgroup that stores the LAST slot of a frame pair adds that pair's slots up (what k_reduce_slots
+// does as a launch of its own): k_lm then reads 8 sums per pair instead of walking slot lists, a chain
+// of dependent L2 round trips per slot.  "Last" is decided by one ticket counter per pair -- the only
+// global atomics of the pass, on counters, not on data: the slots are added in slot order whoever does
+// it, bit for bit what k_reduce_slots gives.  No workgroup waits for another one.
+// pair_ticket == nullptr: no tail (launches over a range of the workgroups, partitioned mode).
+// `red` (the workgroup's reduction buffer, free after block_store_partials) holds the to-do list.
+__device__ __forceinline__ void block_finish_pairs(int32_t* pair_ticket, const TileDev* __restrict__ tiles, uint32_t bt0,
+                                                   uint32_t bt1, const PairDev* __restrict__ pairs, double* red,
+                                                   const double* partial, double* __restrict__ pair_sums) {
+  if (pair_ticket == nullptr) return;
+  __shared__ uint32_t n_todo;
+  // the slot stores above are device-coherent; they have completed (vmcnt = 0) before a ticket is taken
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (threadIdx.x == 0) n_todo = 0;
+  __syncthreads();
+  uint32_t* todo = reinterpret_cast<uint32_t*>(red);
+  const uint32_t nt = bt1 - bt0;
+  for (uint32_t lt = threadIdx.x; lt < nt; lt += FOLD_THREADS) {
+    const uint32_t slot = tiles[bt0 + lt].slot;
+    if (lt == 0 || tiles[bt0 + lt - 1].slot != slot) {  // one ticket per slot this workgroup stored
+      const uint32_t p = tiles[bt0 + lt].pair;
+      const PairDev pd = pairs[p];
+      const int32_t t = __hip_atomic_fetch_add(pair_ticket + p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t == (int32_t)(pd.slot_end - pd.slot_begin) - 1) {
+        __hip_atomic_store(pair_ticket + p, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
+        todo[atomicAdd(&n_todo, 1u)] = p;
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t nq = n_todo;
+  for (uint32_t item = threadIdx.x; item < nq * 8; item += FOLD_THREADS) {
+    const uint32_t p = todo[item >> 3], v = item & 7;
+    const PairDev pd = pairs[p];
+    double acc = 0.0;
+    for (uint32_t sl = pd.slot_begin; sl < pd.slot_end; ++sl)
+      acc += __hip_atomic_load(partial + (size_t)sl * 8 + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    pair_sums[(size_t)p * 8 + v] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_fold: reads m0, m1 (48 B / residual block, caller's interleaved layout), optionally writes
+// c (24 B / block) and/or accumulates S = sum c c^T.
+// ---------------------------------------------------------------------------------------
+// PASS0 (robust path): besides storing c, the fold is also the evaluation pass at the starting point --
+// u(x0) per pair is known before it starts (pair_u0, computed by the host at upload), c is in registers:
+// one of the max_it + 1 passes over c saved.  1: w = 1, 2: Cauchy(0.5); sums as in k_pass.
+template <bool WRITE_C, bool MOMENTS, int PASS0 = 0>
+__global__ __launch_bounds__(FOLD_THREADS) void k_fold(const TileDev* __restrict__ tiles,
+                                                       const uint32_t* __restrict__ wave_tiles, uint32_t n_waves,
+                                                       const double* __restrict__ frames,
+                                                       const double* __restrict__ m0,
+                                                       const double* __restrict__ m1,
+                                                       double* __restrict__ cbuf, size_t cstride,
+                                                       double* partial, const double* __restrict__ pair_u0,
+                                                       int32_t* pair_ticket, const PairDev* __restrict__ pairs,
+                                                       double* __restrict__ pair_sums) {
+  static_assert(!(MOMENTS && PASS0), "either the plain moments or the pass sums");
+  extern __shared__ double red[];  // [tiles of this workgroup][8]
+  const int lane = threadIdx.x & 63;
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t bw0 = blockIdx.x * FOLD_WAVES;
+  const uint32_t bw1 = bw0 + FOLD_WAVES < n_waves ? bw0 + FOLD_WAVES : n_waves;
+  const uint32_t bt0 = wave_tiles[bw0], bt1 = wave_tiles[bw1];
+  const uint32_t gw = bw0 + wv;
+  if (gw < n_waves) {
+    const uint32_t t0 = wave_tiles[gw], t1 = wave_tiles[gw + 1];
+    for (uint32_t t = t0; t < t1; ++t) {
+      const TileDev tl = tiles[t];
+      const double* __restrict__ R0 = frames + (size_t)MVO_FRAME_DOUBLES * tl.f0;
+      const double* __restrict__ R1 = frames + (size_t)MVO_FRAME_DOUBLES * tl.f1;
+      const double a0 = R0[0], a1 = R0[1], a2 = R0[2], a3 = R0[3], a4 = R0[4], a5 = R0[5], a6 = R0[6],
+                   a7 = R0[7], a8 = R0[8];
+      const double b0 = R1[0], b1 = R1[1], b2 = R1[2], b3 = R1[3], b4 = R1[4], b5 = R1[5], b6 = R1[6],
+                   b7 = R1[7], b8 = R1[8];
+      double u0 = 0.0, u1 = 0.0, u2 = 0.0;
+      if (PASS0) {
+        u0 = pair_u0[4 * (size_t)tl.pair];
+        u1 = pair_u0[4 * (size_t)tl.pair + 1];
+        u2 = pair_u0[4 * (size_t)tl.pair + 2];
+      }
+      const double* __restrict__ p0 = m0 + 3 * (size_t)tl.src_start;
+      const double* __restrict__ p1 = m1 + 3 * (size_t)tl.src_start;
+      double* __restrict__ cx = cbuf + tl.c_start;
+      double* __restrict__ cy = cx + cstride;
+      double* __restrict__ cz = cy + cstride;
+      double S[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      double prod = 1.0;     // PASS0 == 2: running product of (1 + 4 r^2) of this lane
+      int32_t prod_exp = 0;  // exponent split off so far
+      for (uint32_t i0 = lane; i0 < tl.count; i0 += 64 * 128) {
+        const uint32_t i1 = (tl.count - i0) > 64 * 128 ? i0 + 64 * 128 : tl.count;
+#pragma unroll 4
+        for (uint32_t i = i0; i < i1; i += 64) {
+          const double x0 = p0[3 * i], y0 = p0[3 * i + 1], z0 = p0[3 * i + 2];
+          const double x1 = p1[3 * i], y1 = p1[3 * i + 1], z1 = p1[3 * i + 2];
+          const double px = a0 * x0 + a1 * y0 + a2 * z0;  // R0 * m0
+          const double py = a3 * x0 + a4 * y0 + a5 * z0;
+          const double pz = a6 * x0 + a7 * y0 + a8 * z0;
+          const double qx = b0 * x1 + b1 * y1 + b2 * z1;  // R1 * m1
+          const double qy = b3 * x1 + b4 * y1 + b5 * z1;
+          const double qz = b6 * x1 + b7 * y1 + b8 * z1;
+          const double vx = py * qz - pz * qy;  // c = p x q
+          const double vy = pz * qx - px * qz;
+          const double vz = px * qy - py * qx;
+          if (WRITE_C) {
+            cx[i] = vx;
+            cy[i] = vy;
+            cz[i] = vz;
+          }
+          if (MOMENTS) {
+            S[0] += vx * vx;
+            S[1] += vx * vy;
+            S[2] += vx * vz;
+            S[3] += vy * vy;
+            S[4] += vy * vz;
+            S[5] += vz * vz;
+          }
+          if (PASS0) pass_accum<PASS0 == 2>(vx, vy, vz, u0, u1, u2, S, prod);
+        }
+        if (PASS0 == 2) {  // <= 128 factors <= 5 since the last split: far from overflow
+          int e;
+          prod = frexp(prod, &e);
+          prod_exp += e;
+        }
+      }
+      if (PASS0 == 2) S[6] = 0.25 * (log(prod) + (double)prod_exp * 0.693147180559945309417232121458);
+      if (MOMENTS || PASS0) {
+        const double tot = wave_reduce8(S, lane);
+        if ((lane & 7) == 0) red[(t - bt0) * 8 + reduce8_value_of_lane(lane)] = tot;
+      }
+    }
+  }
+  if (MOMENTS || PASS0) {
+    block_store_partials(tiles, bt0, bt1, red, partial, pair_ticket != nullptr);
+    block_finish_pairs(pair_ticket, tiles, bt0, bt1, pairs, red, partial, pair_sums);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_pass: one evaluation of all residual blocks at the unit baselines in pair_u.
+// reads c (24 B / block) as 16-byte loads from three SoA planes.
+// partial[slot] = { S (6, weighted), sum rho(r^2) or sum r^2, sum w r^2 }
+// ---------------------------------------------------------------------------------------
 template <bool ROBUST>
 __global__ __launch_bounds__(FOLD_THREADS) void k_pass(const TileDev* __restrict__ tiles,
                                                        const uint32_t* __restrict__ wave_tiles, uint32_t n_waves,
                                                        const double* __restrict__ cbuf, size_t cstride,
                                                        const double* __restrict__ pair_u,
                                                        const int32_t* __restrict__ win_status,
-                                                       double* __restrict__ partial) {
+                                                       double* partial, int32_t* pair_ticket,
+                                                       const PairDev* __restrict__ pairs,
+                                                       double* __restrict__ pair_sums) {
   extern __shared__ double red[];
   const int lane = threadIdx.x & 63;
   const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -201,7 +277,8 @@ __global__ __launch_bounds__(FOLD_THREADS) void k_pass(const TileDev* __restrict
       if ((lane & 7) == 0) red[(t - bt0) * 8 + reduce8_value_of_lane(lane)] = tot;
     }
   }
-  block_store_partials(tiles, bt0, bt1, red, partial);
+  block_store_partials(tiles, bt0, bt1, red, partial, pair_ticket != nullptr);
+  block_finish_pairs(pair_ticket, tiles, bt0, bt1, pairs, red, partial, pair_sums);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -1137,7 +1137,8 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
   bool need_pass = false;
   if (sh.phase == PH_START) {
     r.phase = PH_EVAL_X0;
-    need_pass = prm.pass_mode != 0 && !prm.inline_eval;
+    // x0_ready: the fold was the pass at the starting point (k_fold<.., PASS0>): its sums are there
+    need_pass = prm.pass_mode != 0 && !prm.inline_eval && !prm.x0_ready;
   }
   double* my_sums = pair_sums + (size_t)win.pair_off * 8;
   if (prm.inline_eval && !prm.pass_mode) {  // no loss: the moments are folded once, here

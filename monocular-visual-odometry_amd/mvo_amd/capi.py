@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG_ROOT, "libmvo_hip.so")
+# MVO_HIP_LIB_PATH: development only (A/B runs of two builds of the same library)
+LIB_PATH = os.environ.get("MVO_HIP_LIB_PATH") or os.path.join(_PKG_ROOT, "libmvo_hip.so")
 
 OK = 0
 ERR_INVALID_ARGUMENT = 1
