@@ -797,6 +797,22 @@ __device__ __forceinline__ void pair_load(PairIn& in, int p, int N, int M, bool 
   }
 }
 
+// the same from the inline pass's LDS sums (k_lm<64>): pair p is row p
+__device__ __forceinline__ void pair_load_lds(PairIn& in, int p, int N, int M, const double* lds_sums,
+                                              const double* __restrict__ fr) {
+  pair_ab(N, M, p, in.a, in.b);
+#pragma unroll
+  for (int v = 0; v < 7; ++v) in.S[v] = lds_sums[p * 8 + v];
+  in.off[0] = in.off[1] = in.off[2] = 0.0;
+  if (in.b >= M) {  // IR.cpp:137-144: only frame b itself
+    const double* __restrict__ f = fr + MVO_FRAME_DOUBLES * in.b;
+    const double nb = f[12];
+    in.off[0] = nb * f[9];
+    in.off[1] = nb * f[10];
+    in.off[2] = nb * f[11];
+  }
+}
+
 // s_a v_a + ... + s_kmax v_kmax of the published point, summed left to right (IR.cpp:466-577).  All
 // five frames are loaded up front (independent LDS reads, one wait) instead of one dependent LDS
 // round trip per term.
@@ -857,10 +873,13 @@ __device__ __forceinline__ int sym6(int r, int c) {
 // MODE 0: second moments only (no loss; done once per solve)
 // MODE 1: pass at the published point, w = 1      (assembly_mode = PASSES)
 // MODE 2: pass at the published point, Cauchy(0.5)
-template <int MODE, int NT>
+// LDS_OUT (k_lm<64>): the sums stay in LDS (lds_sums) -- the wavefront that wrote them reads them right
+// back, a store -> load round trip through the L2 per evaluation otherwise.
+template <int MODE, int NT, bool LDS_OUT = false>
 __device__ __forceinline__ void inline_pass(const LmShared& sh, const PairDev* __restrict__ wp, int P, int M,
                                             const double* __restrict__ fr, const double* __restrict__ m0,
-                                            const double* __restrict__ m1, double* pair_sums) {
+                                            const double* __restrict__ m1, double* pair_sums,
+                                            double* lds_sums = nullptr) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   for (int p = wave; p < P; p += NT / 64) {
@@ -908,7 +927,10 @@ __device__ __forceinline__ void inline_pass(const LmShared& sh, const PairDev* _
     }
     if (MODE == 2) S[6] = 0.25 * (log(prod) + (double)prod_exp * 0.693147180559945309417232121458);
     const double tot = wave_reduce8(S, lane);
-    if ((lane & 7) == 0) pair_sums[(size_t)p * 8 + reduce8_value_of_lane(lane)] = tot;
+    if ((lane & 7) == 0) {
+      if (LDS_OUT) lds_sums[p * 8 + reduce8_value_of_lane(lane)] = tot;
+      else pair_sums[(size_t)p * 8 + reduce8_value_of_lane(lane)] = tot;
+    }
   }
 }
 
@@ -1082,6 +1104,7 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
   static_assert(NT == 64 || NT == MVO_LM_NT_LARGE, "one wavefront, or three class wavefronts + one for the short pairs and the LM step");
   __shared__ LmShared sh;
   __shared__ double pairbuf[LARGE ? 1 : 64 * 10];  // k_lm<64>: P x 10: T(6) q(3) cost(1)
+  __shared__ double inl_sums[LARGE ? 1 : 64 * 8];   // k_lm<64>, inline evaluation: the passes' 8 sums per pair
   const int w = (int)blockIdx.x + prm.win_base, tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1142,7 +1165,7 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
   }
   double* my_sums = pair_sums + (size_t)win.pair_off * 8;
   if (prm.inline_eval && !prm.pass_mode) {  // no loss: the moments are folded once, here
-    inline_pass<0, NT>(sh, wp, P, M, fr, m0, m1, my_sums);
+    inline_pass<0, NT, !LARGE>(sh, wp, P, M, fr, m0, m1, my_sums, inl_sums);
     __syncthreads();
   }
 
@@ -1172,15 +1195,16 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
     MVO_STAMP(0);
     // ---------------- evaluation at z: assemble J^T J, J^T r, cost ----------------
     if (prm.inline_eval && prm.pass_mode) {  // one observation pass per evaluation, in this workgroup
-      if (prm.use_loss) inline_pass<2, NT>(sh, wp, P, M, fr, m0, m1, my_sums);
-      else inline_pass<1, NT>(sh, wp, P, M, fr, m0, m1, my_sums);
+      if (prm.use_loss) inline_pass<2, NT, !LARGE>(sh, wp, P, M, fr, m0, m1, my_sums, inl_sums);
+      else inline_pass<1, NT, !LARGE>(sh, wp, P, M, fr, m0, m1, my_sums, inl_sums);
       __syncthreads();  // B0
     }
     // (1) per frame pair: projected moments.  Without a loss the moments never change: the inputs are
     // loaded once and stay in registers.  Loads are unconditional, at a clamped pair index: a load
     // inside a divergent `if` is waited for on the spot, which would serialise the L2 latencies.
     if (!have_in) {
-      pair_load(in0, my_p0, N, M, unit_slots != 0, wp, partial, win.pair_off, fr);
+      if (!LARGE && prm.inline_eval) pair_load_lds(in0, my_p0, N, M, inl_sums, fr);
+      else pair_load(in0, my_p0, N, M, unit_slots != 0, wp, partial, win.pair_off, fr);
       have_in = !prm.pass_mode;
     }
     {
