@@ -81,6 +81,12 @@ typedef struct mvo_hip_options {
 #define MVO_HIP_ASSEMBLY_PASSES 1 /* bit 0 */
 #define MVO_HIP_ASSEMBLY_TILED 2  /* bit 1: always use the chip-wide tiled observation passes; by default
                                      small or many windows are evaluated by their own LM workgroup */
+/* Batches of windows with at most 64 frame pairs, no loss: one window per wavefront (k_lm<64>) or four
+ * (k_lm4, shares the LM step between four windows: 1.35 x the time of one wavefront for 4 x the windows).
+ * By default the library takes whichever needs fewer rounds of the chip's 1024 wavefront slots (four per
+ * wavefront from 1025 windows up); these two bits force one or the other.  Same results to rounding. */
+#define MVO_HIP_ASSEMBLY_ONE_PER_WAVE 4  /* bit 2 */
+#define MVO_HIP_ASSEMBLY_FOUR_PER_WAVE 8 /* bit 3 */
 
 /* What IterativeRefinement.cpp:111-183 gathers from nowFrame: replaces the
  * std::list<std::vector<Eigen::Vector3d>> "features" (IterativeRefinement.cpp:111,147-165). */

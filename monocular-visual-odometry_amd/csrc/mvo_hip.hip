@@ -23,6 +23,7 @@
 
 #include "mvo_kernels.h"
 #include "mvo_lm.h"
+#include "mvo_lm4.h"
 
 static_assert(sizeof(mvo_hip_frame) == MVO_FRAME_DOUBLES * sizeof(double), "frame record layout");
 static_assert(sizeof(TraceRec) == sizeof(mvo_hip_iteration), "trace record layout");
@@ -327,6 +328,8 @@ int ensure_events(mvo_hip_context* h) {
   return MVO_HIP_OK;
 }
 
+bool lm4_eligible(const mvo_hip_context* h);
+
 // Unit baselines of window w's pairs at the starting point (v_initx): what k_lm publishes for a
 // candidate (pair_unit_baseline, IR.cpp:137-144, 254-255, 298-309, 466-577), here on the host so that the
 // fold can be the evaluation pass at x0 as well.  out: 4 doubles per pair (u, |baseline|).
@@ -393,7 +396,11 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
     uint64_t max_win_obs = 0;
     for (uint32_t w = 0; w < W; ++w)
       if (obs[w].pair_offsets[P] > max_win_obs) max_win_obs = obs[w].pair_offsets[P];
-    h->inline_eval = max_win_obs <= kInlineWindowLimit && !(opt->assembly_mode & MVO_HIP_ASSEMBLY_TILED);
+    // ... except for batches that k_lm4 takes four windows per wavefront: one chip-wide fold and a
+    // quarter of the LM wavefronts beat a fold per window inside its own workgroup
+    h->inline_eval = false;
+    const bool four_per_wave = lm4_eligible(h);
+    h->inline_eval = max_win_obs <= kInlineWindowLimit && !(opt->assembly_mode & MVO_HIP_ASSEMBLY_TILED) && !four_per_wave;
   }
   // One chunk of consecutive residual blocks per wavefront, all wavefronts resident at once:
   // waves_per_cu * 256 CUs of them, but at least kMinChunk blocks each so that small problems
@@ -411,7 +418,7 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
     const int t = std::atoi(e);
     if (t >= 2 && t <= kMaxOverlapChunks) overlap_chunks = t;
   }
-  const bool want_overlap = !h->pass_mode && !h->inline_eval && W >= 256 && P <= 256 &&
+  const bool want_overlap = !h->pass_mode && !h->inline_eval && W >= 256 && P <= 256 && !lm4_eligible(h) &&
                             n_obs >= (uint64_t)kMinChunk * 256 * waves_per_cu * overlap_chunks &&
                             !std::getenv("MVO_HIP_NO_OVERLAP");
   const uint64_t max_waves = 256ull * waves_per_cu * (want_overlap ? overlap_chunks : 1);
@@ -740,6 +747,29 @@ hipError_t launch_lm_range(mvo_hip_context* h, SolveParams prm, uint32_t win0, u
   return hipGetLastError();
 }
 
+// batches, no loss, at most 64 pairs per window, no trace: four windows per wavefront (mvo_lm4.h)
+bool lm4_eligible(const mvo_hip_context* h) {
+  if (h->pass_mode || h->inline_eval || h->P > 64 || h->W < 4 || h->trace_cap != 0) return false;
+  if (h->opt.assembly_mode & MVO_HIP_ASSEMBLY_ONE_PER_WAVE) return false;
+  if (h->opt.assembly_mode & MVO_HIP_ASSEMBLY_FOUR_PER_WAVE) return true;
+  // one wavefront per SIMD (512 registers each): 1024 slots.  A k_lm4 wavefront runs ~1.35 x as long as a
+  // k_lm<64> one (config 3: 159 us against 119 us for eleven evaluations) and carries four windows.
+  const double slots = 1024.0;
+  const double rounds1 = std::ceil(h->W / slots), rounds4 = std::ceil(h->W / (4.0 * slots));
+  return rounds1 > 1.35 * rounds4;
+}
+hipError_t launch_lm4_range(mvo_hip_context* h, SolveParams prm, uint32_t win0, uint32_t win1, hipStream_t stream,
+                            bool from_pair_sums) {
+  prm.fresh = 1;
+  prm.win_base = (int32_t)win0;
+  const uint32_t groups = (win1 - win0 + LM4_WINDOWS - 1) / LM4_WINDOWS;
+  hipLaunchKernelGGL(k_lm4, dim3(groups), dim3(64), 0, stream, prm, (int)win1, from_pair_sums ? 1 : 0, h->t.frames,
+                     h->t.initx, from_pair_sums ? h->t.pairs_unit : h->t.pairs,
+                     from_pair_sums ? h->d_pairsum.as<double>() : h->d_partial.as<double>(), h->d_results, h->d_status,
+                     h->d_done);
+  return hipGetLastError();
+}
+
 hipError_t launch_lm_any(mvo_hip_context* h, SolveParams prm, bool from_pair_sums = false) {
   prm.fresh = h->lm_started ? 0 : 1;  // the first launch of a solve starts from a zeroed state
   h->lm_started = true;
@@ -962,7 +992,8 @@ int do_solve(mvo_hip_context* h) {
         used[c & 1] = true;
         HIP_TRY(hipEventRecord(h->ev_chunk[c], s));
         HIP_TRY(hipStreamWaitEvent(q, h->ev_chunk[c], 0));
-        HIP_TRY(h->P <= 64 ? launch_lm_range<64>(h, prm, win0, win1, q) : launch_lm_range<MVO_LM_NT_LARGE>(h, prm, win0, win1, q));
+        if (lm4_eligible(h)) HIP_TRY(launch_lm4_range(h, prm, win0, win1, q, false));
+        else HIP_TRY(h->P <= 64 ? launch_lm_range<64>(h, prm, win0, win1, q) : launch_lm_range<MVO_LM_NT_LARGE>(h, prm, win0, win1, q));
         ++lm_launches;
       }
       b0 = b1;
@@ -984,7 +1015,12 @@ int do_solve(mvo_hip_context* h) {
       HIP_TRY(timed_end());
       ++asm_launches;
     }
-    HIP_TRY(launch_lm_any(h, prm, fold_blocks != 0));
+    if (lm4_eligible(h) && fold_blocks) {
+      HIP_TRY(launch_lm4_range(h, prm, 0, h->W, s, true));
+      h->lm_started = true;
+    } else {
+      HIP_TRY(launch_lm_any(h, prm, fold_blocks != 0));
+    }
     ++lm_launches;
   } else {
     // robust / pass mode: max_it + 1 evaluations (x0 and one candidate per iteration), each one pass over

@@ -160,6 +160,8 @@ __global__ __launch_bounds__(FOLD_THREADS) void k_fold(const TileDev* __restrict
         u1 = pair_u0[4 * (size_t)tl.pair + 1];
         u2 = pair_u0[4 * (size_t)tl.pair + 2];
       }
+      // (two rays per lane through 16-byte loads were tried: 7 % slower than one 8-byte load per component,
+      // profiles/r2b/NOTES.md -- the fold runs at 5.1 TB/s, 81 % of what a plain copy reaches on this chip)
       const double* __restrict__ p0 = m0 + 3 * (size_t)tl.src_start;
       const double* __restrict__ p1 = m1 + 3 * (size_t)tl.src_start;
       double* __restrict__ cx = cbuf + tl.c_start;

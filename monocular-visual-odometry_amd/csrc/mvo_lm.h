@@ -276,7 +276,8 @@ __device__ __forceinline__ void lm_terminate(LmRegs& r, int termination, int rea
 
 // Lanes k < M publish the point to evaluate and everything the evaluation needs per frame:
 // s_k, s'_k and G_k = [s_k J_loc(v_k) | s'_k v_k], J_loc(v) = [[-2vy, 2vz], [2vx, 0], [0, -2vx]].
-__device__ __forceinline__ void lm_publish_point(LmShared& sh, const SolveParams& prm, int M, int lane,
+template <class SH>
+__device__ __forceinline__ void lm_publish_point(SH& sh, const SolveParams& prm, int M, int lane,
                                                  const double v[3], double t) {
   if (lane < M) {
     const int k = lane;
@@ -670,9 +671,8 @@ __device__ __forceinline__ BlockRole block_role(int M, int lane) {
 
 // WHICH: 0 = every block row, 1 = the rows of the diagonal blocks only, 2 = the others only (k_lm<256>
 // gives the two kinds to two wavefronts: each then runs a stream without the other's special cases)
-template <int WHICH>
-__device__ __forceinline__ void lm_block_rows(LmShared& sh, const BlockRole& br, int lane, int hsel) {
-  double* __restrict__ Hw = hsel ? sh.st.H : sh.Hz;
+template <int WHICH, class SH>
+__device__ __forceinline__ void lm_block_rows(SH& sh, const BlockRole& br, int lane, double* __restrict__ Hw) {
   const int k4 = br.k4, l4 = br.l4, i4 = br.i4;
   if (lane < br.nB4 && (WHICH == 0 || (WHICH == 1) == (k4 == l4))) {
     const bool diag = WHICH == 0 ? k4 == l4 : WHICH == 1;
@@ -711,7 +711,8 @@ __device__ __forceinline__ void lm_block_rows(LmShared& sh, const BlockRole& br,
 }
 
 // gradient entry (k, i) = G_k^T y_k, for the lanes `on`
-__device__ __forceinline__ void lm_gradient_entry(LmShared& sh, bool on, int k4, int i4) {
+template <class SH>
+__device__ __forceinline__ void lm_gradient_entry(SH& sh, bool on, int k4, int i4) {
   if (on) {
     const double* __restrict__ dk = sh.D[k4 * MCX + k4 + 1];
     const double* __restrict__ ck = sh.C1[(k4 > 0 ? k4 - 1 : 0) * MCX + k4];
@@ -816,7 +817,8 @@ __device__ __forceinline__ void pair_load_lds(PairIn& in, int p, int N, int M, c
 // s_a v_a + ... + s_kmax v_kmax of the published point, summed left to right (IR.cpp:466-577).  All
 // five frames are loaded up front (independent LDS reads, one wait) instead of one dependent LDS
 // round trip per term.
-__device__ __forceinline__ void free_baseline(const LmShared& sh, int a, int kmax, double (&beta)[3]) {
+template <class SH>
+__device__ __forceinline__ void free_baseline(const SH& sh, int a, int kmax, double (&beta)[3]) {
   double zs[MVO_MAXM], zv[MVO_MAXM][3];
 #pragma unroll
   for (int k = 0; k < MVO_MAXM; ++k) {
@@ -1080,9 +1082,9 @@ __device__ __forceinline__ void lm_class_wave(LmShared& sh, const SolveParams& p
     }
     __syncthreads();  // B1: class totals are in LDS
     __syncthreads();  // B1b: wavefront 0 has formed C1 and D
-    if (cw == 0) lm_block_rows<1>(sh, br, lane, sh.hsel);
+    if (cw == 0) lm_block_rows<1>(sh, br, lane, sh.hsel ? sh.st.H : sh.Hz);
     else if (cw == 1) lm_gradient_and_norm(sh, M, prm.fix_length, lane);
-    else lm_block_rows<2>(sh, br, lane, sh.hsel);
+    else lm_block_rows<2>(sh, br, lane, sh.hsel ? sh.st.H : sh.Hz);
     __syncthreads();  // B1c: the system at z is in LDS
     __syncthreads();  // B2: wavefront 0 has taken its step and published the next point
     if (!sh.go) break;
@@ -1284,7 +1286,7 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
         lm_decide(r, sh, prm, M, lane, (w == 0) ? trace : nullptr, dec MVO_STAMP_ARG);
         __syncthreads();  // B1c: the system at z and its gradient norm are complete
       } else {
-        lm_block_rows<0>(sh, br, lane, hsel);
+        lm_block_rows<0>(sh, br, lane, hsel ? sh.st.H : sh.Hz);
         lm_gradient_entry(sh, lane >= br.nB4 && lane < br.nB4 + 3 * M, br.k4, br.i4);
         wave0_sync();
         lm_decide(r, sh, prm, M, lane, (w == 0) ? trace : nullptr, dec MVO_STAMP_ARG);

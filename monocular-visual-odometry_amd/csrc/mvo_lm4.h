@@ -1,0 +1,530 @@
+// mvo_lm4.h -- k_lm4: the device-resident Levenberg-Marquardt loop for BATCHES of small windows
+// (at most 64 frame pairs each, no loss, sums folded before the launch): FOUR windows per wavefront.
+//
+// Why: in k_lm<64> the LM step (decision, damped 15 x 15 solve, candidate; lm_decide / lm_step) is half
+// of an evaluation's instruction stream and uses 15 of the 64 lanes.  A wavefront issues one instruction
+// per ~4.4 cycles whatever the lane count, so four windows side by side -- window q in the 16-lane DPP
+// row q -- take the step for the price of one.  The evaluation itself (per-pair moments, class sums,
+// 3 x 3 blocks: already 35..60 lanes wide) runs window after window with the code of k_lm<64>.
+//
+// The step is the same restatement of Ceres 1.14's TrustRegionMinimizer as lm_decide / lm_step
+// (mvo_lm.h), written without branches: what is wave-uniform there is row-uniform here, every `if` is a
+// select under the row's condition.  Same arithmetic, operation for operation: a window solved here and
+// a window solved by k_lm<64> take the same decisions and agree to rounding (tests/test_gpu_lm4.py).
+//
+// One launch runs its windows to termination (no re-entry, no state in HBM).  Replaces ceres::Solve,
+// IterativeRefinement.cpp:231-233, for mvo_hip_refine_batch.
+#pragma once
+
+#include "mvo_lm.h"
+
+constexpr int LM4_WINDOWS = 4;
+
+struct Lm4Win {  // one window, kept across evaluations
+  double zvec[MVO_MAXM][3], zt[MVO_MAXM], zs[MVO_MAXM], zsp[MVO_MAXM];
+  double G[MVO_MAXM][9];
+  double H[2][MVO_MAXC * MVO_MAXC];  // the accepted system and the one assembled at z (roles swap: hsel)
+  double gz[MVO_MAXC];
+  double cost;
+};
+
+struct Lm4Shared {
+  Lm4Win win[LM4_WINDOWS];
+  // scratch of ONE evaluation (the windows are evaluated one after the other)
+  double kk[MVO_MAXM][10], C1[MVO_MAXM * MCX][10], D[MVO_MAXM * MCX][10];
+  double pairbuf[64 * 10];
+};
+
+// what the evaluation helpers of mvo_lm.h expect of "sh", for window q
+struct Lm4View {
+  double (*zvec)[3];
+  double *zt, *zs, *zsp;
+  double (*G)[9];
+  double (*kk)[10];
+  double (*C1)[10];
+  double (*D)[10];
+  double* gz;
+};
+
+__device__ __forceinline__ Lm4View lm4_view(Lm4Shared& sh, int q) {
+  Lm4View v;
+  Lm4Win& w = sh.win[q];
+  v.zvec = w.zvec; v.zt = w.zt; v.zs = w.zs; v.zsp = w.zsp; v.G = w.G;
+  v.kk = sh.kk; v.C1 = sh.C1; v.D = sh.D; v.gz = w.gz;
+  return v;
+}
+
+// totals over each 16-lane row, left in every lane of the row
+__device__ __forceinline__ double row_sum_all(double v) {
+  v += dpp_f64<0xB1>(v);
+  v += dpp_f64<0x4E>(v);
+  v += dpp_f64<0x141>(v);
+  v += dpp_f64<0x140>(v);
+  return v;
+}
+__device__ __forceinline__ double row_max_all(double v) {
+  v = fmax(v, dpp_f64<0xB1>(v));
+  v = fmax(v, dpp_f64<0x4E>(v));
+  v = fmax(v, dpp_f64<0x141>(v));
+  v = fmax(v, dpp_f64<0x140>(v));
+  return v;
+}
+__device__ __forceinline__ bool row_any(bool b) { return row_max_all(b ? 1.0 : 0.0) > 0.0; }
+
+__device__ __forceinline__ double sel(bool c, double a, double b) { return c ? a : b; }
+__device__ __forceinline__ int sel(bool c, int a, int b) { return c ? a : b; }
+
+// frames_plus / frames_diff_* of mvo_lm.h per row: l = lane & 15 is the frame / the compact column
+__device__ __forceinline__ void frames_plus4(int lane, int M, int fix, const double xv[3], double xt,
+                                             double delta_lane, double sign, double ov[3], double& ot) {
+  const int l = lane & 15, base = lane & 48;
+  const int k = l < M ? l : 0;
+  const double da = __shfl(delta_lane, base + ccol(k, 0, fix), 64);
+  const double db = __shfl(delta_lane, base + ccol(k, 1, fix), 64);
+  const double dt = __shfl(delta_lane, base + (fix ? 0 : ccol(k, 2, fix)), 64);
+  d_plus(xv, sign * da, sign * db, ov);
+  ot = fix ? xt : xt + sign * dt;
+}
+__device__ __forceinline__ double frames_diff_sq4(int lane, int M, int fix, const double av[3], double at,
+                                                  const double bv[3], double bt) {
+  const double d0 = av[0] - bv[0], d1 = av[1] - bv[1], d2 = av[2] - bv[2], d3 = fix ? 0.0 : at - bt;
+  const double acc = ((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3;
+  return row_sum_all((lane & 15) < M ? acc : 0.0);
+}
+__device__ __forceinline__ double frames_diff_max4(int lane, int M, int fix, const double av[3], double at,
+                                                   const double bv[3], double bt) {
+  const double d3 = fix ? 0.0 : fabs(at - bt);
+  const double acc = fmax(fmax(fabs(av[0] - bv[0]), fabs(av[1] - bv[1])), fmax(fabs(av[2] - bv[2]), d3));
+  return row_max_all((lane & 15) < M ? acc : 0.0);
+}
+
+// gj_eliminate of mvo_lm.h with the pivot kept per row (row_bcast instead of v_readlane)
+template <int J>
+__device__ __forceinline__ void gj_eliminate4(double (&a)[MVO_MAXC], double& rhs, double& myrinv, unsigned& phimax,
+                                              int l, double ddl, double piv, double rinv) {
+  if constexpr (J < MVO_MAXC) {
+    const unsigned hi = (unsigned)__double2hiint(piv);
+    phimax = hi > phimax ? hi : phimax;
+    int l_here = l;
+    asm volatile("" : "+v"(l_here));
+    const bool me = l_here == J;
+    const double f = me ? 0.0 : a[J] * rinv;
+    myrinv = me ? rinv : myrinv;
+    double piv_next = 1.0, rinv_next = 1.0;
+    if constexpr (J + 1 < MVO_MAXC) {
+      a[J + 1] -= f * row_bcast<J>(a[J + 1]);
+      piv_next = row_bcast<J + 1>(a[J + 1] + ddl);
+      rinv_next = fast_rcp(piv_next);
+      gj_row_update<J, J + 2>(a, f);
+    }
+    rhs -= f * row_bcast<J>(rhs);
+    gj_eliminate4<J + 1>(a, rhs, myrinv, phimax, l, ddl, piv_next, rinv_next);
+  }
+}
+
+// Solver state of the lane's row (window): as LmRegs, every scalar row-uniform.
+struct Lm4Regs {
+  double g, js, dg, hdiag;
+  double xv[3], xt, cv[3], ct, bv[3], bt;
+  double x_cost, x_norm, min_cost, mcc, radius, decf, gmn, initial_cost, final_cost;
+  double se_min, se_cur, se_ref, se_cand, se_acc_ref, se_acc_cand;
+  int32_t se_nonmono, reuse_diag, iteration, num_invalid, nsucc, nunsucc, status, termination, reason, phase, ntrace,
+      hsel;
+};
+
+__device__ __forceinline__ void lm4_terminate(Lm4Regs& r, bool c, int termination, int reason) {
+  r.status = sel(c, 1, r.status);
+  r.termination = sel(c, termination, r.termination);
+  r.reason = sel(c, reason, r.reason);
+}
+
+// One LM step for the four rows.  act: the row's window was just evaluated at its published point.
+// Returns (per lane, row-uniform) whether the row published a new candidate.
+__device__ __forceinline__ bool lm4_advance(Lm4Regs& r, Lm4Shared& sh, const SolveParams& prm, int M, int n, int lane,
+                                            bool act) {
+  const int fix = prm.fix_length;
+  const int row = lane >> 4, l = lane & 15;
+  Lm4Win& win = sh.win[row];
+  // ---------------- lm_decide ----------------
+  double it_cost = 0.0, it_gmn = 0.0;
+  bool it_succ = false;
+  const bool first = r.phase == PH_EVAL_X0;
+  const double cost_raw = win.cost;
+  const double cost_z = (first || isfinite(cost_raw)) ? cost_raw : DBL_MAX;
+  const bool bad0 = act && first && !isfinite(cost_z);
+  const bool init0 = act && first && !bad0;
+  const bool cand = act && !first;
+  {
+    // the initial point failed to evaluate
+    r.iteration = sel(bad0, 0, r.iteration);
+    r.ntrace = sel(bad0, 1, r.ntrace);
+    r.nsucc = sel(bad0 || init0, 0, r.nsucc);
+    r.nunsucc = sel(bad0 || init0, 0, r.nunsucc);
+    r.initial_cost = sel(bad0, cost_z, r.initial_cost);
+    r.final_cost = sel(bad0, cost_z, r.final_cost);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) r.bv[j] = sel(bad0, r.xv[j], r.bv[j]);
+    r.bt = sel(bad0, r.xt, r.bt);
+    lm4_terminate(r, bad0, 2, 8);
+    // IterationZero
+    r.iteration = sel(init0, 0, r.iteration);
+    r.min_cost = sel(init0, DBL_MAX, r.min_cost);
+    r.radius = sel(init0, 1e4, r.radius);
+    r.decf = sel(init0, 2.0, r.decf);
+    r.reuse_diag = sel(init0, 0, r.reuse_diag);
+    r.num_invalid = sel(init0, 0, r.num_invalid);
+    r.ntrace = sel(init0, 0, r.ntrace);
+    r.mcc = sel(init0, 0.0, r.mcc);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) r.cv[j] = sel(init0, r.xv[j], r.cv[j]);
+    r.ct = sel(init0, r.xt, r.ct);
+  }
+  // ParameterToleranceReached / FunctionToleranceReached
+  const double sn2 = frames_diff_sq4(lane, M, fix, r.xv, r.xt, r.cv, r.ct);
+  const double step_norm = prm.ptol > 0.0 ? sqrt(sn2) : 0.0;
+  const bool ptol_hit = cand && (prm.ptol > 0.0 ? step_norm <= prm.ptol * (r.x_norm + prm.ptol) : sn2 <= 0.0);
+  const double cost_change = r.x_cost - cost_z;
+  const bool ftol_hit = cand && !ptol_hit && fabs(cost_change) <= prm.ftol * r.x_cost;
+  lm4_terminate(r, ptol_hit, 0, 3);
+  lm4_terminate(r, ftol_hit, 0, 4);
+  const bool judged = cand && !ptol_hit && !ftol_hit;
+  // TrustRegionStepEvaluator::StepQuality
+  const double rel = (r.se_cur - cost_z) * fast_rcp(r.mcc);
+  const double hist = (r.se_ref - cost_z) * fast_rcp(r.se_acc_ref + r.mcc);
+  const double it_rel = fmax(rel, hist);
+  const bool accept = judged && it_rel > 1e-3;  // min_relative_decrease
+  const bool reject = judged && !accept;
+  {
+    // LevenbergMarquardtStrategy::StepAccepted
+    const double q = 2.0 * it_rel - 1.0;
+    const double rad_acc = fmin(1e16, r.radius * fast_rcp(fmax(1.0 / 3.0, 1.0 - q * q * q)));
+    const double rad_rej = r.radius * fast_rcp(r.decf);  // a power of two: exact
+    r.radius = sel(accept, rad_acc, sel(reject, rad_rej, r.radius));
+    r.decf = sel(accept, 2.0, sel(reject, r.decf * 2.0, r.decf));
+    r.reuse_diag = sel(accept, 0, sel(reject, 1, r.reuse_diag));
+    // TrustRegionStepEvaluator::StepAccepted
+    const double se_cur = cost_z;
+    double se_acc_cand = r.se_acc_cand + r.mcc, se_acc_ref = r.se_acc_ref + r.mcc;
+    double se_min = r.se_min, se_cand = r.se_cand, se_ref = r.se_ref;
+    int se_nonmono = r.se_nonmono;
+    const bool lower = se_cur < se_min;
+    const bool above = !lower && se_cur > se_cand;
+    se_min = sel(lower, se_cur, se_min);
+    se_nonmono = sel(lower, 0, se_nonmono + 1);
+    se_cand = sel(lower || above, se_cur, se_cand);
+    se_acc_cand = sel(lower || above, 0.0, se_acc_cand);
+    const bool reset_ref = se_nonmono == 5;  // max_consecutive_nonmonotonic_steps
+    se_ref = sel(reset_ref, se_cand, se_ref);
+    se_acc_ref = sel(reset_ref, se_acc_cand, se_acc_ref);
+    r.se_cur = sel(accept, se_cur, r.se_cur);
+    r.se_acc_cand = sel(accept, se_acc_cand, r.se_acc_cand);
+    r.se_acc_ref = sel(accept, se_acc_ref, r.se_acc_ref);
+    r.se_min = sel(accept, se_min, r.se_min);
+    r.se_cand = sel(accept, se_cand, r.se_cand);
+    r.se_ref = sel(accept, se_ref, r.se_ref);
+    r.se_nonmono = sel(accept, se_nonmono, r.se_nonmono);
+    // HandleUnsuccessfulStep + StepRejected
+    it_cost = sel(reject, cost_z, it_cost);
+    it_gmn = sel(reject, r.gmn, it_gmn);
+  }
+  const bool take_z = init0 || accept;
+  it_succ = take_z;
+  {
+    // x <- z
+#pragma unroll
+    for (int j = 0; j < 3; ++j) r.xv[j] = sel(take_z, r.cv[j], r.xv[j]);
+    r.xt = sel(take_z, r.ct, r.xt);
+    r.x_cost = sel(take_z, cost_z, r.x_cost);
+    if (prm.ptol > 0.0) {  // ||x|| is only ever read by the parameter-tolerance test
+      const double zero3[3] = {0.0, 0.0, 0.0};
+      const double xn = sqrt(frames_diff_sq4(lane, M, fix, r.xv, r.xt, zero3, 0.0));
+      r.x_norm = sel(take_z, xn, r.x_norm);
+    }
+    r.initial_cost = sel(init0, r.x_cost, r.initial_cost);
+    r.final_cost = sel(init0, r.x_cost, r.final_cost);
+    r.se_min = sel(init0, r.x_cost, r.se_min);
+    r.se_cur = sel(init0, r.x_cost, r.se_cur);
+    r.se_ref = sel(init0, r.x_cost, r.se_ref);
+    r.se_cand = sel(init0, r.x_cost, r.se_cand);
+    r.se_acc_ref = sel(init0, 0.0, r.se_acc_ref);
+    r.se_acc_cand = sel(init0, 0.0, r.se_acc_cand);
+    r.se_nonmono = sel(init0, 0, r.se_nonmono);
+    it_cost = sel(take_z, r.x_cost, it_cost);
+  }
+  // ---------------- lm_step ----------------
+  {
+    // EvaluateGradientAndJacobian = the system assembled at z (the buffer hsel does not select)
+    const double* __restrict__ Hnew = win.H[r.hsel ^ 1];
+    const int fl = fcol(l < n ? l : 0, fix);
+    const double gz = win.gz[fl], hd = Hnew[fl * MVO_MAXC + fl];
+    r.hsel = sel(take_z, r.hsel ^ 1, r.hsel);
+    r.g = sel(take_z, l < n ? gz : 0.0, r.g);
+    r.hdiag = sel(take_z, l < n ? hd : 0.0, r.hdiag);
+    const double js0 = 1.0 / (1.0 + sqrt(fmax(r.hdiag, 0.0)));  // jacobi_scaling, fixed at iteration 0
+    r.js = sel(init0, js0, r.js);
+    // gradient_max_norm = || x - Plus(x, -g) ||_inf
+    double pv[3], pt;
+    frames_plus4(lane, M, fix, r.xv, r.xt, r.g, -1.0, pv, pt);
+    const double gmn = frames_diff_max4(lane, M, fix, r.xv, r.xt, pv, pt);
+    r.gmn = sel(take_z, gmn, r.gmn);
+    it_gmn = sel(take_z, r.gmn, it_gmn);
+  }
+  bool run = act && !bad0 && !ptol_hit && !ftol_hit;  // rows that go on to the end of the iteration
+  bool go = false;
+  for (;;) {
+    // ---- FinalizeIterationAndCheckIfMinimizerCanContinue ----
+    {
+      const bool succ = run && it_succ, unsucc = run && !it_succ;
+      r.nsucc += succ ? 1 : 0;
+      r.nunsucc += unsucc ? 1 : 0;
+      const bool better = succ && r.x_cost < r.min_cost;
+      r.min_cost = sel(better, r.x_cost, r.min_cost);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) r.bv[j] = sel(better, r.xv[j], r.bv[j]);
+      r.bt = sel(better, r.xt, r.bt);
+      r.ntrace += run ? 1 : 0;
+      r.final_cost = sel(run, fmin(r.final_cost, it_cost), r.final_cost);
+    }
+    const bool stop_it = run && r.iteration >= prm.max_it;
+    const bool stop_g = run && !stop_it && it_succ && it_gmn <= prm.gtol;
+    const bool stop_r = run && !stop_it && !stop_g && r.radius <= 1e-32;  // min_trust_region_radius
+    lm4_terminate(r, stop_it, 1, 1);
+    lm4_terminate(r, stop_g, 0, 2);
+    lm4_terminate(r, stop_r, 0, 5);
+    const bool stp = run && !stop_it && !stop_g && !stop_r;
+    if (!__any(stp)) break;
+    // ---- next iteration: ComputeTrustRegionStep ----
+    r.iteration += stp ? 1 : 0;
+    it_cost = sel(stp, 0.0, it_cost);
+    it_gmn = sel(stp, 0.0, it_gmn);
+    it_succ = it_succ && !stp;
+    {
+      const double dg = fmin(fmax(r.js * r.js * r.hdiag, 1e-6), 1e32);  // min/max_lm_diagonal
+      r.dg = sel(stp && !r.reuse_diag, dg, r.dg);
+      r.reuse_diag = sel(stp, 1, r.reuse_diag);
+    }
+    const double jsm = l < n ? r.js : 0.0;
+    double a[MVO_MAXC];
+    {
+      const double* __restrict__ Hacc = win.H[r.hsel];
+      const int fl = fcol(l < n ? l : 0, fix);
+      double hrow[MVO_MAXC];
+#pragma unroll
+      for (int j = 0; j < MVO_MAXC; ++j) hrow[j] = Hacc[fl * MVO_MAXC + (fix ? 3 * (j >> 1) + (j & 1) : j)];
+      gj_setup<0>(a, hrow, jsm);
+    }
+    const double dd = r.dg * fast_rcp(r.radius);
+    const double ddl = l < n ? dd : 1.0;
+    const double rhs0 = jsm * r.g;
+    double rhs = rhs0, myrinv = 1.0;
+    unsigned phimax = 0;
+    {
+      const double piv0 = row_bcast<0>(a[0] + ddl);
+      gj_eliminate4<0>(a, rhs, myrinv, phimax, l, ddl, piv0, fast_rcp(piv0));
+    }
+    const double step = l < n ? -(rhs * myrinv) : 0.0;
+    const bool ok = phimax < 0x7ff00000u && !row_any(!isfinite(step));
+    const double mcc = ok ? 0.5 * row_sum_all(step * (dd * step - rhs0)) : 0.0;
+    r.mcc = sel(stp, mcc, r.mcc);
+    const bool valid = stp && ok && mcc > 0.0;
+    const bool invalid = stp && !valid;
+    // ---- HandleInvalidStep ----
+    r.num_invalid = sel(invalid, r.num_invalid + 1, sel(valid, 0, r.num_invalid));
+    const bool give_up = invalid && r.num_invalid >= 5;  // max_num_consecutive_invalid_steps
+    lm4_terminate(r, give_up, 2, 6);
+    const bool retry = invalid && !give_up;
+    r.radius = sel(retry, r.radius * 0.5, r.radius);  // StepIsInvalid
+    it_cost = sel(retry, r.x_cost, it_cost);
+    it_gmn = sel(retry, r.gmn, it_gmn);
+    // ---- ComputeCandidatePoint: delta = step o jscale; candidate = Plus(x, delta) ----
+    {
+      double cv[3], ct;
+      frames_plus4(lane, M, fix, r.xv, r.xt, step * r.js, 1.0, cv, ct);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) r.cv[j] = sel(valid, cv[j], r.cv[j]);
+      r.ct = sel(valid, ct, r.ct);
+      if (valid) {
+        Lm4View v = lm4_view(sh, row);
+        lm_publish_point(v, prm, M, l, r.cv, r.ct);
+      }
+      r.phase = sel(valid, (int)PH_EVAL_CAND, r.phase);
+      go = go || valid;
+    }
+    run = retry;
+    if (!__any(run)) break;
+  }
+  return go;
+}
+
+// One evaluation of window q at its published point: per-pair moments, class sums, prefix / suffix,
+// 3 x 3 blocks and gradient -- the stages of k_lm<64>, on all 64 lanes.
+__device__ __forceinline__ void lm4_evaluate(Lm4Shared& sh, int q, const PairIn& in0, bool my_ok0, int lane, int M,
+                                             int N, int hsel_q, const BlockRole& br) {
+  Lm4View v = lm4_view(sh, q);
+  {
+    double o[10], beta[3];
+    free_baseline(v, in0.a, in0.b < M - 1 ? in0.b : M - 1, beta);
+    pair_eval(in0, beta, 0, o);
+    if (my_ok0) {
+      double* __restrict__ dst = sh.pairbuf + lane * 10;
+#pragma unroll
+      for (int e = 0; e < 10; ++e) dst[e] = o[e];
+      if (in0.a == in0.b) {
+#pragma unroll
+        for (int e = 0; e < 10; ++e) sh.kk[in0.a][e] = o[e];
+      }
+    }
+  }
+  wave0_sync();
+  const int jA = lane / 10, vA = lane - 10 * jA;
+  if (lane < MCX * 10) {
+    double x[MVO_MAXM];
+    const int cnt = (jA < M) ? 1 : (jA == M ? N - 1 - M : 0);
+    int rowp[MVO_MAXM];
+#pragma unroll
+    for (int a = 0; a < MVO_MAXM; ++a) {
+      x[a] = 0.0;
+      rowp[a] = (a < M && a <= jA && jA <= M) ? pair_index(N, a, jA) : -1;
+    }
+    for (int i = 0; i < cnt; ++i) {
+#pragma unroll
+      for (int a = 0; a < MVO_MAXM; ++a) {
+        const double t = sh.pairbuf[(rowp[a] >= 0 ? rowp[a] + i : 0) * 10 + vA];
+        x[a] += rowp[a] >= 0 ? t : 0.0;
+      }
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int a = 0; a < MVO_MAXM; ++a) {
+      acc += (a < M && a <= jA && jA <= M) ? x[a] : 0.0;
+      sh.C1[a * MCX + jA][vA] = acc;
+    }
+  }
+  wave0_sync();
+  if (lane < MVO_MAXM * 10) {
+    double x[MCX];
+#pragma unroll
+    for (int j = 0; j < MCX; ++j) x[j] = sh.C1[jA * MCX + j][vA];
+    double acc = 0.0;
+#pragma unroll
+    for (int j = MCX - 1; j >= 0; --j) {
+      acc += x[j];
+      sh.D[jA * MCX + j][vA] = acc;
+    }
+    if (jA == MVO_MAXM - 1 && vA == 9) sh.win[q].cost = acc;  // all classes: prefix over every a, suffix from j = 0
+  }
+  wave0_sync();
+  lm_block_rows<0>(v, br, lane, sh.win[q].H[hsel_q ^ 1]);
+  lm_gradient_entry(v, lane >= br.nB4 && lane < br.nB4 + 3 * M, br.k4, br.i4);
+  wave0_sync();
+}
+
+// Workgroup b solves the windows win_base + 4 b .. + 3 (those below win_end).
+__global__ __launch_bounds__(64) void k_lm4(SolveParams prm, int win_end, int unit_slots,
+                                            const double* __restrict__ frames, const double* __restrict__ init_x,
+                                            const PairDev* __restrict__ pairs, const double* partial,
+                                            LmResult* __restrict__ results, int32_t* __restrict__ win_status,
+                                            int32_t* __restrict__ done_count) {
+  __shared__ Lm4Shared sh;
+  const int lane = threadIdx.x, row = lane >> 4, l = lane & 15;
+  const int M = prm.M, N = prm.N, P = prm.P;
+  const int fix = prm.fix_length;
+  const int n = fix ? 2 * M : 3 * M;
+  const int wbase = prm.win_base + LM4_WINDOWS * (int)blockIdx.x;
+  const int w_row = wbase + row;
+  const bool row_exists = w_row < win_end;
+  const int w_ld = row_exists ? w_row : win_end - 1;  // loads of a row without a window: any valid one
+
+  // every global load of the prologue first: the starting points and the pairs' inputs of the four windows
+  double x0w[4];
+  {
+    const int k = l < M ? l : 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x0w[e] = init_x[((size_t)w_ld * MVO_MAXM + k) * 4 + e];
+  }
+  const int my_p0 = lane < P ? lane : 0;
+  const bool my_ok0 = lane < P;
+  PairIn in[LM4_WINDOWS];
+#pragma unroll
+  for (int q = 0; q < LM4_WINDOWS; ++q) {
+    const int wq = wbase + q < win_end ? wbase + q : win_end - 1;
+    pair_load(in[q], my_p0, N, M, unit_slots != 0, pairs + (size_t)wq * P, partial, (uint32_t)wq * (uint32_t)P,
+              frames + (size_t)MVO_FRAME_DOUBLES * wq * N);
+  }
+  // both system buffers of every window start from zero (see k_lm: the elimination reads whole rows)
+  for (int i = lane; i < LM4_WINDOWS * 2 * MVO_MAXC * MVO_MAXC; i += 64) {
+    const int q = i / (2 * MVO_MAXC * MVO_MAXC), e = i - q * (2 * MVO_MAXC * MVO_MAXC);
+    (&sh.win[q].H[0][0])[e] = 0.0;
+  }
+  if (lane < LM4_WINDOWS) sh.win[lane].cost = 0.0;
+  if (row_exists && l == 0) win_status[w_row] = 0;
+
+  Lm4Regs r;
+  r.g = r.js = r.dg = r.hdiag = 0.0;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) r.xv[j] = r.cv[j] = r.bv[j] = 0.0;
+  r.xt = r.ct = r.bt = 0.0;
+  r.x_cost = r.x_norm = r.min_cost = r.mcc = r.radius = r.decf = r.gmn = r.initial_cost = r.final_cost = 0.0;
+  r.se_min = r.se_cur = r.se_ref = r.se_cand = r.se_acc_ref = r.se_acc_cand = 0.0;
+  r.se_nonmono = r.reuse_diag = r.iteration = r.num_invalid = r.nsucc = r.nunsucc = 0;
+  r.termination = r.reason = r.ntrace = r.hsel = 0;
+  r.status = row_exists ? 0 : 1;
+  r.phase = PH_EVAL_X0;
+  r.xv[0] = x0w[0]; r.xv[1] = x0w[1]; r.xv[2] = x0w[2]; r.xt = x0w[3];  // IR.cpp:95-109
+  {
+    Lm4View v = lm4_view(sh, row);
+    lm_publish_point(v, prm, M, l, r.xv, r.xt);
+  }
+  wave0_sync();
+  const BlockRole br = block_role(M, lane);
+
+  unsigned long long need = __ballot(r.status == 0 && l == 0);  // bit 16 q: window q awaits an evaluation
+  while (need) {
+    for (int q = 0; q < LM4_WINDOWS; ++q) {
+      if (!((need >> (16 * q)) & 1ull)) continue;
+      // the inputs of window q (q is wave-uniform: scalar selects)
+      PairIn cur = in[0];
+#pragma unroll
+      for (int t = 1; t < LM4_WINDOWS; ++t) {
+        const bool take = q == t;
+#pragma unroll
+        for (int e = 0; e < 7; ++e) cur.S[e] = take ? in[t].S[e] : cur.S[e];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) cur.off[e] = take ? in[t].off[e] : cur.off[e];
+      }
+      const int hsel_q = __builtin_amdgcn_readlane(r.hsel, 16 * q);
+      lm4_evaluate(sh, q, cur, my_ok0, lane, M, N, hsel_q, br);
+    }
+    const bool act = (need >> (16 * row)) & 1ull;
+    const bool go = lm4_advance(r, sh, prm, M, n, lane, act);
+    wave0_sync();
+    need = __ballot(go && l == 0);
+  }
+
+  if (row_exists) {
+    LmResult* __restrict__ res = results + w_row;
+    if (l < MVO_MAXM) {
+      // Ceres hands the lowest-cost iterate back only when the summary is usable; after FAILURE the
+      // user's arrays keep their INITIAL values (see k_lm)
+      const bool usable = r.termination != 2;
+      const double bt = usable ? r.bt : x0w[3];
+      res->vec[l][0] = usable ? r.bv[0] : x0w[0];
+      res->vec[l][1] = usable ? r.bv[1] : x0w[1];
+      res->vec[l][2] = usable ? r.bv[2] : x0w[2];
+      res->t[l] = bt;
+      res->scale[l] = d_scale(bt, prm.max_len, prm.min_len);
+    }
+    if (l == 0) {
+      res->initial_cost = r.initial_cost;
+      res->final_cost = r.final_cost;
+      res->termination = r.termination;
+      res->reason = r.reason;
+      res->iterations = r.ntrace - 1;
+      res->nsucc = r.nsucc;
+      res->nunsucc = r.nunsucc;
+      res->pad = 0;
+      win_status[w_row] = 1;
+      atomicAdd(done_count, 1);
+    }
+  }
+}

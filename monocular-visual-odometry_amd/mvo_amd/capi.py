@@ -26,6 +26,8 @@ ERR_STATE = 6
 ASSEMBLY_AUTO = 0
 ASSEMBLY_PASSES = 1
 ASSEMBLY_TILED = 2
+ASSEMBLY_ONE_PER_WAVE = 4
+ASSEMBLY_FOUR_PER_WAVE = 8
 
 EXPORTED_SYMBOLS = [
     "mvo_hip_create", "mvo_hip_destroy", "mvo_hip_refine", "mvo_hip_refine_batch", "mvo_hip_upload",

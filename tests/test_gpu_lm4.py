@@ -1,0 +1,59 @@
+"""k_lm4 (four windows per wavefront, csrc/mvo_lm4.h) against k_lm<64> (one window per wavefront) and
+against the oracle: the batched solver of mvo_hip_refine_batch for windows with at most 64 frame pairs.
+The LM step of k_lm4 is the branch-free restatement of lm_decide / lm_step: same arithmetic, so the
+two kernels must take the same decisions and agree to rounding, whatever the windows of a wavefront do
+(different accept / reject sequences, different termination evaluations, rows without a window)."""
+import numpy as np
+import pytest
+
+from mvo_amd import capi, scene
+
+pytestmark = pytest.mark.gpu
+
+FIXED10 = dict(max_num_iterations=10, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
+
+
+def _batch(n, N=10, M=5, feats=120, seed0=300, **kw):
+    return [scene.make_window(N, M, feats, seed=seed0 + i, **kw) for i in range(n)]
+
+
+def _solve(solver, ws, **opt):
+    return solver.refine_batch(ws, capi.make_options(**opt))
+
+
+@pytest.mark.parametrize("n", [4, 5, 7, 16, 33])
+@pytest.mark.parametrize("opts", [dict(**FIXED10), dict(max_num_iterations=50), dict(fix_length=True, **FIXED10),
+                                  dict(max_num_iterations=50, function_tolerance=1e-6, gradient_tolerance=1e-10,
+                                       parameter_tolerance=1e-8)])
+def test_four_per_wave_equals_one_per_wave(solver, n, opts):
+    ws = _batch(n)
+    f4, s4 = _solve(solver, ws, assembly_mode=capi.ASSEMBLY_TILED | capi.ASSEMBLY_FOUR_PER_WAVE, **opts)
+    f1, s1 = _solve(solver, ws, assembly_mode=capi.ASSEMBLY_TILED | capi.ASSEMBLY_ONE_PER_WAVE, **opts)
+    for a, b in zip(s4, s1):
+        ka = (a.termination, a.reason, a.iterations, a.num_successful_steps, a.num_unsuccessful_steps)
+        kb = (b.termination, b.reason, b.iterations, b.num_successful_steps, b.num_unsuccessful_steps)
+        assert ka == kb
+        # the same operations, but the compiler contracts multiply-adds differently in the two kernels
+        assert abs(a.initial_cost - b.initial_cost) <= 1e-13 * b.initial_cost
+        assert abs(a.final_cost - b.final_cost) <= 1e-11 * b.initial_cost
+    assert np.abs(np.asarray(f4) - np.asarray(f1)).max() < 1e-9
+
+
+def test_rows_that_stop_at_different_evaluations(solver, oracle):
+    """Windows of one wavefront with very different histories: noise-free (stops at once on the gradient /
+    function tolerance), noisy, and far-off starts -- every window against the oracle."""
+    ws = []
+    for i in range(12):
+        ws.append(scene.make_window(8, 4, 90, seed=700 + i, noise_sigma=0.0 if i % 3 == 0 else 2e-3,
+                                    init_angle_deg=3.0 if i % 4 else 20.0))
+    opt = dict(max_num_iterations=30)
+    fg, sg = _solve(solver, ws, assembly_mode=capi.ASSEMBLY_TILED | capi.ASSEMBLY_FOUR_PER_WAVE, **opt)
+    its = set()
+    for w, f, s in zip(ws, fg, sg):
+        fo, so, _ = oracle.refine(w, oracle.make_options(**opt))
+        assert (s.termination, s.reason) == (so.termination, so.reason)
+        assert s.iterations == so.iterations
+        assert abs(s.final_cost - so.final_cost) <= 1e-8 * max(so.initial_cost, 1e-300)
+        assert np.abs(np.asarray(f)[: w.M, 9:13] - np.asarray(fo)[: w.M, 9:13]).max() < 1e-6
+        its.add(s.iterations)
+    assert len(its) >= 3  # the rows of a wavefront really did finish at different evaluations
