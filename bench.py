@@ -112,7 +112,7 @@ def measured_traffic(workload, kernel):
 
 
 def pass_kernel(workload):
-    return "k_pass<true>" if workload in ("config5", "config4r") else "k_fold<false, true>"
+    return "k_pass<true>" if workload in ("config5", "config4r") else "k_fold<false, true, 0>"
 
 
 def roofline_of(timing, workload=None):
