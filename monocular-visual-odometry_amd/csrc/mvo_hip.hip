@@ -773,7 +773,12 @@ hipError_t launch_lm4_range(mvo_hip_context* h, SolveParams prm, uint32_t win0, 
 hipError_t launch_lm_any(mvo_hip_context* h, SolveParams prm, bool from_pair_sums = false) {
   prm.fresh = h->lm_started ? 0 : 1;  // the first launch of a solve starts from a zeroed state
   h->lm_started = true;
-  return h->P <= 64 ? launch_lm<64>(h, prm, from_pair_sums) : launch_lm<MVO_LM_NT_LARGE>(h, prm, from_pair_sums);
+  // Up to one window per CU the four-wavefront kernel is the faster one whatever the window's size: the
+  // verdict on a point runs beside the block products, an inline pass takes a pair per wavefront.  Beyond
+  // that a window with at most 64 pairs gets one wavefront (four windows per CU at a time).
+  // (MVO_HIP_ASSEMBLY_ONE_PER_WAVE asks for the one-wavefront kernel by name: tests compare against it)
+  const bool one_wave = h->P <= 64 && (h->W > 256 || (h->opt.assembly_mode & MVO_HIP_ASSEMBLY_ONE_PER_WAVE));
+  return one_wave ? launch_lm<64>(h, prm, from_pair_sums) : launch_lm<MVO_LM_NT_LARGE>(h, prm, from_pair_sums);
 }
 
 // ---- observation-partitioned mode: fold / pass -> per-pair sums -> caller's

@@ -33,10 +33,11 @@ def test_four_per_wave_equals_one_per_wave(solver, n, opts):
         ka = (a.termination, a.reason, a.iterations, a.num_successful_steps, a.num_unsuccessful_steps)
         kb = (b.termination, b.reason, b.iterations, b.num_successful_steps, b.num_unsuccessful_steps)
         assert ka == kb
-        # the same operations, but the compiler contracts multiply-adds differently in the two kernels
+        # the same operations, but different summation orders (up to 256 windows the other path is the
+        # four-wavefront kernel) and differently contracted multiply-adds; ten iterations amplify them
         assert abs(a.initial_cost - b.initial_cost) <= 1e-13 * b.initial_cost
-        assert abs(a.final_cost - b.final_cost) <= 1e-11 * b.initial_cost
-    assert np.abs(np.asarray(f4) - np.asarray(f1)).max() < 1e-9
+        assert abs(a.final_cost - b.final_cost) <= 1e-9 * b.initial_cost
+    assert np.abs(np.asarray(f4) - np.asarray(f1)).max() < 1e-7
 
 
 def test_rows_that_stop_at_different_evaluations(solver, oracle):

@@ -56,7 +56,11 @@ def test_eval_and_moments_match_oracle(solver, oracle, name):
 
 
 # ------------------------------------------------------------------ refine(): fixed iteration count
-MODES = [capi.ASSEMBLY_AUTO, capi.ASSEMBLY_PASSES, capi.ASSEMBLY_TILED, capi.ASSEMBLY_TILED | capi.ASSEMBLY_PASSES]
+MODES = [capi.ASSEMBLY_AUTO, capi.ASSEMBLY_PASSES, capi.ASSEMBLY_TILED, capi.ASSEMBLY_TILED | capi.ASSEMBLY_PASSES,
+         # up to 256 windows the four-wavefront kernel solves every window; these two ask for the
+         # one-wavefront kernel (windows of at most 64 pairs), inline and tiled
+         capi.ASSEMBLY_ONE_PER_WAVE, capi.ASSEMBLY_TILED | capi.ASSEMBLY_ONE_PER_WAVE,
+         capi.ASSEMBLY_PASSES | capi.ASSEMBLY_ONE_PER_WAVE]
 
 
 @pytest.mark.parametrize("mode", MODES)
