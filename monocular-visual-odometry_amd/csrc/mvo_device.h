@@ -85,8 +85,9 @@ struct LmResult {
   double t[MVO_MAXM];
   double scale[MVO_MAXM];  // s(t): the write-back value of IR.cpp:240-246, so that a download is a copy
   double initial_cost, final_cost;
-  int32_t termination, reason, iterations, nsucc, nunsucc, pad;
+  int32_t termination, reason, iterations, nsucc, nunsucc, pad;  // pad = kResultWritten once written
 };
+constexpr int32_t kResultWritten = 0x600D;
 
 // ---- scalar math ----------------------------------------------------------------------
 

@@ -179,6 +179,7 @@ struct mvo_hip_context {
   int32_t* d_status = nullptr;
   int32_t* d_done = nullptr;
   LmResult* d_results = nullptr;
+  bool results_on_host = false;  // this solve's k_lm writes its (few) result records straight into h_results
   char* h_ctl = nullptr;  // pinned: [done: 4 int32][results]
   size_t h_ctl_cap = 0;
   int32_t* h_done = nullptr;
@@ -718,7 +719,7 @@ hipError_t launch_lm(mvo_hip_context* h, const SolveParams& prm, bool from_pair_
                      from_pair_sums ? h->t.pairs_unit : h->t.pairs,
                      from_pair_sums ? h->d_pairsum.as<double>() : h->d_partial.as<double>(),
                      h->t.m0, h->t.m1, h->d_pairsum.as<double>(),
-                     h->d_states.as<LmState>(), h->d_results,
+                     h->d_states.as<LmState>(), h->results_on_host ? h->h_results : h->d_results,
                      h->d_pair_u.as<double>(), h->d_status, h->d_trace.as<TraceRec>(),
                      h->d_done);
   return hipGetLastError();
@@ -765,7 +766,8 @@ hipError_t launch_lm4_range(mvo_hip_context* h, SolveParams prm, uint32_t win0, 
   const uint32_t groups = (win1 - win0 + LM4_WINDOWS - 1) / LM4_WINDOWS;
   hipLaunchKernelGGL(k_lm4, dim3(groups), dim3(64), 0, stream, prm, (int)win1, from_pair_sums ? 1 : 0, h->t.frames,
                      h->t.initx, from_pair_sums ? h->t.pairs_unit : h->t.pairs,
-                     from_pair_sums ? h->d_pairsum.as<double>() : h->d_partial.as<double>(), h->d_results, h->d_status,
+                     from_pair_sums ? h->d_pairsum.as<double>() : h->d_partial.as<double>(),
+                     h->results_on_host ? h->h_results : h->d_results, h->d_status,
                      h->d_done);
   return hipGetLastError();
 }
@@ -792,6 +794,7 @@ hipError_t launch_reduce_slots(mvo_hip_context* h) {
 
 int partial_begin(mvo_hip_context* h) {
   if (!h->uploaded) return MVO_HIP_ERR_STATE;
+  h->results_on_host = false;
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t s = h->stream;
   const uint32_t n = h->W * h->P;
@@ -854,6 +857,7 @@ int partial_advance(mvo_hip_context* h, int32_t* done) {
 // so every rank takes the same decisions and finishes at the same evaluation.
 int do_solve_partitioned(mvo_hip_context* h) {
   if (!h->uploaded || !h->comm) return MVO_HIP_ERR_STATE;
+  h->results_on_host = false;
   const auto t_begin = std::chrono::steady_clock::now();
   HIP_TRY(hipSetDevice(h->device));
   const MvoRccl& rc = mvo_rccl();
@@ -959,6 +963,11 @@ int do_solve(mvo_hip_context* h) {
   h->done_ready = false;  // until this solve has been seen to complete
   h->solved = false;
   const uint32_t done_base = h->done_base;
+  // Up to 64 windows the result records (208 B each) are written by k_lm straight into the pinned host
+  // mirror: one command less on the stream (~4 us of a 45-us default-size solve).
+  h->results_on_host = h->W <= 64 && !std::getenv("MVO_HIP_NO_HOST_RESULTS");
+  if (h->results_on_host)
+    for (uint32_t w = 0; w < h->W; ++w) h->h_results[w].pad = 0;
 
   const uint32_t fold_blocks = pass_blocks(h);
   int n_timed = 0;
@@ -1067,11 +1076,21 @@ int do_solve(mvo_hip_context* h) {
     }
   }
   if (prof) HIP_TRY(hipEventRecord(h->ev[1], s));
-  // done counter and results are adjacent on both sides: one copy
-  HIP_TRY(hipMemcpyAsync(h->h_ctl, h->d_done, 16 + sizeof(LmResult) * h->W, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  h->copy_pending = false;
-  if ((uint32_t)h->h_done[0] - done_base != h->W) return MVO_HIP_ERR_DEVICE;  // every window must have terminated
+  if (h->results_on_host) {
+    // a few windows: k_lm wrote the result records into the pinned mirror itself (and marked each: pad);
+    // no copy command, the done counter is accounted for without being read
+    HIP_TRY(hipStreamSynchronize(s));
+    h->copy_pending = false;
+    for (uint32_t w = 0; w < h->W; ++w)
+      if (h->h_results[w].pad != kResultWritten) return MVO_HIP_ERR_DEVICE;  // every window must have terminated
+    h->h_done[0] = (int32_t)(done_base + h->W);
+  } else {
+    // done counter and results are adjacent on both sides: one copy
+    HIP_TRY(hipMemcpyAsync(h->h_ctl, h->d_done, 16 + sizeof(LmResult) * h->W, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    h->copy_pending = false;
+    if ((uint32_t)h->h_done[0] - done_base != h->W) return MVO_HIP_ERR_DEVICE;  // every window must have terminated
+  }
   h->done_base = (uint32_t)h->h_done[0];
   h->done_ready = true;
   h->solved = true;

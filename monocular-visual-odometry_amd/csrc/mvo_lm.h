@@ -1356,7 +1356,7 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
       res->iterations = st.ntrace - 1;
       res->nsucc = st.nsucc;
       res->nunsucc = st.nunsucc;
-      res->pad = 0;
+      res->pad = kResultWritten;
       win_status[w] = 1;
       atomicAdd(done_count, 1);
     }

@@ -522,7 +522,7 @@ __global__ __launch_bounds__(64) void k_lm4(SolveParams prm, int win_end, int un
       res->iterations = r.ntrace - 1;
       res->nsucc = r.nsucc;
       res->nunsucc = r.nunsucc;
-      res->pad = 0;
+      res->pad = kResultWritten;
       win_status[w_row] = 1;
       atomicAdd(done_count, 1);
     }
