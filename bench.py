@@ -506,10 +506,14 @@ def bench_tracks(args, rank, local_rank, world, barrier, dist, torch):
         for _ in range(k):
             exp, es = solver.refine(hw, opt)
         host_ms = (time.perf_counter() - t1) / k * 1e3
-        assert np.array_equal(exp, out_frames), "device-gathered and host-gathered refinement differ"
+        # no loss: the moments are summed straight from the tables, in another order than k_fold sums the
+        # gathered blocks (bit-exact with MVO_HIP_TRACKS_NO_FUSE=1, tests/test_gpu_tracks.py)
+        assert np.abs(exp - out_frames).max() < 1e-8, "device-gathered and host-gathered refinement differ"
 
     dur = fill_s / n_prof
     gbs = tt["fill_bytes"] / dur / 1e9 if dur > 0 else 0.0
+    fused = not os.environ.get("MVO_HIP_TRACKS_NO_FUSE")
+    gather_kernel = "k_tracks_fold" if fused else "k_tracks_fill"
     out = {
         "metric": "lm_iterations_per_sec", "value": round(summ.iterations * args.steps * world / elapsed, 3),
         "unit": "LM iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -526,8 +530,8 @@ def bench_tracks(args, rank, local_rank, world, barrier, dist, torch):
         "steps_with_hip_events": n_prof,
         "host_gathered_refine_ms_pcie_inclusive": None if host_ms is None else round(host_ms, 5),
         "roofline": {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.workload, "k_tracks_fill"),
-                     "kernel": "k_tracks_fill", "bytes_per_launch": int(tt["fill_bytes"]),
+                     "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.workload, gather_kernel),
+                     "kernel": gather_kernel + (" (+ k_tracks_reduce)" if fused else ""), "bytes_per_launch": int(tt["fill_bytes"]),
                      "avg_launch_us": round(dur * 1e6, 3), "launches_timed": n_prof},
     }
     if rank == 0 and world == 1 and not args.no_cpu:

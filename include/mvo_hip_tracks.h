@@ -50,6 +50,16 @@ int mvo_hip_tracks_reset(mvo_hip_tracks_handle t);
 int mvo_hip_tracks_refine(mvo_hip_tracks_handle t, mvo_hip_frame *frames, uint32_t M, uint32_t N,
                           const mvo_hip_options *options, mvo_hip_summary *summary);
 
+/* IterativeRefinement::refine on the newest N pushed keyframes ... without a loss function the library
+ * does not gather the residual blocks at all: the LM loop needs 6 second moments per frame pair
+ * (DESIGN.md section 2), and those are summed straight from the track tables (k_tracks_fold).  parity/debug:
+ * these moments, S_p = sum c c^T with c = (R_a m0) x (R_{b+1} m1) over the pair's blocks
+ * (IterativeRefinement.cpp:116-172, 252-263), 6 doubles per pair (xx, xy, xz, yy, yz, zz) in the
+ * reference's pair order -- what mvo_hip_pair_moments returns for the host-gathered blocks, to
+ * rounding (the summation order differs). */
+int mvo_hip_tracks_pair_moments(mvo_hip_tracks_handle t, const mvo_hip_frame *frames, uint32_t M, uint32_t N,
+                                double *moments);
+
 /* parity/debug: the gathered residual blocks of the newest N frames in the reference's pair order.
  * pair_offsets: n_pairs + 1 entries; m0 / m1 (3 doubles per block, capacity `capacity` blocks) may
  * be NULL to query the total = pair_offsets[n_pairs] first. */
@@ -72,11 +82,12 @@ int mvo_hip_tracks_scale(mvo_hip_tracks_handle t, mvo_hip_scaler_handle scaler, 
  * the last refine / gather call. */
 typedef struct {
   double count_seconds;      /* k_tracks_count + k_tracks_scan */
-  double fill_seconds;       /* k_tracks_fill */
+  double fill_seconds;       /* k_tracks_fill, or k_tracks_fold + k_tracks_reduce when the refine ran fused */
   uint64_t residual_blocks;  /* gathered by the last call */
   uint64_t fill_bytes;       /* algorithmic bytes of that k_tracks_fill launch: 32 B per feature of the M
                               * newest frames (counter, predecessor, ray); per gathered block 4 B of
-                              * predecessor index, 24 B of ray read, 2 x 24 B written */
+                              * predecessor index, 24 B of ray read, 2 x 24 B written (fused fold: nothing
+                              * written per block, 28 B per block) */
 } mvo_hip_tracks_timing; /* 32 bytes */
 int mvo_hip_tracks_set_profiling(mvo_hip_tracks_handle t, int enabled);
 int mvo_hip_tracks_get_timing(mvo_hip_tracks_handle t, mvo_hip_tracks_timing *out);

@@ -179,6 +179,7 @@ struct mvo_hip_context {
   int32_t* d_status = nullptr;
   int32_t* d_done = nullptr;
   LmResult* d_results = nullptr;
+  bool sums_external = false;  // the per-pair sums in d_pairsum were put there by the caller (fused track fold)
   bool results_on_host = false;  // this solve's k_lm writes its (few) result records straight into h_results
   char* h_ctl = nullptr;  // pinned: [done: 4 int32][results]
   size_t h_ctl_cap = 0;
@@ -371,13 +372,15 @@ void host_pair_u0(const mvo_hip_context* h, uint32_t w, double* out) {
 // rays_on_device: obs[w].m0 / m1 are not read; the caller fills h->t.m0 / m1 itself with work it queues
 // on h->stream after this call (the device-side gather of mvo_tracks.hip); pair_offsets are host memory.
 int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint32_t M, uint32_t N,
-              const mvo_hip_options* opt, const mvo_hip_observations* obs, bool rays_on_device = false) {
+              const mvo_hip_options* opt, const mvo_hip_observations* obs, bool rays_on_device = false,
+              bool no_rays = false) {
   const auto t_begin = std::chrono::steady_clock::now();
   int rc = validate(W, frames, M, N, opt, obs);
   if (rc != MVO_HIP_OK) return rc;
   HIP_TRY(hipSetDevice(h->device));
   h->uploaded = false;
   h->solved = false;
+  h->sums_external = false;
   const uint32_t P = num_pairs(M, N);
   h->W = W;
   h->M = M;
@@ -542,7 +545,7 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
   }
 
   // ---- lay the tables out in the arena; rays join them when they are few (one copy in all)
-  const bool rays_in_arena = n_obs <= kArenaRayLimit;
+  const bool rays_in_arena = n_obs <= kArenaRayLimit && !no_rays;
   size_t off = 0;
   auto place = [&off](size_t bytes) {
     const size_t o = off;
@@ -575,7 +578,7 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
     h->h_arena_cap = want;
   }
   HIP_TRY(h->d_arena.reserve(arena_bytes));
-  if (!rays_in_arena) {
+  if (!rays_in_arena && !no_rays) {
     HIP_TRY(h->d_m0.reserve(sizeof(double) * 3 * (n_obs + 1)));
     HIP_TRY(h->d_m1.reserve(sizeof(double) * 3 * (n_obs + 1)));
   }
@@ -1023,7 +1026,7 @@ int do_solve(mvo_hip_context* h) {
     // one fold+moment pass, then the whole LM loop in a single launch.  S_p never changes without a
     // loss: the fold's last workgroup adds the slots up per pair, every k_lm lane loads the sums of its
     // (up to four) pairs once and keeps them in registers.
-    if (fold_blocks) {
+    if (fold_blocks && !h->sums_external) {
       HIP_TRY(timed_begin());
       HIP_TRY(launch_fold(h, false, true));
       HIP_TRY(timed_end());
@@ -1033,7 +1036,7 @@ int do_solve(mvo_hip_context* h) {
       HIP_TRY(launch_lm4_range(h, prm, 0, h->W, s, true));
       h->lm_started = true;
     } else {
-      HIP_TRY(launch_lm_any(h, prm, fold_blocks != 0));
+      HIP_TRY(launch_lm_any(h, prm, fold_blocks != 0 || h->sums_external));
     }
     ++lm_launches;
   } else {
@@ -1250,6 +1253,21 @@ int mvo_hip_internal_upload_device_rays(mvo_hip_handle h, const mvo_hip_frame* f
   if (rc != MVO_HIP_OK) return rc;
   *m0_device = h->t.m0;
   *m1_device = h->t.m1;
+  return MVO_HIP_OK;
+}
+
+int mvo_hip_internal_upload_pair_sums(mvo_hip_handle h, const mvo_hip_frame* frames, uint32_t M, uint32_t N,
+                                      const mvo_hip_options* options, const mvo_hip_observations* observations,
+                                      const double** frames_device, double** pair_sums_device) {
+  if (!h || !options || !frames_device || !pair_sums_device) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  if (options->use_loss_function || (options->assembly_mode & MVO_HIP_ASSEMBLY_PASSES)) return MVO_HIP_ERR_UNSUPPORTED;
+  mvo_hip_options opt = *options;
+  opt.assembly_mode |= MVO_HIP_ASSEMBLY_TILED;  // the window's own workgroup must not go looking for rays
+  const int rc = do_upload(h, 1, frames, M, N, &opt, observations, true, true);
+  if (rc != MVO_HIP_OK) return rc;
+  h->sums_external = true;
+  *frames_device = h->t.frames;
+  *pair_sums_device = h->d_pairsum.as<double>();
   return MVO_HIP_OK;
 }
 

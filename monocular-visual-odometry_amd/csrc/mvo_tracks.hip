@@ -29,11 +29,15 @@
 #include "mvo_alloc.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
 
 #include "mvo_internal.h"
+#include "mvo_wave.h"
+
+#define MVO_FRAME_DOUBLES 13  // R(9) vec(3) scale(1): mvo_hip_frame
 
 #define TR_THREADS 256
 #define TR_SCAN_GROUPS 16  // k_tracks_scan: 16 wavefronts share the feature groups of one (a, 64 steps)
@@ -180,6 +184,89 @@ __global__ __launch_bounds__(64) void k_tracks_fill(TracksDev t, uint32_t N, uin
   }
 }
 
+// ---- fused gather-and-fold (no loss): the chain walk of k_tracks_fill, but instead of writing the two
+// rays of a residual block (48 B) for k_fold to read back (48 B), the block's c = (R_a m0) x (R_{a+s} m1)
+// is formed on the spot and c c^T summed per (frame a, feature group, step): 6 sums per step and
+// wavefront (wave_reduce8), parked in `part`; k_tracks_reduce adds the groups up in group order into the
+// solver's per-pair sums, which is all k_lm reads without a loss.  The residual blocks never exist in HBM.
+// part[((a * n_groups + g) * SP + s - 1) * 8 + v]
+__global__ __launch_bounds__(64) void k_tracks_fold(TracksDev t, uint32_t N, uint32_t n_groups, uint32_t SP,
+                                                   const double* __restrict__ frames, double* __restrict__ part) {
+  const uint32_t g = blockIdx.x, a = blockIdx.y, lane = threadIdx.x;
+  const uint32_t slot_a = tr_slot(t, a), n = t.n_feat[slot_a];
+  if (g * 64 >= n) return;
+  const uint32_t i = g * 64 + lane;
+  const bool have = i < n;
+  const uint32_t c = have ? min(t.counter[(size_t)slot_a * t.max_features + i], N - 1 - a) : 0u;
+  double px = 0.0, py = 0.0, pz = 0.0;  // R_a m0 (IterativeRefinement.cpp:172)
+  if (c) {
+    const double* __restrict__ r0 = t.rays + ((size_t)slot_a * t.max_features + i) * 3;
+    const double* __restrict__ R0 = frames + (size_t)MVO_FRAME_DOUBLES * a;
+    const double x = r0[0], y = r0[1], z = r0[2];
+    px = R0[0] * x + R0[1] * y + R0[2] * z;
+    py = R0[3] * x + R0[4] * y + R0[5] * z;
+    pz = R0[6] * x + R0[7] * y + R0[8] * z;
+  }
+  double* __restrict__ prow = part + (size_t)(a * n_groups + g) * SP * 8;
+  uint32_t idx = i;
+  int32_t nxt = c ? t.pre[(size_t)slot_a * t.max_features + i] : -1;
+  for (uint32_t s = 1;; ++s) {
+    const bool alive = c >= s;
+    if (!__ballot(alive)) break;
+    double S[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (alive) {
+      idx = (uint32_t)nxt;
+      const size_t cell = (size_t)tr_slot(t, a + s) * t.max_features + idx;
+      const double* __restrict__ r1 = t.rays + cell * 3;
+      const double x = r1[0], y = r1[1], z = r1[2];
+      if (c > s) nxt = t.pre[cell];  // in flight together with the ray
+      const double* __restrict__ R1 = frames + (size_t)MVO_FRAME_DOUBLES * (a + s);  // frames[b + 1], IR.cpp:171
+      const double qx = R1[0] * x + R1[1] * y + R1[2] * z;
+      const double qy = R1[3] * x + R1[4] * y + R1[5] * z;
+      const double qz = R1[6] * x + R1[7] * y + R1[8] * z;
+      const double vx = py * qz - pz * qy, vy = pz * qx - px * qz, vz = px * qy - py * qx;
+      S[0] = vx * vx;
+      S[1] = vx * vy;
+      S[2] = vx * vz;
+      S[3] = vy * vy;
+      S[4] = vy * vz;
+      S[5] = vz * vz;
+    }
+    const double tot = wave_reduce8(S, (int)lane);
+    if ((lane & 7) == 0) prow[(size_t)(s - 1) * 8 + reduce8_value_of_lane((int)lane)] = tot;
+  }
+}
+
+// pair (a, s): sum of the groups' partial sums in group order; a group that had no block at step s
+// wrote nothing (base ranks after the scan: an empty group's equals the next one's).
+// grid (N - 1, M), 256 threads = 32 group lanes x 8 values.
+__global__ __launch_bounds__(256) void k_tracks_reduce(TracksDev t, uint32_t N, uint32_t n_groups, uint32_t SP,
+                                                      const uint32_t* __restrict__ base,
+                                                      const uint32_t* __restrict__ counts,
+                                                      const double* __restrict__ part, double* __restrict__ pair_sums) {
+  __shared__ double red[32][8];
+  const uint32_t s1 = blockIdx.x, a = blockIdx.y;  // s - 1
+  if (s1 >= N - 1 - a) return;
+  const uint32_t v = threadIdx.x & 7, gl = threadIdx.x >> 3;
+  const uint32_t ng = (t.n_feat[tr_slot(t, a)] + 63) / 64;
+  const uint32_t p = tr_pair_start(N, a) + s1;
+  const uint32_t total = counts[p];
+  const uint32_t* __restrict__ col = base + (size_t)a * n_groups * SP + s1;
+  double acc = 0.0;
+  for (uint32_t g = gl; g < ng; g += 32) {
+    const uint32_t b0 = col[(size_t)g * SP], b1 = g + 1 < ng ? col[(size_t)(g + 1) * SP] : total;
+    if (b1 > b0) acc += part[((size_t)(a * n_groups + g) * SP + s1) * 8 + v];
+  }
+  red[gl][v] = acc;
+  __syncthreads();
+  if (gl == 0) {
+    double sum = 0.0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) sum += red[k][v];
+    pair_sums[(size_t)p * 8 + v] = v < 6 ? sum : 0.0;
+  }
+}
+
 // ---- the scale stage's three-frame gather (Scaler.cpp:22 -> Frame.hpp:103-152, depth 2): features of
 // the frame `age` pushes ago whose track reaches back two more frames, in that frame's order.
 // cnt[g] = such features in the 64-feature group g; one workgroup scans the groups (-> base ranks in
@@ -248,6 +335,8 @@ struct mvo_hip_tracks_context {
   uint32_t *d_counter = nullptr, *d_nfeat = nullptr, *d_counts = nullptr;
   uint32_t* d_cnt = nullptr;  // [M][n_groups][SP]: per-group counts, then base ranks
   size_t cap_cnt = 0;
+  double* d_part = nullptr;   // fused fold: [M][n_groups][SP][8] partial moments
+  size_t cap_part = 0;
   double* d_rays_in = nullptr;  // staging of the caller's rays
   uint32_t g_groups = 0, g_sp = 0;  // shape of d_cnt at the last count
   uint32_t* h_total = nullptr;      // pinned: number of three-frame tracks
@@ -261,7 +350,8 @@ struct mvo_hip_tracks_context {
   uint64_t* h_offsets = nullptr; // pinned
   bool profiling = false, events_ready = false, count_timed = false, fill_timed = false;
   hipEvent_t ev[4] = {};
-  uint64_t last_blocks = 0, last_fill_bytes = 0;
+  uint64_t last_blocks = 0, last_fill_bytes = 0, last_feature_bytes = 0;
+  bool last_fused = false;
 };
 
 namespace {
@@ -355,6 +445,7 @@ int count_pairs(mvo_hip_tracks_context* t, uint32_t M, uint32_t N) {
     uint64_t bytes = 0;
     for (uint32_t a = 0; a < M; ++a) bytes += 32ull * t->h_nfeat[(t->head + t->max_frames - a) % t->max_frames];
     t->last_blocks = t->h_offsets[P];
+    t->last_feature_bytes = bytes;
     t->last_fill_bytes = bytes + 76ull * t->last_blocks;
   }
   TR_TRY(hipMemcpyAsync(t->d_offsets, t->h_offsets, sizeof(uint64_t) * (P + 1), hipMemcpyHostToDevice, s));
@@ -364,6 +455,7 @@ int count_pairs(mvo_hip_tracks_context* t, uint32_t M, uint32_t N) {
 // k_tracks_fill into m0 / m1 (device, room for h_offsets[P] blocks); queued on the stream
 int fill_pairs(mvo_hip_tracks_context* t, uint32_t M, uint32_t N, double* m0, double* m1) {
   const uint32_t P = num_pairs(M, N);
+  t->last_fused = false;
   if (t->h_offsets[P] == 0) return MVO_HIP_OK;
   if (t->profiling) TR_TRY(hipEventRecord(t->ev[2], t->stream));
   hipLaunchKernelGGL(k_tracks_fill, dim3(t->g_groups, M), dim3(64), 0, t->stream, dev_view(t), N, t->g_groups, t->g_sp,
@@ -371,6 +463,39 @@ int fill_pairs(mvo_hip_tracks_context* t, uint32_t M, uint32_t N, double* m0, do
   TR_TRY(hipGetLastError());
   if (t->profiling) {
     TR_TRY(hipEventRecord(t->ev[3], t->stream));
+    t->fill_timed = true;
+  }
+  return MVO_HIP_OK;
+}
+
+// fused gather-and-fold (no loss): per-pair sums straight from the track tables into pair_sums (device,
+// 8 doubles per pair); frames = the solver's device copy of the N frame records.  Queued on the stream.
+int fold_pairs(mvo_hip_tracks_context* t, uint32_t M, uint32_t N, const double* frames, double* pair_sums) {
+  const uint32_t P = num_pairs(M, N);
+  t->last_fused = true;
+  t->last_fill_bytes = t->last_feature_bytes + 28ull * t->last_blocks;  // per block: predecessor index + ray read
+  hipStream_t s = t->stream;
+  if (t->g_groups == 0) {
+    TR_TRY(hipMemsetAsync(pair_sums, 0, sizeof(double) * 8 * P, s));
+    return MVO_HIP_OK;
+  }
+  const size_t part_elems = (size_t)M * t->g_groups * t->g_sp * 8;
+  if (part_elems > t->cap_part) {
+    if (t->d_part) (void)mvo_device_free(t->d_part);
+    t->d_part = nullptr;
+    t->cap_part = 0;
+    TR_TRY(mvo_device_alloc((void**)&t->d_part, sizeof(double) * part_elems));
+    t->cap_part = part_elems;
+  }
+  if (t->profiling) TR_TRY(hipEventRecord(t->ev[2], s));
+  hipLaunchKernelGGL(k_tracks_fold, dim3(t->g_groups, M), dim3(64), 0, s, dev_view(t), N, t->g_groups, t->g_sp, frames,
+                     t->d_part);
+  TR_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_tracks_reduce, dim3(N - 1, M), dim3(256), 0, s, dev_view(t), N, t->g_groups, t->g_sp, t->d_cnt,
+                     t->d_counts, t->d_part, pair_sums);
+  TR_TRY(hipGetLastError());
+  if (t->profiling) {
+    TR_TRY(hipEventRecord(t->ev[3], s));
     t->fill_timed = true;
   }
   return MVO_HIP_OK;
@@ -418,7 +543,7 @@ void mvo_hip_tracks_destroy(mvo_hip_tracks_handle t) {
   (void)hipSetDevice(t->device);
   if (t->stream) (void)hipStreamSynchronize(t->stream);
   void* bufs[] = {t->d_rays, t->d_pre, t->d_counter, t->d_nfeat, t->d_counts, t->d_pre_in, t->d_offsets, t->d_m0, t->d_m1,
-                  t->d_cnt, t->d_rays_in};
+                  t->d_cnt, t->d_rays_in, t->d_part};
   for (void* p : bufs)
     if (p) (void)mvo_device_free(p);
   if (t->h_counts) (void)hipHostFree(t->h_counts);
@@ -526,14 +651,54 @@ int mvo_hip_tracks_refine(mvo_hip_tracks_handle t, mvo_hip_frame* frames, uint32
   obs.pair_offsets = t->h_offsets;
   obs.m0 = placeholder;
   obs.m1 = placeholder;
-  double *m0 = nullptr, *m1 = nullptr;
-  rc = mvo_hip_internal_upload_device_rays(t->solver, frames, M, N, options, &obs, &m0, &m1);
-  if (rc != MVO_HIP_OK) return rc;
-  rc = fill_pairs(t, M, N, m0, m1);  // straight into the solver's ray buffers
-  if (rc != MVO_HIP_OK) return rc;
+  // Without a loss the LM loop reads nothing but 8 sums per pair: they are formed straight from the
+  // tables (k_tracks_fold) and the residual blocks never reach HBM.  With a loss (or per-evaluation
+  // passes) the blocks are gathered into the solver's ray buffers as before.
+  const bool fused = !options->use_loss_function && !(options->assembly_mode & MVO_HIP_ASSEMBLY_PASSES) &&
+                     !std::getenv("MVO_HIP_TRACKS_NO_FUSE");
+  if (fused) {
+    const double* frames_dev = nullptr;
+    double* sums = nullptr;
+    rc = mvo_hip_internal_upload_pair_sums(t->solver, frames, M, N, options, &obs, &frames_dev, &sums);
+    if (rc != MVO_HIP_OK) return rc;
+    rc = fold_pairs(t, M, N, frames_dev, sums);
+    if (rc != MVO_HIP_OK) return rc;
+  } else {
+    double *m0 = nullptr, *m1 = nullptr;
+    rc = mvo_hip_internal_upload_device_rays(t->solver, frames, M, N, options, &obs, &m0, &m1);
+    if (rc != MVO_HIP_OK) return rc;
+    rc = fill_pairs(t, M, N, m0, m1);  // straight into the solver's ray buffers
+    if (rc != MVO_HIP_OK) return rc;
+  }
   rc = mvo_hip_solve(t->solver);
   if (rc != MVO_HIP_OK) return rc;
   return mvo_hip_download(t->solver, frames, summary);
+}
+
+int mvo_hip_tracks_pair_moments(mvo_hip_tracks_handle t, const mvo_hip_frame* frames, uint32_t M, uint32_t N,
+                                double* moments) {
+  if (!t || !frames || !moments) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  int rc = count_pairs(t, M, N);
+  if (rc != MVO_HIP_OK) return rc;
+  const uint32_t P = num_pairs(M, N);
+  hipStream_t s = t->stream;
+  double *d_frames = nullptr, *d_sums = nullptr;
+  TR_TRY(mvo_device_alloc((void**)&d_frames, sizeof(mvo_hip_frame) * N));
+  hipError_t e = mvo_device_alloc((void**)&d_sums, sizeof(double) * 8 * P);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_frames, frames, sizeof(mvo_hip_frame) * N, hipMemcpyHostToDevice, s);
+  std::vector<double> sums(8 * (size_t)P);
+  if (e == hipSuccess) {
+    rc = fold_pairs(t, M, N, d_frames, d_sums);
+    if (rc == MVO_HIP_OK) e = hipMemcpyAsync(sums.data(), d_sums, sizeof(double) * 8 * P, hipMemcpyDeviceToHost, s);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)mvo_device_free(d_frames);
+  if (d_sums) (void)mvo_device_free(d_sums);
+  if (rc != MVO_HIP_OK) return rc;
+  TR_TRY(e);
+  for (uint32_t p = 0; p < P; ++p)
+    for (int v = 0; v < 6; ++v) moments[(size_t)p * 6 + v] = sums[(size_t)p * 8 + v];
+  return MVO_HIP_OK;
 }
 
 int mvo_hip_tracks_scale(mvo_hip_tracks_handle t, mvo_hip_scaler_handle scaler, uint32_t age,

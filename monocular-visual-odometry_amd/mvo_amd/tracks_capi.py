@@ -12,7 +12,7 @@ EXPORTED_SYMBOLS = [
     "mvo_hip_tracks_create", "mvo_hip_tracks_destroy", "mvo_hip_tracks_push", "mvo_hip_tracks_append",
     "mvo_hip_tracks_reset",
     "mvo_hip_tracks_refine", "mvo_hip_tracks_gather", "mvo_hip_tracks_scale", "mvo_hip_tracks_set_profiling",
-    "mvo_hip_tracks_get_timing",
+    "mvo_hip_tracks_get_timing", "mvo_hip_tracks_pair_moments",
 ]
 
 
@@ -39,6 +39,7 @@ def load():
                                             C.c_void_p, C.c_uint64]
         L.mvo_hip_tracks_scale.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(scaler_capi.Input),
                                            C.c_void_p, C.POINTER(scaler_capi.Result)]
+        L.mvo_hip_tracks_pair_moments.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.mvo_hip_tracks_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.mvo_hip_tracks_get_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
         _BOUND = True
@@ -112,6 +113,16 @@ class TrackTable:
             if rc != capi.OK:
                 raise capi.MvoHipError(rc, "mvo_hip_tracks_gather")
         return offs, m0, m1
+
+    def pair_moments(self, frames, M):
+        """S_p of every frame pair summed straight from the tables (the fused gather-and-fold) -> [P, 6]."""
+        frames = np.ascontiguousarray(frames, dtype=np.float64)
+        P = capi.num_pairs(M, len(frames))
+        out = np.zeros((P, 6))
+        rc = self._lib.mvo_hip_tracks_pair_moments(self._h, frames.ctypes.data, int(M), len(frames), out.ctypes.data)
+        if rc != capi.OK:
+            raise capi.MvoHipError(rc, "mvo_hip_tracks_pair_moments")
+        return out
 
     def refine(self, frames, M, options=None):
         """IterativeRefinement::refine on the newest len(frames) keyframes -> (frames_out, Summary)."""

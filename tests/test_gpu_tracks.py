@@ -69,10 +69,52 @@ def test_refine_equals_host_gathered_refine(solver, N, M, L, span, use_loss):
     w2 = scene.Window(N=N, M=M, frames=w.frames, pair_offsets=offs, m0=m0, m1=m1, true_vec=w.true_vec,
                       true_scale=w.true_scale, bearing_observations=w.bearing_observations, meta={})
     exp, es = solver.refine(w2, opt)
-    assert np.array_equal(got, exp)
-    assert gs.iterations == es.iterations and gs.final_cost == es.final_cost and gs.termination == es.termination
+    if use_loss:
+        # the blocks are gathered into the solver's ray buffers: same kernels, same inputs
+        assert np.array_equal(got, exp)
+        assert gs.iterations == es.iterations and gs.final_cost == es.final_cost and gs.termination == es.termination
+    else:
+        # no loss: the per-pair moments are summed straight from the tables (k_tracks_fold), in another
+        # order than k_fold sums the gathered blocks -- rounding apart, the same solve
+        assert gs.iterations == es.iterations and gs.termination == es.termination
+        assert abs(gs.initial_cost - es.initial_cost) <= 1e-12 * es.initial_cost
+        assert abs(gs.final_cost - es.final_cost) <= 1e-9 * es.initial_cost
+        assert np.abs(got - exp).max() < 1e-8
+        # ... and with the fusion switched off it is the very same solve again
+        import os
+        os.environ["MVO_HIP_TRACKS_NO_FUSE"] = "1"
+        try:
+            with tracks_capi.TrackTable(solver, max_frames=N + 3, max_features=max(len(p) for _, p in frames)) as table:
+                _push_all(table, frames)
+                got2, gs2 = table.refine(w.frames, M, opt)
+        finally:
+            del os.environ["MVO_HIP_TRACKS_NO_FUSE"]
+        assert np.array_equal(got2, exp)
+        assert gs2.iterations == es.iterations and gs2.final_cost == es.final_cost
     # and the refinement did its job on the clean scene
     assert gs.final_cost < gs.initial_cost
+
+
+@pytest.mark.parametrize("N,M,L,span", CASES, ids=lambda v: str(v).replace(" ", ""))
+def test_fused_fold_moments(solver, N, M, L, span):
+    """S_p summed straight from the track tables (k_tracks_fold + k_tracks_reduce) against the moments
+    k_fold forms from the host-gathered blocks: 1e-12 of the largest entry (the order of summation
+    differs: feature groups here, chunks of consecutive blocks there)."""
+    w = scene.make_window(N, M, L, seed=4100 + N, span=span, keep_tracks=True)
+    frames = scene.track_frames(w)
+    width = max(len(p) for _, p in frames)
+    with tracks_capi.TrackTable(solver, max_frames=N, max_features=max(width, 1)) as table:
+        _push_all(table, frames)
+        S = table.pair_moments(w.frames, M)
+        offs, m0, m1 = table.gather(M, N)
+    w2 = scene.Window(N=N, M=M, frames=w.frames, pair_offsets=offs, m0=m0, m1=m1, true_vec=w.true_vec,
+                      true_scale=w.true_scale, bearing_observations=w.bearing_observations, meta={})
+    solver.upload([w2])
+    So = solver.pair_moments()
+    assert S.shape == So.shape
+    assert np.abs(S - So).max() <= 1e-12 * max(np.abs(So).max(), 1e-300)
+    empty = np.diff(offs.astype(np.int64)) == 0
+    assert np.all(S[empty] == 0.0)
 
 
 def test_ring_slides_over_a_sequence(solver):

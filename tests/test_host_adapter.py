@@ -92,14 +92,24 @@ def test_track_mirror_equals_host_gathering_adapter(tmp_path, c, use_loss):
     tracks = str(tmp_path / "tracks.bin")
     scene.write_track_file(w, tracks, use_loss_function=use_loss, **FIXED10)
     outs = {}
+    # without a loss mvo_hip_tracks_refine sums the pair moments straight from the tables (other summation
+    # order: rounding-level agreement); with the fusion off it is the same kernels on the same blocks
+    env_nofuse = dict(os.environ, MVO_HIP_TRACKS_NO_FUSE="1")
     for mode in ("gather", "refine", "tracks"):
         outs[mode] = str(tmp_path / f"out_{mode}.bin")
-        subprocess.check_call([EXE, mode, tracks, outs[mode]])
+        subprocess.check_call([EXE, mode, tracks, outs[mode]], env=env_nofuse if mode == "tracks" else None)
     host_csr = _read_csr(open(outs["gather"], "rb").read(), 0)
     host = open(outs["refine"], "rb").read()
     dev = open(outs["tracks"], "rb").read()
     n_res = 32 * w.N + 40  # N x (vec, scale) + mvo_hip_summary
     assert dev[:n_res] == host[:n_res]
+    if not use_loss:
+        fused_out = str(tmp_path / "out_tracks_fused.bin")
+        subprocess.check_call([EXE, "tracks", tracks, fused_out])
+        fused = open(fused_out, "rb").read()
+        a = np.frombuffer(fused, dtype="<f8", count=4 * w.N)
+        b = np.frombuffer(host, dtype="<f8", count=4 * w.N)
+        assert np.abs(a - b).max() < 1e-8
     dev_csr = _read_csr(dev, n_res)
     for got, exp in zip(dev_csr, host_csr):
         assert np.array_equal(got, exp)
