@@ -1108,14 +1108,24 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
   __shared__ double pairbuf[LARGE ? 1 : 64 * 10];  // k_lm<64>: P x 10: T(6) q(3) cost(1)
   __shared__ double inl_sums[LARGE ? 1 : 64 * 8];   // k_lm<64>, inline evaluation: the passes' 8 sums per pair
   const int w = (int)blockIdx.x + prm.win_base, tid = threadIdx.x;
+#ifdef MVO_LM_STAMPS
+  const unsigned long long stamp_entry_ = __builtin_amdgcn_s_memtime();
+#endif
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool wave0 = wv == 0;
   LmState* __restrict__ gst = states + w;
   const bool fresh = prm.fresh != 0;
-  if (!fresh && gst->status != 0) return;  // uniform: every thread reads the same word
   if (fresh && tid == 0) win_status[w] = 0;  // read by k_pass: set again when this window terminates
-  const WinDev win = wins[w];
+  // every window of an upload has the same shape (SolveParams): no table look-up in front of everything,
+  // and the status word comes in with the state image instead of a round trip of its own (a relaunch of
+  // the robust path is one evaluation long: -1.4 k of 7 k prologue cycles at config 4r)
+  WinDev win;
+  win.frame_off = (uint32_t)w * (uint32_t)prm.N;
+  win.pair_off = (uint32_t)w * (uint32_t)prm.P;
+  win.N = (uint32_t)prm.N;
+  win.M = (uint32_t)prm.M;
+  win.P = (uint32_t)prm.P;
   const int M = win.M, N = win.N, P = win.P;
   const int fix = prm.fix_length;
   const int n = fix ? 2 * M : 3 * M;
@@ -1132,6 +1142,7 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
   for (int i = tid; i < MVO_MAXC * MVO_MAXC; i += NT) sh.Hz[i] = 0.0;
   if (tid == 0) sh.hsel = 0;
   __syncthreads();
+  if (sh.st.status != 0) return;  // a window that has terminated (uniform)
   LmRegs r;      // wavefront 0: the solver state, in registers until the launch ends
   int hsel = 0;  // which of {st.H, Hz} holds the ACCEPTED system; between launches it is st.H
   if (wave0) {
@@ -1158,6 +1169,10 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
   if (tid < 16) stamp_lds_[tid] = 0;
   __syncthreads();
   unsigned long long* stamp_acc_ = (w == 0) ? stamp_lds_ : nullptr;
+  if (w == 0 && tid == 0) {  // slot 6: kernel entry -> here (state in, point published)
+    stamp_prev_ = __builtin_amdgcn_s_memtime();
+    stamp_lds_[6] = stamp_prev_ - stamp_entry_;
+  }
 #endif
   bool need_pass = false;
   if (sh.phase == PH_START) {
@@ -1329,6 +1344,7 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
   for (int i = tid; i < (int)(sizeof(LmState) / 8); i += NT)
     reinterpret_cast<double*>(gst)[i] = reinterpret_cast<const double*>(&sh.st)[i];
 #ifdef MVO_LM_STAMPS
+  if (w == 0 && tid == 0) stamp_lds_[7] += __builtin_amdgcn_s_memtime() - stamp_prev_;  // slot 7: last stamp -> state out
   __syncthreads();
   if (w == 0 && tid < 16) mvo_lm_stamps[tid] += stamp_lds_[tid];
 #endif
