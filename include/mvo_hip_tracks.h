@@ -25,7 +25,10 @@ extern "C" {
 typedef struct mvo_hip_tracks_context *mvo_hip_tracks_handle;
 
 /* The table is a ring of max_frames keyframes with at most max_features features each, bound to
- * `solver` (its device and stream; the solver must outlive the table). */
+ * `solver` (its device and stream; the solver must outlive the table).  HBM per cell: 24 B unit ray,
+ * 4 B predecessor, 4 B counter and 16 B of skip links (the track's feature 16 / 32 / 64 / 128 keyframes
+ * back, derived at push; they let the gather start anywhere along a track after at most four lookups
+ * instead of walking up to N - 1 dependent links): 48 B x max_frames x max_features. */
 int mvo_hip_tracks_create(mvo_hip_handle solver, uint32_t max_frames, uint32_t max_features,
                           mvo_hip_tracks_handle *out);
 void mvo_hip_tracks_destroy(mvo_hip_tracks_handle t);

@@ -19,8 +19,12 @@
 //   k_tracks_scan     per frame a and step s: exclusive scan of cnt over the groups (-> the group's
 //                     base rank, in place) and the pair's block count
 //   (host: prefix sum of the P pair counts -> CSR offsets, needed by the solver's tiling anyway)
-//   k_tracks_fill     wavefront per (group, frame a): the chain walk; ranks inside the group by
-//                     ballot; m0 / m1 written straight into the solver's ray buffers
+//   k_tracks_fill     wavefront per (group, frame a, 16-step segment): the chain walk; ranks inside the
+//                     group by ballot; m0 / m1 written straight into the solver's ray buffers
+//   k_tracks_skip     on push: skip links of the new frame (the feature 16 / 32 / 64 / 128 frames back
+//                     along the track), so that a walker can START at step 16 k after at most four
+//                     lookups: the walk is a chain of dependent loads (~0.7 us each from the 256-MB
+//                     cache), and 199 of them in a row were all of k_tracks_fold's 143 us at N = 200
 // All kernels run on the solver's stream; the solve is queued right behind the gather.
 #include "../../include/mvo_hip_tracks.h"
 
@@ -41,10 +45,14 @@
 
 #define TR_THREADS 256
 #define TR_SCAN_GROUPS 16  // k_tracks_scan: 16 wavefronts share the feature groups of one (a, 64 steps)
+#define TR_SEG 16          // steps one walker wavefront takes (k_tracks_fill / k_tracks_fold)
+#define TR_SKIP_LEVELS 4   // skip links of TR_SEG << level frames: 16, 32, 64, 128 (N <= MVO_HIP_MAX_FRAMES = 256)
+static_assert((TR_SEG << TR_SKIP_LEVELS) >= MVO_HIP_MAX_FRAMES, "a segment start must be reachable by the skip levels");
 
 struct TracksDev {
   const double* rays;     // [max_frames][max_features][3], unit length
   const int32_t* pre;     // [max_frames][max_features]
+  const int32_t* skip;    // [max_frames][TR_SKIP_LEVELS][max_features]: the track's feature TR_SEG << level frames back, -1 = none
   const uint32_t* counter;
   const uint32_t* n_feat; // [max_frames]
   uint32_t max_frames, max_features, head;  // slot of the newest frame
@@ -90,6 +98,59 @@ __global__ __launch_bounds__(TR_THREADS) void k_tracks_counter(uint32_t n, const
   rays_out[3 * i] = x * sc;
   rays_out[3 * i + 1] = y * sc;
   rays_out[3 * i + 2] = z * sc;
+}
+
+// Skip links of the frame just pushed (t.head = its slot; n_avail = frames in the ring, this one
+// included).  Level 0 follows TR_SEG predecessor links; level l is two jumps of level l - 1, the second
+// one read from the older frame's own links.  A link over more frames than the ring holds, or than the
+// track is long, is -1.  Every index read is range-checked before it is used as an index again.
+__global__ __launch_bounds__(TR_THREADS) void k_tracks_skip(TracksDev t, uint32_t first, uint32_t n, uint32_t n_avail,
+                                                           int32_t* __restrict__ skip) {
+  const uint32_t i = first + blockIdx.x * TR_THREADS + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t mf = t.max_features, slot0 = t.head;
+  const uint32_t c = t.counter[(size_t)slot0 * mf + i];
+  bool ok = c >= TR_SEG && TR_SEG < n_avail;
+  uint32_t idx = i;
+  if (ok) {
+    for (uint32_t s = 0; s < TR_SEG; ++s) {
+      const int32_t v = t.pre[(size_t)tr_slot(t, s) * mf + idx];
+      if ((uint32_t)v >= mf) {
+        ok = false;
+        break;
+      }
+      idx = (uint32_t)v;
+    }
+  }
+  skip[((size_t)slot0 * TR_SKIP_LEVELS) * mf + i] = ok ? (int32_t)idx : -1;
+  for (uint32_t l = 1; l < TR_SKIP_LEVELS; ++l) {
+    const uint32_t jump = (uint32_t)TR_SEG << l;
+    ok = ok && c >= jump && jump < n_avail;
+    if (ok) {
+      const int32_t v = skip[((size_t)tr_slot(t, jump / 2) * TR_SKIP_LEVELS + (l - 1)) * mf + idx];
+      if ((uint32_t)v >= mf) ok = false;
+      else idx = (uint32_t)v;
+    }
+    skip[((size_t)slot0 * TR_SKIP_LEVELS + l) * mf + i] = ok ? (int32_t)idx : -1;
+  }
+}
+
+// index, in frame a + TR_SEG k, of the feature the track of feature i of frame a passes through
+// (k wave-uniform, < 1 << TR_SKIP_LEVELS); -1 when a link is missing
+__device__ __forceinline__ int32_t tr_seek(const TracksDev& t, uint32_t a, uint32_t k, uint32_t i) {
+  int32_t idx = (int32_t)i;
+  uint32_t age = a;
+#pragma unroll
+  for (int l = TR_SKIP_LEVELS - 1; l >= 0; --l) {
+    if ((k >> l) & 1u) {
+      if (idx >= 0) {
+        const int32_t v = t.skip[((size_t)tr_slot(t, age) * TR_SKIP_LEVELS + (uint32_t)l) * t.max_features + (uint32_t)idx];
+        idx = (uint32_t)v < t.max_features ? v : -1;
+      }
+      age += (uint32_t)TR_SEG << l;
+    }
+  }
+  return idx;
 }
 
 // cnt[(a * n_groups + g) * SP + (s - 1)], SP = N - 1 rounded up to 64 (steps beyond N - 1 - a count 0)
@@ -140,8 +201,11 @@ __global__ __launch_bounds__(64 * TR_SCAN_GROUPS) void k_tracks_scan(TracksDev t
   if (w == 0 && s1 < N - 1 - a) counts[tr_pair_start(N, a) + s1] = total;
 }
 
+// grid (groups, M, segments): the wavefront takes the steps seg * blockIdx.z + 1 ... seg * (blockIdx.z + 1)
+// of its 64 features' walks (seg = TR_SEG with skip links, N - 1 and one segment without).  What it writes
+// for a step depends on the step alone, so the split changes no byte of the output.
 __global__ __launch_bounds__(64) void k_tracks_fill(TracksDev t, uint32_t N, uint32_t n_groups, uint32_t SP,
-                                                   const uint32_t* __restrict__ base,
+                                                   uint32_t seg, const uint32_t* __restrict__ base,
                                                    const uint64_t* __restrict__ offsets, double* __restrict__ m0,
                                                    double* __restrict__ m1) {
   const uint32_t g = blockIdx.x, a = blockIdx.y, lane = threadIdx.x;
@@ -149,7 +213,15 @@ __global__ __launch_bounds__(64) void k_tracks_fill(TracksDev t, uint32_t N, uin
   if (g * 64 >= n) return;
   const uint32_t i = g * 64 + lane;
   const bool have = i < n;
-  const uint32_t c = have ? min(t.counter[(size_t)slot_a * t.max_features + i], N - 1 - a) : 0u;
+  const uint32_t s_lo = blockIdx.z * seg;
+  uint32_t c = have ? min(t.counter[(size_t)slot_a * t.max_features + i], N - 1 - a) : 0u;
+  if (c <= s_lo) c = 0;  // nothing to do in this segment
+  if (!__ballot(c != 0)) return;
+  int32_t cur = (int32_t)i;
+  if (s_lo && c) {
+    cur = tr_seek(t, a, blockIdx.z, i);
+    if (cur < 0) c = 0;
+  }
   double r0x = 0.0, r0y = 0.0, r0z = 0.0;
   if (c) {
     const double* __restrict__ r0 = t.rays + ((size_t)slot_a * t.max_features + i) * 3;
@@ -161,14 +233,15 @@ __global__ __launch_bounds__(64) void k_tracks_fill(TracksDev t, uint32_t N, uin
   const uint64_t* __restrict__ orow = offsets + tr_pair_start(N, a);
   const unsigned long long below = (1ull << lane) - 1ull;
   // Frame.hpp:283-289: follow _preFeature; idx is the feature's index in frame a + s - 1
-  uint32_t idx = i;
-  int32_t nxt = c ? t.pre[(size_t)slot_a * t.max_features + i] : -1;
-  for (uint32_t s = 1;; ++s) {
+  uint32_t idx = (uint32_t)cur;
+  int32_t nxt = c ? t.pre[(size_t)tr_slot(t, a + s_lo) * t.max_features + idx] : -1;
+  const uint32_t s_hi = s_lo + seg;
+  for (uint32_t s = s_lo + 1; s <= s_hi; ++s) {
     const bool alive = c >= s;
     const unsigned long long bal = __ballot(alive);
     if (!bal) break;
     if (alive) {
-      idx = (uint32_t)nxt;
+      idx = min((uint32_t)nxt, t.max_features - 1);  // a valid link is in range; the clamp only keeps a broken table from faulting
       const size_t cell = (size_t)tr_slot(t, a + s) * t.max_features + idx;
       const double* __restrict__ r1 = t.rays + cell * 3;
       const double x = r1[0], y = r1[1], z = r1[2];
@@ -190,14 +263,25 @@ __global__ __launch_bounds__(64) void k_tracks_fill(TracksDev t, uint32_t N, uin
 // wavefront (wave_reduce8), parked in `part`; k_tracks_reduce adds the groups up in group order into the
 // solver's per-pair sums, which is all k_lm reads without a loss.  The residual blocks never exist in HBM.
 // part[((a * n_groups + g) * SP + s - 1) * 8 + v]
+// grid (groups, M, segments) as k_tracks_fill: a step's partial sum is formed by the same 64 lanes in the
+// same order whichever wavefront takes the step.
 __global__ __launch_bounds__(64) void k_tracks_fold(TracksDev t, uint32_t N, uint32_t n_groups, uint32_t SP,
-                                                   const double* __restrict__ frames, double* __restrict__ part) {
+                                                   uint32_t seg, const double* __restrict__ frames,
+                                                   double* __restrict__ part) {
   const uint32_t g = blockIdx.x, a = blockIdx.y, lane = threadIdx.x;
   const uint32_t slot_a = tr_slot(t, a), n = t.n_feat[slot_a];
   if (g * 64 >= n) return;
   const uint32_t i = g * 64 + lane;
   const bool have = i < n;
-  const uint32_t c = have ? min(t.counter[(size_t)slot_a * t.max_features + i], N - 1 - a) : 0u;
+  const uint32_t s_lo = blockIdx.z * seg;
+  uint32_t c = have ? min(t.counter[(size_t)slot_a * t.max_features + i], N - 1 - a) : 0u;
+  if (c <= s_lo) c = 0;  // nothing to do in this segment
+  if (!__ballot(c != 0)) return;
+  int32_t cur = (int32_t)i;
+  if (s_lo && c) {
+    cur = tr_seek(t, a, blockIdx.z, i);
+    if (cur < 0) c = 0;
+  }
   double px = 0.0, py = 0.0, pz = 0.0;  // R_a m0 (IterativeRefinement.cpp:172)
   if (c) {
     const double* __restrict__ r0 = t.rays + ((size_t)slot_a * t.max_features + i) * 3;
@@ -208,14 +292,15 @@ __global__ __launch_bounds__(64) void k_tracks_fold(TracksDev t, uint32_t N, uin
     pz = R0[6] * x + R0[7] * y + R0[8] * z;
   }
   double* __restrict__ prow = part + (size_t)(a * n_groups + g) * SP * 8;
-  uint32_t idx = i;
-  int32_t nxt = c ? t.pre[(size_t)slot_a * t.max_features + i] : -1;
-  for (uint32_t s = 1;; ++s) {
+  uint32_t idx = (uint32_t)cur;
+  int32_t nxt = c ? t.pre[(size_t)tr_slot(t, a + s_lo) * t.max_features + idx] : -1;
+  const uint32_t s_hi = s_lo + seg;
+  for (uint32_t s = s_lo + 1; s <= s_hi; ++s) {
     const bool alive = c >= s;
     if (!__ballot(alive)) break;
     double S[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (alive) {
-      idx = (uint32_t)nxt;
+      idx = min((uint32_t)nxt, t.max_features - 1);  // see k_tracks_fill
       const size_t cell = (size_t)tr_slot(t, a + s) * t.max_features + idx;
       const double* __restrict__ r1 = t.rays + cell * 3;
       const double x = r1[0], y = r1[1], z = r1[2];
@@ -332,6 +417,7 @@ struct mvo_hip_tracks_context {
   uint32_t max_frames = 0, max_features = 0, head = 0, n_pushed = 0;
   double* d_rays = nullptr;
   int32_t* d_pre = nullptr;
+  int32_t* d_skip = nullptr;  // [max_frames][TR_SKIP_LEVELS][max_features]
   uint32_t *d_counter = nullptr, *d_nfeat = nullptr, *d_counts = nullptr;
   uint32_t* d_cnt = nullptr;  // [M][n_groups][SP]: per-group counts, then base ranks
   size_t cap_cnt = 0;
@@ -367,10 +453,23 @@ namespace {
 
 uint32_t num_pairs(uint32_t M, uint32_t N) { return M * (N - 1) - (M * (M - 1)) / 2; }
 
+// walkers: TR_SEG steps per wavefront from a skip-link start; MVO_HIP_TRACKS_NO_SKIP (experiments, and the
+// test that both give the same bytes): one wavefront walks the whole chain
+void walk_shape(uint32_t N, uint32_t* seg, uint32_t* n_seg) {
+  if (std::getenv("MVO_HIP_TRACKS_NO_SKIP")) {
+    *seg = N - 1;
+    *n_seg = 1;
+  } else {
+    *seg = TR_SEG;
+    *n_seg = (N - 1 + TR_SEG - 1) / TR_SEG;
+  }
+}
+
 TracksDev dev_view(const mvo_hip_tracks_context* t) {
   TracksDev d;
   d.rays = t->d_rays;
   d.pre = t->d_pre;
+  d.skip = t->d_skip;
   d.counter = t->d_counter;
   d.n_feat = t->d_nfeat;
   d.max_frames = t->max_frames;
@@ -458,8 +557,10 @@ int fill_pairs(mvo_hip_tracks_context* t, uint32_t M, uint32_t N, double* m0, do
   t->last_fused = false;
   if (t->h_offsets[P] == 0) return MVO_HIP_OK;
   if (t->profiling) TR_TRY(hipEventRecord(t->ev[2], t->stream));
-  hipLaunchKernelGGL(k_tracks_fill, dim3(t->g_groups, M), dim3(64), 0, t->stream, dev_view(t), N, t->g_groups, t->g_sp,
-                     t->d_cnt, t->d_offsets, m0, m1);
+  uint32_t seg = 0, n_seg = 0;
+  walk_shape(N, &seg, &n_seg);
+  hipLaunchKernelGGL(k_tracks_fill, dim3(t->g_groups, M, n_seg), dim3(64), 0, t->stream, dev_view(t), N, t->g_groups,
+                     t->g_sp, seg, t->d_cnt, t->d_offsets, m0, m1);
   TR_TRY(hipGetLastError());
   if (t->profiling) {
     TR_TRY(hipEventRecord(t->ev[3], t->stream));
@@ -488,8 +589,10 @@ int fold_pairs(mvo_hip_tracks_context* t, uint32_t M, uint32_t N, const double* 
     t->cap_part = part_elems;
   }
   if (t->profiling) TR_TRY(hipEventRecord(t->ev[2], s));
-  hipLaunchKernelGGL(k_tracks_fold, dim3(t->g_groups, M), dim3(64), 0, s, dev_view(t), N, t->g_groups, t->g_sp, frames,
-                     t->d_part);
+  uint32_t seg = 0, n_seg = 0;
+  walk_shape(N, &seg, &n_seg);
+  hipLaunchKernelGGL(k_tracks_fold, dim3(t->g_groups, M, n_seg), dim3(64), 0, s, dev_view(t), N, t->g_groups, t->g_sp,
+                     seg, frames, t->d_part);
   TR_TRY(hipGetLastError());
   hipLaunchKernelGGL(k_tracks_reduce, dim3(N - 1, M), dim3(256), 0, s, dev_view(t), N, t->g_groups, t->g_sp, t->d_cnt,
                      t->d_counts, t->d_part, pair_sums);
@@ -523,6 +626,7 @@ int mvo_hip_tracks_create(mvo_hip_handle solver, uint32_t max_frames, uint32_t m
   const bool ok = hipSetDevice(t->device) == hipSuccess &&
                   mvo_device_alloc((void**)&t->d_rays, sizeof(double) * 3 * cells) == hipSuccess &&
                   mvo_device_alloc((void**)&t->d_pre, sizeof(int32_t) * cells) == hipSuccess &&
+                  mvo_device_alloc((void**)&t->d_skip, sizeof(int32_t) * TR_SKIP_LEVELS * cells) == hipSuccess &&
                   mvo_device_alloc((void**)&t->d_counter, sizeof(uint32_t) * cells) == hipSuccess &&
                   mvo_device_alloc((void**)&t->d_pre_in, sizeof(int32_t) * max_features) == hipSuccess &&
                   mvo_device_alloc((void**)&t->d_rays_in, sizeof(double) * 3 * max_features) == hipSuccess &&
@@ -542,7 +646,7 @@ void mvo_hip_tracks_destroy(mvo_hip_tracks_handle t) {
   if (!t) return;
   (void)hipSetDevice(t->device);
   if (t->stream) (void)hipStreamSynchronize(t->stream);
-  void* bufs[] = {t->d_rays, t->d_pre, t->d_counter, t->d_nfeat, t->d_counts, t->d_pre_in, t->d_offsets, t->d_m0, t->d_m1,
+  void* bufs[] = {t->d_rays, t->d_pre, t->d_skip, t->d_counter, t->d_nfeat, t->d_counts, t->d_pre_in, t->d_offsets, t->d_m0, t->d_m1,
                   t->d_cnt, t->d_rays_in, t->d_part};
   for (void* p : bufs)
     if (p) (void)mvo_device_free(p);
@@ -579,6 +683,12 @@ int mvo_hip_tracks_push(mvo_hip_tracks_handle t, uint32_t n_features, const doub
                        t->d_rays + (size_t)slot * t->max_features * 3, t->d_pre + (size_t)slot * t->max_features,
                        t->d_counter + (size_t)slot * t->max_features);
     TR_TRY(hipGetLastError());
+    TracksDev d = dev_view(t);
+    d.head = slot;  // the frame being pushed is age 0 for its skip links
+    const uint32_t n_avail = std::min<uint64_t>((uint64_t)t->n_pushed + 1, t->max_frames);
+    hipLaunchKernelGGL(k_tracks_skip, dim3((n_features + TR_THREADS - 1) / TR_THREADS), dim3(TR_THREADS), 0, s, d, 0u,
+                       n_features, n_avail, t->d_skip);
+    TR_TRY(hipGetLastError());
   }
   TR_TRY(hipMemcpyAsync(t->d_nfeat + slot, &n_features, sizeof(uint32_t), hipMemcpyHostToDevice, s));
   TR_TRY(hipStreamSynchronize(s));  // the caller's arrays (and n_features on our stack) may go away
@@ -602,6 +712,10 @@ int mvo_hip_tracks_append(mvo_hip_tracks_handle t, uint32_t n_features, const do
   hipLaunchKernelGGL(k_tracks_counter, dim3((n_features + TR_THREADS - 1) / TR_THREADS), dim3(TR_THREADS), 0, s,
                      n_features, t->d_rays_in, (const int32_t*)nullptr, (const uint32_t*)nullptr, 0u,
                      t->d_rays + cell * 3, t->d_pre + cell, t->d_counter + cell);
+  TR_TRY(hipGetLastError());
+  // new tracks: counter 0, so every skip link comes out -1
+  hipLaunchKernelGGL(k_tracks_skip, dim3((n_features + TR_THREADS - 1) / TR_THREADS), dim3(TR_THREADS), 0, s, dev_view(t),
+                     n_old, n_new, (uint32_t)std::min<uint64_t>(t->n_pushed, t->max_frames), t->d_skip);
   TR_TRY(hipGetLastError());
   TR_TRY(hipMemcpyAsync(t->d_nfeat + slot, &n_new, sizeof(uint32_t), hipMemcpyHostToDevice, s));
   TR_TRY(hipStreamSynchronize(s));

@@ -320,3 +320,65 @@ def test_gather_with_shuffled_feature_order(solver, seed):
         ref, per_ref = sc.scale(inp, np.ascontiguousarray(unit[1][sel]), np.ascontiguousarray(unit[2][p0[sel]]),
                                 np.ascontiguousarray(unit[3][p1[p0[sel]]]))
         assert res.n_tracks == len(sel) > 100 and np.array_equal(per, per_ref) and res.median == ref.median
+
+
+LONG_CASES = [
+    # windows long enough for the skip links of 16 / 32 / 64 / 128 frames (k_tracks_skip) to be followed
+    (40, 5, 300, ("anchored", 2, 40)),
+    (80, 5, 400, ("sliding", 50)),
+    (150, 5, 150, "full"),
+    (200, 4, 300, ("anchored", 2, 200)),   # the shape of configs[3], fewer landmarks
+]
+
+
+@pytest.mark.parametrize("N,M,L,span", LONG_CASES, ids=lambda v: str(v).replace(" ", ""))
+def test_long_windows_follow_skip_links(solver, N, M, L, span):
+    """Walker wavefronts take 16 steps each and start from a skip link; the gather must stay bit-exact
+    against the numpy restatement, and gather and fused moments must be the very bytes the single
+    whole-chain walker (MVO_HIP_TRACKS_NO_SKIP) produces."""
+    import os
+    w = scene.make_window(N, M, L, seed=4700 + N, span=span, keep_tracks=True)
+    frames = scene.track_frames(w)
+    width = max(len(p) for _, p in frames)
+    with tracks_capi.TrackTable(solver, max_frames=N, max_features=max(width, 1)) as table:
+        _push_all(table, frames)
+        offs, m0, m1 = table.gather(M, N)
+        S = table.pair_moments(w.frames, M)
+        os.environ["MVO_HIP_TRACKS_NO_SKIP"] = "1"
+        try:
+            offs1, m01, m11 = table.gather(M, N)
+            S1 = table.pair_moments(w.frames, M)
+        finally:
+            del os.environ["MVO_HIP_TRACKS_NO_SKIP"]
+    eo, e0, e1 = scene.gather_tracks_numpy(frames, M)
+    assert np.array_equal(offs, eo) and np.array_equal(offs1, eo)
+    assert np.array_equal(m0, e0) and np.array_equal(m1, e1)
+    assert np.array_equal(m01, e0) and np.array_equal(m11, e1)
+    assert np.array_equal(S, S1)
+    assert int(offs[-1]) > 0
+
+
+def test_skip_links_in_a_sliding_ring(solver):
+    """90 keyframes through a 70-slot ring, windows of 60: skip links are written at push relative to the
+    frame pushed, must survive the ring wrapping round, and links that would reach beyond the ring are
+    never followed.  A few features are appended to every third keyframe (new tracks: no links)."""
+    w = scene.make_window(90, 3, 250, seed=4777, span=("sliding", 70), keep_tracks=True)
+    frames = scene.track_frames(w)  # oldest first
+    width = max(len(p) for _, p in frames) + 8
+    N, M = 60, 3
+    rng = np.random.default_rng(5)
+    kept = []
+    with tracks_capi.TrackTable(solver, max_frames=70, max_features=width) as ring:
+        for k, (rays, pre) in enumerate(frames):
+            ring.push(rays, pre)
+            if k % 3 == 0:
+                extra = rng.normal(size=(5, 3)) + np.array([0.0, 0.0, 4.0])
+                ring.append(extra)
+                rays = np.concatenate([rays, extra])
+                pre = np.concatenate([pre, -np.ones(5, dtype=pre.dtype)])
+            kept.append((rays, pre))
+            if k + 1 >= N and (k % 7 == 0 or k + 1 == len(frames)):
+                offs, m0, m1 = ring.gather(M, N)
+                eo, e0, e1 = scene.gather_tracks_numpy(kept[k + 1 - N:k + 1], M)
+                assert np.array_equal(offs, eo), k
+                assert np.array_equal(m0, e0) and np.array_equal(m1, e1), k
