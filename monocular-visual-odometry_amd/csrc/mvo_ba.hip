@@ -734,6 +734,101 @@ __device__ __forceinline__ double ba_readlane(double v, int src) {
 __device__ __forceinline__ uint32_t tri(uint32_t i, uint32_t j) { return (i * (i + 1)) / 2 + j; }  // j <= i
 
 
+// Back substitution and step statistics shared by both factorisation kernels.  Lf: the factor, block
+// (ib, jb) at tri(ib, jb) * 36, diagonal blocks zero on and above their diagonal, block row M = the
+// forward-substituted right-hand side (row 0 of each block).
+__device__ __forceinline__ void ba_solve_finish(const BaParams& prm, BaState* __restrict__ st,
+                                                const double* __restrict__ redV, double* __restrict__ poses2,
+                                                double* __restrict__ delta_c, const double* Lf, double* xs,
+                                                const double* dc2, bool bad, double gm, uint32_t M, uint32_t n,
+                                                uint32_t tid) {
+  if (!bad && tid < 64) {
+    // Back substitution L^T x = w (w = row 0 of block row M), block row by block row from the
+    // bottom, by wavefront 0 alone and without any exchange through memory.  Lane l owns components
+    // 3l, 3l+1, 3l+2 in registers: block kb lives in lanes 2kb and 2kb+1, whose values every lane
+    // fetches with v_readlane (wave-uniform lane numbers, compile-time register) and solves the
+    // 6 x 6 unit-triangular tail itself.  The dumped diagonal blocks are zero on and above their
+    // diagonal, so the update y_j -= sum_r L[6kb+r][j] x_r applied to the block's OWN components
+    // leaves exactly x_j in them: one formula for every lane with jb <= kb, no selects, and LDS is
+    // only read (the factor).
+    const uint32_t lane = tid, jb_l = lane >> 1, jr0 = 3 * (lane & 1);
+    const bool mine = 3 * lane < n;  // n = 6 M: a lane owns three components or none
+    double y[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) y[q] = mine ? Lf[(size_t)tri(M, jb_l) * 36 + jr0 + q] : 0.0;
+    for (int kb = (int)M - 1; kb >= 0; --kb) {
+      const double* __restrict__ l = Lf + (size_t)tri(kb, kb) * 36;  // unit lower block: l[6 r + c], r > c
+      // every LDS read of the step is issued up front, unconditionally (lanes without work in this
+      // block row read block (kb, 0) and discard the result): one LDS latency per step
+      const bool act = mine && (int)jb_l <= kb;
+      const double* __restrict__ src = Lf + (size_t)tri(kb, act ? jb_l : 0u) * 36 + jr0;  // L[6 kb + r][j] = src[6 r + q]
+      double lt[36], lq[3][6];
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) lq[q][r] = src[6 * r + q];
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int r2 = r + 1; r2 < 6; ++r2) lt[6 * r2 + r] = l[6 * r2 + r];
+      double x[6];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) x[r] = ba_readlane(y[r % 3], 2 * kb + r / 3);
+      // column-oriented: as soon as x[k] is final every row above it takes its product, and the
+      // three y chains advance side by side, newest x first
+      double v[3] = {y[0], y[1], y[2]};
+#pragma unroll
+      for (int k = 5; k >= 0; --k) {
+#pragma unroll
+        for (int r = 0; r < k; ++r) x[r] -= lt[6 * k + r] * x[k];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) v[q] -= lq[q][k] * x[k];
+      }
+#pragma unroll
+      for (int q = 0; q < 3; ++q) y[q] = act ? v[q] : y[q];
+    }
+    if (mine) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) xs[3 * lane + q] = y[q];
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {
+    double mcc = 0.0, s2 = 0.0, xn2 = 0.0;
+    bool nonfinite = false;
+    if (!bad) {
+      for (uint32_t i = tid; i < n; i += 64) {
+        const double dcv = -xs[i];
+        if (!isfinite(dcv)) nonfinite = true;
+        delta_c[i] = dcv;
+        mcc += dcv * (dc2[i] * dcv - redV[6 * M + i]);
+        s2 += dcv * dcv;
+      }
+      const int cur = st->cur;
+      if (tid < M) {
+        double d[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) d[q] = -xs[6 * tid + q];
+        const double* in = poses2 + ((size_t)cur * prm.N + tid) * 12;
+        ba_pose_plus(in, d, poses2 + ((size_t)(1 - cur) * prm.N + tid) * 12);
+        xn2 = in[9] * in[9] + in[10] * in[10] + in[11] * in[11];
+      }
+    }
+    mcc = ba_wave_sum(mcc);
+    s2 = ba_wave_sum(s2);
+    xn2 = ba_wave_sum(xn2);
+    const bool any_nonfinite = __any(nonfinite);
+    if (tid == 0) {
+      st->iteration += 1;
+      st->gmax = gm;
+      st->step_bad = (bad || any_nonfinite) ? 1 : 0;
+      st->mcc_c = mcc;
+      st->step2_c = s2;
+      st->xnorm2_c = xn2;
+    }
+  }
+}
+
 __global__ __launch_bounds__(BA_SOLVE_THREADS) void k_ba_solve(BaParams prm, BaState* __restrict__ st,
                                                               const double* __restrict__ redS,
                                                               const double* __restrict__ redV,
@@ -903,92 +998,216 @@ __global__ __launch_bounds__(BA_SOLVE_THREADS) void k_ba_solve(BaParams prm, BaS
   }
   __syncthreads();
   BA_STAMP(6);
-  if (!bad && tid < 64) {
-    // Back substitution L^T x = w (w = row 0 of block row M), block row by block row from the
-    // bottom, by wavefront 0 alone and without any exchange through memory.  Lane l owns components
-    // 3l, 3l+1, 3l+2 in registers: block kb lives in lanes 2kb and 2kb+1, whose values every lane
-    // fetches with v_readlane (wave-uniform lane numbers, compile-time register) and solves the
-    // 6 x 6 unit-triangular tail itself.  The dumped diagonal blocks are zero on and above their
-    // diagonal, so the update y_j -= sum_r L[6kb+r][j] x_r applied to the block's OWN components
-    // leaves exactly x_j in them: one formula for every lane with jb <= kb, no selects, and LDS is
-    // only read (the factor).
-    const uint32_t lane = tid, jb_l = lane >> 1, jr0 = 3 * (lane & 1);
-    const bool mine = 3 * lane < n;  // n = 6 M: a lane owns three components or none
-    double y[3];
-#pragma unroll
-    for (int q = 0; q < 3; ++q) y[q] = mine ? Lf[(size_t)tri(M, jb_l) * 36 + jr0 + q] : 0.0;
-    for (int kb = (int)M - 1; kb >= 0; --kb) {
-      const double* __restrict__ l = Lf + (size_t)tri(kb, kb) * 36;  // unit lower block: l[6 r + c], r > c
-      // every LDS read of the step is issued up front, unconditionally (lanes without work in this
-      // block row read block (kb, 0) and discard the result): one LDS latency per step
-      const bool act = mine && (int)jb_l <= kb;
-      const double* __restrict__ src = Lf + (size_t)tri(kb, act ? jb_l : 0u) * 36 + jr0;  // L[6 kb + r][j] = src[6 r + q]
-      double lt[36], lq[3][6];
-#pragma unroll
-      for (int r = 0; r < 6; ++r)
-#pragma unroll
-        for (int q = 0; q < 3; ++q) lq[q][r] = src[6 * r + q];
-#pragma unroll
-      for (int r = 0; r < 6; ++r)
-#pragma unroll
-        for (int r2 = r + 1; r2 < 6; ++r2) lt[6 * r2 + r] = l[6 * r2 + r];
-      double x[6];
-#pragma unroll
-      for (int r = 0; r < 6; ++r) x[r] = ba_readlane(y[r % 3], 2 * kb + r / 3);
-      // column-oriented: as soon as x[k] is final every row above it takes its product, and the
-      // three y chains advance side by side, newest x first
-      double v[3] = {y[0], y[1], y[2]};
-#pragma unroll
-      for (int k = 5; k >= 0; --k) {
-#pragma unroll
-        for (int r = 0; r < k; ++r) x[r] -= lt[6 * k + r] * x[k];
-#pragma unroll
-        for (int q = 0; q < 3; ++q) v[q] -= lq[q][k] * x[k];
-      }
-#pragma unroll
-      for (int q = 0; q < 3; ++q) y[q] = act ? v[q] : y[q];
-    }
-    if (mine) {
-#pragma unroll
-      for (int q = 0; q < 3; ++q) xs[3 * lane + q] = y[q];
-    }
+  ba_solve_finish(prm, st, redV, poses2, delta_c, Lf, xs, dc2, bad, gm, M, n, tid);
+  BA_STAMP(4);
+#ifdef MVO_BA_STAMPS
+  BA_STAMP(5);
+  if (tid == 0)
+    for (int q = 0; q < 8; ++q) mvo_ba_stamps[q] += ba_acc_[q];
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_ba_solve_mfma: the same block L D L^T with the trailing update on the matrix cores.  The lower
+// triangle of the (6 M + 1) x 6 M system (last row = the right-hand side) lives in 16 x 16
+// v_mfma_f64_16x16x4 accumulator tiles (<= 66 tiles, <= 9 per wavefront, 4 doubles per lane and tile;
+// C layout: column = lane & 15, row = (lane >> 4) + 4 reg).  Per block column kb, two barriers:
+//   (b) every thread of the three row wavefronts factors the 6 x 6 diagonal block for itself (the same
+//       21 numbers, the same arithmetic: no hand-over), thread R solves ROW R of the panel against it
+//       -- X = A l^-T, one row of 6 instead of a block of 6 rows -- and publishes X, -W = -X d^-1 (MFMA
+//       operands, K = 6 padded to 8 with zeros) and the factor's row for the back substitution
+//   (c) every tile that still has active entries takes  C -= W X^T  as two MFMAs, and
+//   (a) the lanes that hold columns of the next panel, 6 kb + 6 .. 6 kb + 11, copy them to LDS
+// f64 MFMA has no higher peak than the vector unit on gfx950 (64 cycles per 16x16x4 = 16 FMA per cycle
+// and SIMD, scripts/exp/mfma_f64_probe.hip); what it saves is the operand traffic and issue slots of
+// the thread-per-block update (2.7 k -> 1.8 k cycles per block column in isolation).  MEASURED IN PLACE
+// (scripts/ba_stamps.py, M = 28): 181 k cycles per call against k_ba_solve's 174 k -- the update falls
+// from 2.7 k to 2.0 k cycles per block column, but handing the panel over through LDS and the per-row
+// solve (2.1 k) cost what the thread-per-block panel did (0.8 k factor + 1.55 k), and decoding the
+// stored blocks into tiles costs 27 k against 11 k.  ba2: 1.83 ms per solve against 1.79.  So
+// k_ba_solve stays the default; this kernel runs with MVO_HIP_BA_SOLVE_MFMA=1 (tests/test_gpu_ba.py
+// holds it to the same parity bar).
+// ---------------------------------------------------------------------------------------------
+typedef double ba_d4 __attribute__((ext_vector_type(4)));
+#define BA_NT16 ((6 * BA_MAXF + 1 + 15) / 16)
+#define BA_TPW ((BA_NT16 * (BA_NT16 + 1) / 2 + BA_SOLVE_THREADS / 64 - 1) / (BA_SOLVE_THREADS / 64))
+
+__global__ __launch_bounds__(BA_SOLVE_THREADS) void k_ba_solve_mfma(BaParams prm, BaState* __restrict__ st,
+                                                                   const double* __restrict__ redS,
+                                                                   const double* __restrict__ redV,
+                                                                   double* __restrict__ poses2,
+                                                                   double* __restrict__ delta_c) {
+  extern __shared__ double Lf[];  // the factor (layout: ba_solve_finish)
+  // MFMA operands, row-major, K along the row: 9 doubles per row so that the 16 rows a quarter-wave
+  // reads fall into distinct banks; entries 6, 7 stay zero
+  __shared__ double Wp[BA_NT16 * 16][9], Xp[BA_NT16 * 16][9];
+  __shared__ double Pan[BA_NT16 * 16][6];
+  __shared__ double xs[6 * BA_MAXF], dc2[6 * BA_MAXF];
+  __shared__ double gmw[BA_SOLVE_THREADS / 64];
+  __shared__ int bad_flag;
+  if (st->status != 0) return;
+  const uint32_t M = prm.M, n = 6 * M, tid = threadIdx.x;
+  const uint32_t lane = tid & 63, wave = tid >> 6;
+  const double radius = st->radius;
+  {
+    double v = tid < n ? fabs(redV[6 * M + tid]) : 0.0;
+    v = ba_wave_max(v);
+    if (lane == 0) gmw[wave] = v;
   }
   __syncthreads();
-  BA_STAMP(4);
-  if (tid < 64) {
-    double mcc = 0.0, s2 = 0.0, xn2 = 0.0;
-    bool nonfinite = false;
-    if (!bad) {
-      for (uint32_t i = tid; i < n; i += 64) {
-        const double dcv = -xs[i];
-        if (!isfinite(dcv)) nonfinite = true;
-        delta_c[i] = dcv;
-        mcc += dcv * (dc2[i] * dcv - redV[6 * M + i]);
-        s2 += dcv * dcv;
-      }
-      const int cur = st->cur;
-      if (tid < M) {
-        double d[6];
+  double gm = redV[18 * M + 1];
 #pragma unroll
-        for (int q = 0; q < 6; ++q) d[q] = -xs[6 * tid + q];
-        const double* in = poses2 + ((size_t)cur * prm.N + tid) * 12;
-        ba_pose_plus(in, d, poses2 + ((size_t)(1 - cur) * prm.N + tid) * 12);
-        xn2 = in[9] * in[9] + in[10] * in[10] + in[11] * in[11];
-      }
-    }
-    mcc = ba_wave_sum(mcc);
-    s2 = ba_wave_sum(s2);
-    xn2 = ba_wave_sum(xn2);
-    const bool any_nonfinite = __any(nonfinite);
+  for (int q = 0; q < BA_SOLVE_THREADS / 64; ++q) gm = fmax(gm, gmw[q]);
+  if (gm <= prm.gtol) {
     if (tid == 0) {
-      st->iteration += 1;
       st->gmax = gm;
-      st->step_bad = (bad || any_nonfinite) ? 1 : 0;
-      st->mcc_c = mcc;
-      st->step2_c = s2;
-      st->xnorm2_c = xn2;
+      st->status = 1;
+      st->termination = 0;
+    }
+    return;
+  }
+#ifdef MVO_BA_STAMPS
+  unsigned long long ba_acc_[16] = {0}, ba_prev_ = __builtin_amdgcn_s_memtime();
+#endif
+  for (uint32_t i = tid; i < BA_NT16 * 16 * 9; i += BA_SOLVE_THREADS) {
+    (&Wp[0][0])[i] = 0.0;
+    (&Xp[0][0])[i] = 0.0;
+  }
+  if (tid < n) dc2[tid] = ba_clamp_diag(redV[12 * M + tid]) / radius;
+  if (tid == 0) bad_flag = 0;
+  // tiles straight from the system as k_ba_reduce left it (upper block triangle, 36 doubles per block,
+  // L2-resident): A[R][Cc] = S[Cc][R] = entry (c, r) of block (jb, ib)
+  const uint32_t NT = (n + 1 + 15) / 16, ntiles = NT * (NT + 1) / 2;
+  ba_d4 acc[BA_TPW];
+  int ti[BA_TPW], tj[BA_TPW];
+#pragma unroll
+  for (int q = 0; q < BA_TPW; ++q) {
+    const uint32_t t = wave + (BA_SOLVE_THREADS / 64) * q;
+    uint32_t i = 0;
+    while ((i + 1) * (i + 2) / 2 <= t) ++i;
+    ti[q] = t < ntiles ? (int)i : -1;
+    tj[q] = (int)(t - i * (i + 1) / 2);
+    const uint32_t Cc = 16 * (uint32_t)tj[q] + (lane & 15);
+    const uint32_t jb = Cc / 6, c = Cc - 6 * jb;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const uint32_t R = 16 * i + (lane >> 4) + 4 * reg;
+      const uint32_t ib = R / 6, r = R - 6 * ib;
+      double v = 0.0;
+      if (ti[q] >= 0) {
+        if (R < n && Cc <= R) {
+          v = redS[(size_t)ba_blk(M, jb, ib) * 36 + 6 * c + r];
+          if (R == Cc) v += ba_clamp_diag(redV[12 * M + R]) / radius;
+        } else if (R == n && Cc < n) {
+          v = redV[Cc];
+        }
+      }
+      acc[q][reg] = v;
     }
   }
+  // panel columns c0n .. c0n + 5 (rows >= c0n) out of tile q into LDS
+  auto extract = [&](int q, uint32_t c0n) {
+    if (16 * (uint32_t)tj[q] > c0n + 5 || 16 * (uint32_t)tj[q] + 15 < c0n) return;  // wave-uniform
+    const uint32_t cc = 16 * (uint32_t)tj[q] + (lane & 15) - c0n;  // wraps for the columns left of the panel
+    if (cc < 6) {
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const uint32_t R = 16 * (uint32_t)ti[q] + (lane >> 4) + 4 * reg;
+        if (R >= c0n && R <= n) Pan[R][cc] = acc[q][reg];
+      }
+    }
+  };
+#pragma unroll
+  for (int q = 0; q < BA_TPW; ++q)
+    if (ti[q] >= 0) extract(q, 0);
+  __syncthreads();
+  BA_STAMP(0);
+  const bool row_wave = wave <= (n >> 6);  // the wavefronts that hold a row thread (tid <= n)
+  for (uint32_t kb = 0; kb < M; ++kb) {
+    const uint32_t c0 = 6 * kb;
+    // (b) l d l^T of the diagonal block, right-looking, in every thread of the row wavefronts (the same
+    // 21 numbers, the same arithmetic: no hand-over); thread R then solves row R of the panel
+    if (row_wave) {
+      double a[36], iv[6];
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c <= r; ++c) a[6 * r + c] = Pan[c0 + r][c];
+      bool ok = true;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const double dcv = a[7 * c];
+        if (!(dcv > 0.0) || isinf(dcv)) ok = false;
+        iv[c] = ba_rcp(dcv);
+        double lc[6], oc[6];
+#pragma unroll
+        for (int r = c + 1; r < 6; ++r) {
+          oc[r] = a[6 * r + c];  // l_rc d_c
+          lc[r] = oc[r] * iv[c];
+          a[6 * r + c] = lc[r];
+        }
+#pragma unroll
+        for (int r = c + 1; r < 6; ++r)
+#pragma unroll
+          for (int q = c + 1; q <= r; ++q) a[6 * r + q] -= lc[r] * oc[q];  // l_rc d_c l_qc
+      }
+      if (!ok) bad_flag = 1;
+      const uint32_t R = tid;
+      if (R >= c0 + 6 && R <= n) {  // X = A l^-T for this row; W = X d^-1
+        double x[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) x[c] = Pan[R][c];
+#pragma unroll
+        for (int p2 = 0; p2 < 5; ++p2)
+#pragma unroll
+          for (int c = p2 + 1; c < 6; ++c) x[c] -= x[p2] * a[6 * c + p2];
+        double* __restrict__ lf = Lf + (size_t)tri(R / 6, kb) * 36 + 6 * (R % 6);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          const double w = x[c] * iv[c];
+          Xp[R][c] = x[c];
+          Wp[R][c] = -w;
+          lf[c] = w;
+        }
+      } else if (R >= c0 && R < c0 + 6) {  // a row of the diagonal block: its strictly lower part is the factor; it is finished
+        const uint32_t r = R - c0;
+        double* __restrict__ lf = Lf + (size_t)tri(kb, kb) * 36 + 6 * r;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          double v = 0.0;  // a[6 r + c] for c < r, by selects: r is a run-time value, a[] lives in registers
+#pragma unroll
+          for (int rr = c + 1; rr < 6; ++rr) v = r == (uint32_t)rr ? a[6 * rr + c] : v;
+          lf[c] = v;
+          Xp[R][c] = 0.0;
+          Wp[R][c] = 0.0;
+        }
+      }
+    }
+    __syncthreads();
+    BA_STAMP(2);
+    if (bad_flag) break;  // uniform
+    // (c) C -= W X^T on every tile that reaches beyond the panel; a tile that holds columns of the NEXT
+    // panel hands them over while it is in registers
+#pragma unroll
+    for (int q = 0; q < BA_TPW; ++q) {
+      if (ti[q] < 0 || 16 * (uint32_t)tj[q] + 15 < c0 + 6) continue;  // wave-uniform; ti >= tj covers the rows
+      const double* __restrict__ wr = Wp[16 * ti[q] + (lane & 15)];
+      const double* __restrict__ xr = Xp[16 * tj[q] + (lane & 15)];
+      const double a0 = wr[lane >> 4], a1 = wr[4 + (lane >> 4)];
+      const double b0 = xr[lane >> 4], b1 = xr[4 + (lane >> 4)];
+      acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[q], 0, 0, 0);
+      acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[q], 0, 0, 0);
+      if (kb + 1 < M) extract(q, c0 + 6);
+    }
+    BA_STAMP(3);
+    __syncthreads();
+    BA_STAMP(1);
+  }
+  const bool bad = bad_flag != 0;
+  __syncthreads();
+  BA_STAMP(6);
+  ba_solve_finish(prm, st, redV, poses2, delta_c, Lf, xs, dc2, bad, gm, M, n, tid);
+  BA_STAMP(4);
 #ifdef MVO_BA_STAMPS
   BA_STAMP(5);
   if (tid == 0)
@@ -1447,6 +1666,7 @@ struct mvo_hip_ba_context {
   bool events_ready = false;
   mvo_hip_ba_timing timing{};
   size_t solve_lds = 0;
+  bool solve_mfma = false;  // MVO_HIP_BA_SOLVE_MFMA=1 at upload: k_ba_solve_mfma (measured 3 % slower, kept for the record)
   uint64_t schur_flops = 0;
 };
 
@@ -1644,6 +1864,9 @@ int ba_upload(mvo_hip_ba_context* h, const mvo_hip_ba_pose* poses, uint32_t M, u
   h->solve_lds = sizeof(double) * 36 * ((size_t)(M + 1) * (M + 2) / 2);
   BA_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ba_solve), hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)h->solve_lds));
+  BA_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ba_solve_mfma),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds));
+  h->solve_mfma = std::getenv("MVO_HIP_BA_SOLVE_MFMA") != nullptr;
   h->uploaded = true;
   h->timing.upload_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   return MVO_HIP_OK;
@@ -1666,6 +1889,19 @@ int ba_reset_point(mvo_hip_ba_context* h) {
   BA_TRY(hipMemcpyAsync(h->d_state.p, &h->h_state, sizeof(BaState), hipMemcpyHostToDevice, s));
   BA_TRY(hipStreamSynchronize(s));  // h_state is reused as the read-back target
   return MVO_HIP_OK;
+}
+
+// the camera solve: one workgroup
+hipError_t launch_solve(mvo_hip_ba_context* h, hipStream_t s) {
+  if (h->solve_mfma)
+    hipLaunchKernelGGL(k_ba_solve_mfma, dim3(1), dim3(BA_SOLVE_THREADS), h->solve_lds, s, h->prm,
+                       h->d_state.as<BaState>(), h->d_redS.as<double>(), h->d_redV.as<double>(),
+                       h->d_poses.as<double>(), h->d_delta.as<double>());
+  else
+    hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(BA_SOLVE_THREADS), h->solve_lds, s, h->prm,
+                       h->d_state.as<BaState>(), h->d_redS.as<double>(), h->d_redV.as<double>(),
+                       h->d_poses.as<double>(), h->d_delta.as<double>());
+  return hipGetLastError();
 }
 
 hipError_t launch_schur(mvo_hip_ba_context* h, double radius_override) {
@@ -1774,10 +2010,7 @@ int ba_partial_linearize(mvo_hip_ba_context* h) {
 int ba_partial_solve(mvo_hip_ba_context* h) {
   if (!h->uploaded) return MVO_HIP_ERR_STATE;
   BA_TRY(hipSetDevice(h->device));
-  hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(BA_SOLVE_THREADS), h->solve_lds, h->stream, h->prm,
-                     h->d_state.as<BaState>(), h->d_redS.as<double>(), h->d_redV.as<double>(),
-                     h->d_poses.as<double>(), h->d_delta.as<double>());
-  BA_TRY(hipGetLastError());
+  BA_TRY(launch_solve(h, h->stream));
   BA_TRY(launch_step_only(h, 1));
   return ba_partial_sum4(h, 1);
 }
@@ -1823,10 +2056,7 @@ int ba_solve(mvo_hip_ba_context* h) {
       BA_TRY(launch_schur(h, 0.0));
       if (timed) BA_TRY(hipEventRecord(h->ev[3 + 2 * n_schur], s));
       ++n_schur;
-      hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(BA_SOLVE_THREADS), h->solve_lds, s, h->prm,
-                         h->d_state.as<BaState>(), h->d_redS.as<double>(), h->d_redV.as<double>(),
-                         h->d_poses.as<double>(), h->d_delta.as<double>());
-      BA_TRY(hipGetLastError());
+      BA_TRY(launch_solve(h, s));
       BA_TRY(launch_step(h, 1));
     }
     issued += n;

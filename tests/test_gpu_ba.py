@@ -143,3 +143,29 @@ def test_non_finite_observation_ends_as_failure_like_the_oracle(ba):
     poses, X, s = ba.refine(good, ba_capi.make_options(**kw))
     po, Xo, so, _ = bo.refine(good, bo.make_options(**kw))
     assert s.termination == so.termination and np.abs(poses - po).max() < 1e-6
+
+
+@pytest.mark.parametrize("name", ["one_free_frame", "tiny_all_visible", "config1", "spans_28_free", "mostly_fixed"])
+def test_mfma_factorisation_gives_the_same_solve(ba, name):
+    """k_ba_solve_mfma (MVO_HIP_BA_SOLVE_MFMA=1, read at upload: the block L D L^T with its trailing
+    update on v_mfma_f64_16x16x4 -- measured slower than the thread-per-block kernel, kept for the
+    record) against the default kernel and the self-oracle: same accept/reject sequence, poses 1e-9."""
+    import os
+    sc = SCENES[name]()
+    kw = dict(max_num_iterations=8, loss=1, loss_scale=0.003, **FIXED)
+    poses, X, s = ba.refine(sc, ba_capi.make_options(**kw))
+    os.environ["MVO_HIP_BA_SOLVE_MFMA"] = "1"
+    try:
+        ba.set_trace(64)
+        poses2, X2, s2 = ba.refine(sc, ba_capi.make_options(**kw))
+        tr = ba.trace()
+        ba.set_trace(0)
+    finally:
+        del os.environ["MVO_HIP_BA_SOLVE_MFMA"]
+    po, Xo, so, tro = bo.refine(sc, bo.make_options(**kw))
+    assert s2.iterations == s.iterations == so.iterations and s2.termination == s.termination
+    assert [t.step_is_successful for t in tr] == [t.step_is_successful for t in tro] or \
+        all(abs(b.cost_change) <= 1e-9 * b.cost for a, b in zip(tr, tro) if a.step_is_successful != b.step_is_successful)
+    assert abs(s2.final_cost - s.final_cost) <= 1e-10 * s.final_cost
+    assert np.abs(poses2 - poses).max() < 1e-9 and _rel(X2, X) < 1e-9
+    assert np.abs(poses2 - po).max() < 1e-6 and _rel(X2, Xo) < 1e-6
