@@ -531,7 +531,7 @@ def bench_tracks(args, rank, local_rank, world, barrier, dist, torch):
         "host_gathered_refine_ms_pcie_inclusive": None if host_ms is None else round(host_ms, 5),
         "roofline": {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.workload, gather_kernel),
-                     "kernel": gather_kernel + (" (+ k_tracks_reduce)" if fused else ""), "bytes_per_launch": int(tt["fill_bytes"]),
+                     "kernel": gather_kernel, "bytes_per_launch": int(tt["fill_bytes"]),
                      "avg_launch_us": round(dur * 1e6, 3), "launches_timed": n_prof},
     }
     if rank == 0 and world == 1 and not args.no_cpu:

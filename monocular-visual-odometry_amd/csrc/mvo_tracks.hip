@@ -423,6 +423,9 @@ struct mvo_hip_tracks_context {
   size_t cap_cnt = 0;
   double* d_part = nullptr;   // fused fold: [M][n_groups][SP][8] partial moments
   size_t cap_part = 0;
+  double* d_frames = nullptr;      // fused fold: the window's frame records (it starts before the solver's upload)
+  double* h_frames_pin = nullptr;  // pinned staging for them
+  hipEvent_t ev_counts = nullptr;  // the pair counts have reached h_counts
   double* d_rays_in = nullptr;  // staging of the caller's rays
   uint32_t g_groups = 0, g_sp = 0;  // shape of d_cnt at the last count
   uint32_t* h_total = nullptr;      // pinned: number of three-frame tracks
@@ -478,8 +481,10 @@ TracksDev dev_view(const mvo_hip_tracks_context* t) {
   return d;
 }
 
-// k_tracks_count -> host prefix sum: h_offsets / d_offsets hold the CSR offsets of the P pairs
-int count_pairs(mvo_hip_tracks_context* t, uint32_t M, uint32_t N) {
+// k_tracks_count / k_tracks_scan and the copy of the P pair counts to the host, queued; count_finish waits
+// for that copy alone (an event, not the stream: the fused fold is queued behind it and keeps running
+// while the host builds the solver's tables)
+int count_launch(mvo_hip_tracks_context* t, uint32_t M, uint32_t N) {
   if (M == 0 || N <= M) return MVO_HIP_ERR_INVALID_ARGUMENT;            // IterativeRefinement.cpp:29-30
   if (M > MVO_HIP_MAX_REFINE || N > MVO_HIP_MAX_FRAMES) return MVO_HIP_ERR_UNSUPPORTED;
   if (N > t->n_pushed || N > t->max_frames) return MVO_HIP_ERR_STATE;  // not enough keyframes in the table
@@ -537,7 +542,16 @@ int count_pairs(mvo_hip_tracks_context* t, uint32_t M, uint32_t N) {
     t->count_timed = true;
   }
   TR_TRY(hipMemcpyAsync(t->h_counts, t->d_counts, sizeof(uint32_t) * P, hipMemcpyDeviceToHost, s));
-  TR_TRY(hipStreamSynchronize(s));
+  if (!t->ev_counts) TR_TRY(hipEventCreateWithFlags(&t->ev_counts, hipEventDisableTiming));
+  TR_TRY(hipEventRecord(t->ev_counts, s));
+  return MVO_HIP_OK;
+}
+
+// host prefix sum: h_offsets / d_offsets hold the CSR offsets of the P pairs
+int count_finish(mvo_hip_tracks_context* t, uint32_t M, uint32_t N) {
+  const uint32_t P = num_pairs(M, N);
+  hipStream_t s = t->stream;
+  TR_TRY(hipEventSynchronize(t->ev_counts));
   t->h_offsets[0] = 0;
   for (uint32_t p = 0; p < P; ++p) t->h_offsets[p + 1] = t->h_offsets[p] + t->h_counts[p];
   {  // algorithmic bytes of the fill that follows (include/mvo_hip_tracks.h)
@@ -549,6 +563,11 @@ int count_pairs(mvo_hip_tracks_context* t, uint32_t M, uint32_t N) {
   }
   TR_TRY(hipMemcpyAsync(t->d_offsets, t->h_offsets, sizeof(uint64_t) * (P + 1), hipMemcpyHostToDevice, s));
   return MVO_HIP_OK;
+}
+
+int count_pairs(mvo_hip_tracks_context* t, uint32_t M, uint32_t N) {
+  const int rc = count_launch(t, M, N);
+  return rc != MVO_HIP_OK ? rc : count_finish(t, M, N);
 }
 
 // k_tracks_fill into m0 / m1 (device, room for h_offsets[P] blocks); queued on the stream
@@ -569,17 +588,13 @@ int fill_pairs(mvo_hip_tracks_context* t, uint32_t M, uint32_t N, double* m0, do
   return MVO_HIP_OK;
 }
 
-// fused gather-and-fold (no loss): per-pair sums straight from the track tables into pair_sums (device,
-// 8 doubles per pair); frames = the solver's device copy of the N frame records.  Queued on the stream.
-int fold_pairs(mvo_hip_tracks_context* t, uint32_t M, uint32_t N, const double* frames, double* pair_sums) {
-  const uint32_t P = num_pairs(M, N);
+// fused gather-and-fold (no loss), first half: k_tracks_fold, per (frame a, feature group, step) partial
+// moments straight from the track tables into d_part.  Needs the frame records on the device and the
+// shape count_launch left (g_groups, g_sp) -- not the pair counts: it is queued before the host has them.
+int fold_launch(mvo_hip_tracks_context* t, uint32_t M, uint32_t N, const double* frames) {
   t->last_fused = true;
-  t->last_fill_bytes = t->last_feature_bytes + 28ull * t->last_blocks;  // per block: predecessor index + ray read
   hipStream_t s = t->stream;
-  if (t->g_groups == 0) {
-    TR_TRY(hipMemsetAsync(pair_sums, 0, sizeof(double) * 8 * P, s));
-    return MVO_HIP_OK;
-  }
+  if (t->g_groups == 0) return MVO_HIP_OK;
   const size_t part_elems = (size_t)M * t->g_groups * t->g_sp * 8;
   if (part_elems > t->cap_part) {
     if (t->d_part) (void)mvo_device_free(t->d_part);
@@ -594,13 +609,37 @@ int fold_pairs(mvo_hip_tracks_context* t, uint32_t M, uint32_t N, const double* 
   hipLaunchKernelGGL(k_tracks_fold, dim3(t->g_groups, M, n_seg), dim3(64), 0, s, dev_view(t), N, t->g_groups, t->g_sp,
                      seg, frames, t->d_part);
   TR_TRY(hipGetLastError());
-  hipLaunchKernelGGL(k_tracks_reduce, dim3(N - 1, M), dim3(256), 0, s, dev_view(t), N, t->g_groups, t->g_sp, t->d_cnt,
-                     t->d_counts, t->d_part, pair_sums);
-  TR_TRY(hipGetLastError());
   if (t->profiling) {
     TR_TRY(hipEventRecord(t->ev[3], s));
     t->fill_timed = true;
   }
+  return MVO_HIP_OK;
+}
+
+// second half: k_tracks_reduce adds the groups up into pair_sums (device, 8 doubles per pair); after
+// count_finish (the bytes it reports) and on the stream behind fold_launch
+int reduce_launch(mvo_hip_tracks_context* t, uint32_t M, uint32_t N, double* pair_sums) {
+  const uint32_t P = num_pairs(M, N);
+  t->last_fill_bytes = t->last_feature_bytes + 28ull * t->last_blocks;  // per block: predecessor index + ray read
+  hipStream_t s = t->stream;
+  if (t->g_groups == 0) {
+    TR_TRY(hipMemsetAsync(pair_sums, 0, sizeof(double) * 8 * P, s));
+    return MVO_HIP_OK;
+  }
+  hipLaunchKernelGGL(k_tracks_reduce, dim3(N - 1, M), dim3(256), 0, s, dev_view(t), N, t->g_groups, t->g_sp, t->d_cnt,
+                     t->d_counts, t->d_part, pair_sums);
+  TR_TRY(hipGetLastError());
+  return MVO_HIP_OK;
+}
+
+// the window's frame records on the device, through the pinned staging block
+int stage_frames(mvo_hip_tracks_context* t, const mvo_hip_frame* frames, uint32_t N) {
+  static_assert(sizeof(mvo_hip_frame) == sizeof(double) * MVO_FRAME_DOUBLES, "frame record layout");
+  if (!t->d_frames) TR_TRY(mvo_device_alloc((void**)&t->d_frames, sizeof(mvo_hip_frame) * MVO_HIP_MAX_FRAMES));
+  if (!t->h_frames_pin)
+    TR_TRY(hipHostMalloc((void**)&t->h_frames_pin, sizeof(mvo_hip_frame) * MVO_HIP_MAX_FRAMES, hipHostMallocDefault));
+  std::memcpy(t->h_frames_pin, frames, sizeof(mvo_hip_frame) * N);
+  TR_TRY(hipMemcpyAsync(t->d_frames, t->h_frames_pin, sizeof(mvo_hip_frame) * N, hipMemcpyHostToDevice, t->stream));
   return MVO_HIP_OK;
 }
 
@@ -647,12 +686,14 @@ void mvo_hip_tracks_destroy(mvo_hip_tracks_handle t) {
   (void)hipSetDevice(t->device);
   if (t->stream) (void)hipStreamSynchronize(t->stream);
   void* bufs[] = {t->d_rays, t->d_pre, t->d_skip, t->d_counter, t->d_nfeat, t->d_counts, t->d_pre_in, t->d_offsets, t->d_m0, t->d_m1,
-                  t->d_cnt, t->d_rays_in, t->d_part};
+                  t->d_cnt, t->d_rays_in, t->d_part, t->d_frames};
   for (void* p : bufs)
     if (p) (void)mvo_device_free(p);
   if (t->h_counts) (void)hipHostFree(t->h_counts);
   if (t->h_offsets) (void)hipHostFree(t->h_offsets);
   if (t->h_total) (void)hipHostFree(t->h_total);
+  if (t->h_frames_pin) (void)hipHostFree(t->h_frames_pin);
+  if (t->ev_counts) (void)hipEventDestroy(t->ev_counts);
   if (t->events_ready)
     for (auto& e : t->ev) (void)hipEventDestroy(e);
   delete t;
@@ -756,7 +797,22 @@ int mvo_hip_tracks_gather(mvo_hip_tracks_handle t, uint32_t M, uint32_t N, uint6
 int mvo_hip_tracks_refine(mvo_hip_tracks_handle t, mvo_hip_frame* frames, uint32_t M, uint32_t N,
                           const mvo_hip_options* options, mvo_hip_summary* summary) {
   if (!t || !frames || !options) return MVO_HIP_ERR_INVALID_ARGUMENT;
-  int rc = count_pairs(t, M, N);
+  // Without a loss the LM loop reads nothing but 8 sums per pair: they are formed straight from the
+  // tables (k_tracks_fold) and the residual blocks never reach HBM.  With a loss (or per-evaluation
+  // passes) the blocks are gathered into the solver's ray buffers as before.
+  const bool fused = !options->use_loss_function && !(options->assembly_mode & MVO_HIP_ASSEMBLY_PASSES) &&
+                     !std::getenv("MVO_HIP_TRACKS_NO_FUSE");
+  int rc = count_launch(t, M, N);
+  if (rc != MVO_HIP_OK) return rc;
+  if (fused) {
+    // the fold needs the tables and the frame records only: it runs while the host waits for the pair
+    // counts, sums them up and builds the solver's tables
+    rc = stage_frames(t, frames, N);
+    if (rc != MVO_HIP_OK) return rc;
+    rc = fold_launch(t, M, N, t->d_frames);
+    if (rc != MVO_HIP_OK) return rc;
+  }
+  rc = count_finish(t, M, N);
   if (rc != MVO_HIP_OK) return rc;
   static double placeholder[3] = {0.0, 0.0, 1.0};  // never read: the rays are written on the device
   mvo_hip_observations obs;
@@ -765,17 +821,12 @@ int mvo_hip_tracks_refine(mvo_hip_tracks_handle t, mvo_hip_frame* frames, uint32
   obs.pair_offsets = t->h_offsets;
   obs.m0 = placeholder;
   obs.m1 = placeholder;
-  // Without a loss the LM loop reads nothing but 8 sums per pair: they are formed straight from the
-  // tables (k_tracks_fold) and the residual blocks never reach HBM.  With a loss (or per-evaluation
-  // passes) the blocks are gathered into the solver's ray buffers as before.
-  const bool fused = !options->use_loss_function && !(options->assembly_mode & MVO_HIP_ASSEMBLY_PASSES) &&
-                     !std::getenv("MVO_HIP_TRACKS_NO_FUSE");
   if (fused) {
     const double* frames_dev = nullptr;
     double* sums = nullptr;
     rc = mvo_hip_internal_upload_pair_sums(t->solver, frames, M, N, options, &obs, &frames_dev, &sums);
     if (rc != MVO_HIP_OK) return rc;
-    rc = fold_pairs(t, M, N, frames_dev, sums);
+    rc = reduce_launch(t, M, N, sums);
     if (rc != MVO_HIP_OK) return rc;
   } else {
     double *m0 = nullptr, *m1 = nullptr;
@@ -802,7 +853,8 @@ int mvo_hip_tracks_pair_moments(mvo_hip_tracks_handle t, const mvo_hip_frame* fr
   if (e == hipSuccess) e = hipMemcpyAsync(d_frames, frames, sizeof(mvo_hip_frame) * N, hipMemcpyHostToDevice, s);
   std::vector<double> sums(8 * (size_t)P);
   if (e == hipSuccess) {
-    rc = fold_pairs(t, M, N, d_frames, d_sums);
+    rc = fold_launch(t, M, N, d_frames);
+    if (rc == MVO_HIP_OK) rc = reduce_launch(t, M, N, d_sums);
     if (rc == MVO_HIP_OK) e = hipMemcpyAsync(sums.data(), d_sums, sizeof(double) * 8 * P, hipMemcpyDeviceToHost, s);
   }
   if (e == hipSuccess) e = hipStreamSynchronize(s);
