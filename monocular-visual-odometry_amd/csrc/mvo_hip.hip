@@ -1080,9 +1080,24 @@ int do_solve(mvo_hip_context* h) {
   }
   if (prof) HIP_TRY(hipEventRecord(h->ev[1], s));
   if (h->results_on_host) {
-    // a few windows: k_lm wrote the result records into the pinned mirror itself (and marked each: pad);
-    // no copy command, the done counter is accounted for without being read
-    HIP_TRY(hipStreamSynchronize(s));
+    // a few windows: k_lm wrote the result records into the pinned mirror itself (and marked each: pad,
+    // behind a system-scope release); no copy command, the done counter is accounted for without being
+    // read.  The host polls the marks for up to half a millisecond before it falls back on waiting for
+    // the stream (config 2: 75.9 -> 74.2 us per solve).  What is still queued behind the marks (the
+    // kernel's end) is ordered before anything the next call queues on the same stream.
+    bool seen = false;
+    if (!prof && !std::getenv("MVO_HIP_NO_POLL")) {
+      const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(500);
+      for (uint32_t spins = 0; !seen; ++spins) {
+        seen = true;
+        for (uint32_t w = 0; w < h->W && seen; ++w)
+          seen = __atomic_load_n(&h->h_results[w].pad, __ATOMIC_ACQUIRE) == kResultWritten;
+        if (seen) break;
+        __builtin_ia32_pause();
+        if ((spins & 63u) == 63u && std::chrono::steady_clock::now() > deadline) break;
+      }
+    }
+    if (!seen) HIP_TRY(hipStreamSynchronize(s));
     h->copy_pending = false;
     for (uint32_t w = 0; w < h->W; ++w)
       if (h->h_results[w].pad != kResultWritten) return MVO_HIP_ERR_DEVICE;  // every window must have terminated

@@ -1372,7 +1372,12 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
       res->iterations = st.ntrace - 1;
       res->nsucc = st.nsucc;
       res->nunsucc = st.nunsucc;
-      res->pad = kResultWritten;
+    }
+    // the record may live in pinned host memory, and the host may be polling its mark instead of waiting
+    // for the stream: every field is out (system scope) before the mark is
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    if (lane == 0) {
+      __hip_atomic_store(&res->pad, kResultWritten, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       win_status[w] = 1;
       atomicAdd(done_count, 1);
     }

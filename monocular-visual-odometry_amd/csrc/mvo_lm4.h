@@ -522,7 +522,13 @@ __global__ __launch_bounds__(64) void k_lm4(SolveParams prm, int win_end, int un
       res->iterations = r.ntrace - 1;
       res->nsucc = r.nsucc;
       res->nunsucc = r.nunsucc;
-      res->pad = kResultWritten;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // see k_lm: the record is out before its mark
+  if (row_exists) {
+    if (l == 0) {
+      LmResult* __restrict__ res = results + w_row;
+      __hip_atomic_store(&res->pad, kResultWritten, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       win_status[w_row] = 1;
       atomicAdd(done_count, 1);
     }

@@ -11,6 +11,8 @@
 // tracks.bin (little endian): int32 N, M, maxNumIterations, useLoss, fixLength; double ftol, gtol,
 //   ptol, lowest, highest; per frame: double R[9], vec[3], scale; int32 nfeat; per feature:
 //   double ray[3] (x,y,1 as projectPixelTo3dRay returns), int32 preFeature, int32 preFeatureCounter.
+#include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -90,7 +92,7 @@ bool rd(FILE *f, void *p, std::size_t n) { return std::fread(p, 1, n, f) == n; }
 
 int main(int argc, char **argv) {
   if (argc != 4) {
-    std::fprintf(stderr, "usage: adapter_check gather|refine|tracks <tracks.bin> <out.bin>\n");
+    std::fprintf(stderr, "usage: adapter_check gather|refine|tracks|latency <tracks.bin> <out.bin>\n");
     return 2;
   }
   const std::string mode = argv[1];
@@ -130,6 +132,67 @@ int main(int argc, char **argv) {
     std::fwrite(g.pair_offsets.data(), 8, g.pair_offsets.size(), o);
     std::fwrite(g.m0.data(), 8, g.m0.size(), o);
     std::fwrite(g.m1.data(), 8, g.m1.size(), o);
+  } else if (mode == "latency") {
+    // what the reference's Refiner::stage would wait for per keyframe: the adapter's refine() (host chain
+    // walk + mvo_hip_refine) and mvo_hip_refine alone on the gathered blocks, from C++, median of 300 calls
+    mvo_hip_handle h = 0;
+    int rc = mvo_hip_create(0, 1, N, 0, &h);
+    if (rc != MVO_HIP_OK) return 10 + rc;
+    const std::vector<RefinementFrame> data0 = data;
+    mvo_hip_summary s;
+    std::vector<double> t_all, t_call;
+    for (int it = 0; it < 320 && rc == MVO_HIP_OK; it++) {
+      data = data0;
+      const std::chrono::steady_clock::time_point a = std::chrono::steady_clock::now();
+      rc = mvo_hip_adapter::refine<Vec3>(h, data, M, N, 4, hdr[2], tol[0], tol[1], tol[2], hdr[3] != 0, tol[3], tol[4],
+                                         frames[0], &s);
+      const std::chrono::steady_clock::time_point b = std::chrono::steady_clock::now();
+      if (it >= 20) t_all.push_back(std::chrono::duration<double, std::micro>(b - a).count());
+    }
+    mvo_hip_adapter::GatheredObservations g;
+    mvo_hip_adapter::gather<Vec3>(frames[0], M, N, g);
+    mvo_hip_observations obs;
+    obs.n_pairs = static_cast<uint32_t>(g.pair_offsets.size() - 1);
+    obs.reserved = 0;
+    obs.pair_offsets = g.pair_offsets.data();
+    obs.m0 = g.m0.data();
+    obs.m1 = g.m1.data();
+    mvo_hip_options opt;
+    opt.max_num_iterations = hdr[2];
+    opt.num_threads = 4;
+    opt.function_tolerance = tol[0];
+    opt.gradient_tolerance = tol[1];
+    opt.parameter_tolerance = tol[2];
+    opt.use_loss_function = hdr[3] != 0;
+    opt.fix_length = hdr[4] != 0;
+    opt.lowest_length = tol[3];
+    opt.highest_length = tol[4];
+    opt.assembly_mode = MVO_HIP_ASSEMBLY_AUTO;
+    opt.reserved = 0;
+    std::vector<mvo_hip_frame> fr0(N), fr(N);
+    for (unsigned int i = 0; i < N; i++) {
+      for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) fr0[i].R[3 * r + c] = data0[i].R(r, c);
+      for (int c = 0; c < 3; c++) fr0[i].vec[c] = data0[i].vec[c];
+      fr0[i].scale = data0[i].scale;
+    }
+    for (int it = 0; it < 320 && rc == MVO_HIP_OK; it++) {
+      fr = fr0;
+      const std::chrono::steady_clock::time_point a = std::chrono::steady_clock::now();
+      rc = mvo_hip_refine(h, fr.data(), M, N, &opt, &obs, &s);
+      const std::chrono::steady_clock::time_point b = std::chrono::steady_clock::now();
+      if (it >= 20) t_call.push_back(std::chrono::duration<double, std::micro>(b - a).count());
+    }
+    mvo_hip_destroy(h);
+    if (rc != MVO_HIP_OK) {
+      std::fprintf(stderr, "latency: %s\n", mvo_hip_status_string(rc));
+      return 10 + rc;
+    }
+    std::sort(t_all.begin(), t_all.end());
+    std::sort(t_call.begin(), t_call.end());
+    std::fprintf(o, "adapter refine (gather + mvo_hip_refine): median %.1f us, p90 %.1f us; mvo_hip_refine alone: median %.1f us, p90 %.1f us; %d iterations, %u residual blocks\n",
+                 t_all[t_all.size() / 2], t_all[t_all.size() * 9 / 10], t_call[t_call.size() / 2],
+                 t_call[t_call.size() * 9 / 10], s.iterations, static_cast<unsigned int>(g.m0.size() / 3));
   } else if (mode == "tracks") {
     mvo_hip_handle h = 0;
     int rc = mvo_hip_create(0, 1, N, 0, &h);
