@@ -382,3 +382,30 @@ def test_skip_links_in_a_sliding_ring(solver):
                 eo, e0, e1 = scene.gather_tracks_numpy(kept[k + 1 - N:k + 1], M)
                 assert np.array_equal(offs, eo), k
                 assert np.array_equal(m0, e0) and np.array_equal(m1, e1), k
+
+
+def test_refine_sequence_on_a_sliding_ring_with_changing_shapes(solver):
+    """The fused path queues its fold before the host knows the pair counts and reuses the partial-sum
+    and count tables from call to call: a sequence of refines with changing (M, N) on a ring that keeps
+    sliding must give, every time, what mvo_hip_refine gives on the blocks gathered at that moment."""
+    w = scene.make_window(40, 5, 350, seed=4888, span=("sliding", 25), keep_tracks=True)
+    frames = scene.track_frames(w)  # oldest first
+    width = max(len(p) for _, p in frames)
+    opt = capi.make_options(max_num_iterations=6, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
+    shapes = [(3, 8), (5, 30), (2, 5), (5, 22), (1, 2), (4, 30)]
+    with tracks_capi.TrackTable(solver, max_frames=32, max_features=width) as ring:
+        for k, (rays, pre) in enumerate(frames):
+            ring.push(rays, pre)
+            M, N = shapes[k % len(shapes)]
+            if k + 1 < N:
+                continue
+            # newest-first frame records of the N newest keyframes (any consistent poses do: reuse the window's)
+            fr = w.frames[w.N - 1 - k: w.N - 1 - k + N].copy()
+            got, gs = ring.refine(fr, M, opt)
+            offs, m0, m1 = ring.gather(M, N)
+            w2 = scene.Window(N=N, M=M, frames=fr, pair_offsets=offs, m0=m0, m1=m1, true_vec=w.true_vec[:N],
+                              true_scale=w.true_scale[:N], bearing_observations=0, meta={})
+            exp, es = solver.refine(w2, opt)
+            assert gs.iterations == es.iterations and gs.termination == es.termination, k
+            assert abs(gs.initial_cost - es.initial_cost) <= 1e-12 * max(es.initial_cost, 1e-300), k
+            assert np.abs(got - exp).max() < 1e-8, k
