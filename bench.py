@@ -598,10 +598,26 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libmvo_hip has no CPU fallback")
+    # MVO_BENCH_REHEARSE=1: every rank on GPU 0, gloo for the bench's own bookkeeping collectives -- a
+    # rehearsal of the N > 1 code path (sharding, per-rank workloads, aggregation) on a one-GPU box; the
+    # line it prints says so and is not a measurement of N GPUs.  RCCL needs one GPU per rank.
+    rehearse = world > 1 and os.environ.get("MVO_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+            _tensor = torch.tensor
+
+            def _cpu_tensor(*a, **kw):  # the bookkeeping tensors go through gloo on the host
+                if kw.get("device") == "cuda":
+                    kw["device"] = "cpu"
+                return _tensor(*a, **kw)
+            torch.tensor = _cpu_tensor
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from mvo_amd import capi
 
@@ -718,7 +734,8 @@ def main():
         "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
         "dtype": "f64",
-        "data": "synthetic",
+        "data": "synthetic" if os.environ.get("MVO_BENCH_REHEARSE") != "1" or world == 1
+                else "synthetic; REHEARSAL: all ranks share GPU 0 (MVO_BENCH_REHEARSE=1), not a measurement of N GPUs",
         "config": {"workload": desc, "windows_per_gpu": n_windows, "residual_blocks_per_gpu": blocks,
                    "windows_whole_job": int(job_windows), "residual_blocks_whole_job": int(job_blocks),
                    "bearing_observations_per_gpu": bearings, "pairs_per_window": ws[0].n_pairs,
