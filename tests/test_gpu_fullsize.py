@@ -242,3 +242,29 @@ def test_config3_all_4096_windows_in_one_batch(solver, oracle):
         assert abs(sb[i].final_cost - so.final_cost) <= 1e-8 * so.initial_cost, i
         f1, s1 = solver.refine(ws[i], capi.make_options(**FIXED10))
         assert np.abs(refined(fb[i], 5) - refined(f1, 5)).max() < 1e-6, i
+
+
+@pytest.mark.parametrize("use_loss", [False, True], ids=["noloss", "cauchy"])
+def test_batch_sizes_around_the_dispatch_boundaries(solver, oracle, use_loss):
+    """The library changes kernels and result paths with the number of windows: up to 64 the result records
+    are written into pinned host memory and polled, up to 256 every window gets the four-wavefront kernel,
+    beyond that one wavefront (or a quarter of one) per window; batches of 4+ small windows may take
+    k_lm4.  Every size right at those edges must return, window by window, what the oracle returns."""
+    ws_all = [scene.make_window(6, 3, 40, seed=7000 + i, span="full") for i in range(258)]
+    opt = capi.make_options(use_loss_function=use_loss, **FIXED10)
+    oopt = oracle.make_options(use_loss_function=use_loss, **FIXED10)
+    expect = {}
+    for W in (1, 3, 4, 5, 63, 64, 65, 255, 256, 257, 258):
+        frames, summ = solver.refine_batch(ws_all[:W], opt)
+        assert len(summ) == W
+        for i in sorted({0, W // 2, W - 1}):
+            if i not in expect:
+                fo, so, _ = oracle.refine(ws_all[i], oopt)
+                expect[i] = (refined(fo, 3), so)
+            fo3, so = expect[i]
+            assert np.abs(refined(frames[i], 3) - fo3).max() < 1e-6, (W, i)
+            assert abs(summ[i].final_cost - so.final_cost) <= 1e-9 * so.initial_cost, (W, i)
+            # with tolerances 0 a stalled solve stops when a cost change is exactly 0.0: which iteration that
+            # is depends on rounding, so only runs that reach the cap on both sides are compared on it
+            if so.iterations == 10 and summ[i].iterations == 10:
+                assert summ[i].termination == so.termination, (W, i)
