@@ -1093,7 +1093,9 @@ int do_solve(mvo_hip_context* h) {
         for (uint32_t w = 0; w < h->W && seen; ++w)
           seen = __atomic_load_n(&h->h_results[w].pad, __ATOMIC_ACQUIRE) == kResultWritten;
         if (seen) break;
+#if defined(__x86_64__) || defined(__i386__)
         __builtin_ia32_pause();
+#endif
         if ((spins & 63u) == 63u && std::chrono::steady_clock::now() > deadline) break;
       }
     }
