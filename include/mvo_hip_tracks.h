@@ -84,9 +84,11 @@ int mvo_hip_tracks_scale(mvo_hip_tracks_handle t, mvo_hip_scaler_handle scaler, 
 /* Measurement (off by default): HIP events on the solver's stream around the two gather kernels of
  * the last refine / gather call. */
 typedef struct {
-  double count_seconds;      /* k_tracks_count + k_tracks_scan */
-  double fill_seconds;       /* k_tracks_fill, or k_tracks_fold + k_tracks_reduce when the refine ran fused */
-  uint64_t residual_blocks;  /* gathered by the last call */
+  double count_seconds;      /* k_tracks_count + k_tracks_scan; 0 after a fused refine (no loss): it counts
+                              * nothing and waits for nothing before the solve is queued */
+  double fill_seconds;       /* k_tracks_fill, or k_tracks_fold when the refine ran fused */
+  uint64_t residual_blocks;  /* gathered by the last call; after a fused refine they are counted when this
+                              * record is asked for (once per table state and window shape) */
   uint64_t fill_bytes;       /* algorithmic bytes of that k_tracks_fill launch: 32 B per feature of the M
                               * newest frames (counter, predecessor, ray); per gathered block 4 B of
                               * predecessor index, 24 B of ray read, 2 x 24 B written (fused fold: nothing

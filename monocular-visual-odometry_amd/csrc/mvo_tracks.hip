@@ -276,7 +276,17 @@ __global__ __launch_bounds__(64) void k_tracks_fold(TracksDev t, uint32_t N, uin
   const uint32_t s_lo = blockIdx.z * seg;
   uint32_t c = have ? min(t.counter[(size_t)slot_a * t.max_features + i], N - 1 - a) : 0u;
   if (c <= s_lo) c = 0;  // nothing to do in this segment
-  if (!__ballot(c != 0)) return;
+  double* __restrict__ prow = part + (size_t)(a * n_groups + g) * SP * 8;
+  const uint32_t s_hi = min(s_lo + seg, N - 1 - a);  // the pairs (a, a + s - 1) exist for s <= N - 1 - a
+  // k_tracks_reduce adds up EVERY group's entry of a step: a step no feature of the group reaches is a
+  // stored zero, not a hole (no count pass, no host in front of the fold)
+  auto zero_from = [&](uint32_t s_first) {
+    for (uint32_t s = s_first + (lane >> 3); s <= s_hi; s += 8) prow[(size_t)(s - 1) * 8 + (lane & 7)] = 0.0;
+  };
+  if (!__ballot(c != 0)) {
+    zero_from(s_lo + 1);
+    return;
+  }
   int32_t cur = (int32_t)i;
   if (s_lo && c) {
     cur = tr_seek(t, a, blockIdx.z, i);
@@ -291,13 +301,14 @@ __global__ __launch_bounds__(64) void k_tracks_fold(TracksDev t, uint32_t N, uin
     py = R0[3] * x + R0[4] * y + R0[5] * z;
     pz = R0[6] * x + R0[7] * y + R0[8] * z;
   }
-  double* __restrict__ prow = part + (size_t)(a * n_groups + g) * SP * 8;
   uint32_t idx = (uint32_t)cur;
   int32_t nxt = c ? t.pre[(size_t)tr_slot(t, a + s_lo) * t.max_features + idx] : -1;
-  const uint32_t s_hi = s_lo + seg;
   for (uint32_t s = s_lo + 1; s <= s_hi; ++s) {
     const bool alive = c >= s;
-    if (!__ballot(alive)) break;
+    if (!__ballot(alive)) {
+      zero_from(s);
+      break;
+    }
     double S[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (alive) {
       idx = min((uint32_t)nxt, t.max_features - 1);  // see k_tracks_fill
@@ -322,12 +333,9 @@ __global__ __launch_bounds__(64) void k_tracks_fold(TracksDev t, uint32_t N, uin
   }
 }
 
-// pair (a, s): sum of the groups' partial sums in group order; a group that had no block at step s
-// wrote nothing (base ranks after the scan: an empty group's equals the next one's).
-// grid (N - 1, M), 256 threads = 32 group lanes x 8 values.
+// pair (a, s): sum of the groups' partial sums in group order (k_tracks_fold stored one for every group
+// of the frame, zeros included).  grid (N - 1, M), 256 threads = 32 group lanes x 8 values.
 __global__ __launch_bounds__(256) void k_tracks_reduce(TracksDev t, uint32_t N, uint32_t n_groups, uint32_t SP,
-                                                      const uint32_t* __restrict__ base,
-                                                      const uint32_t* __restrict__ counts,
                                                       const double* __restrict__ part, double* __restrict__ pair_sums) {
   __shared__ double red[32][8];
   const uint32_t s1 = blockIdx.x, a = blockIdx.y;  // s - 1
@@ -335,13 +343,8 @@ __global__ __launch_bounds__(256) void k_tracks_reduce(TracksDev t, uint32_t N, 
   const uint32_t v = threadIdx.x & 7, gl = threadIdx.x >> 3;
   const uint32_t ng = (t.n_feat[tr_slot(t, a)] + 63) / 64;
   const uint32_t p = tr_pair_start(N, a) + s1;
-  const uint32_t total = counts[p];
-  const uint32_t* __restrict__ col = base + (size_t)a * n_groups * SP + s1;
   double acc = 0.0;
-  for (uint32_t g = gl; g < ng; g += 32) {
-    const uint32_t b0 = col[(size_t)g * SP], b1 = g + 1 < ng ? col[(size_t)(g + 1) * SP] : total;
-    if (b1 > b0) acc += part[((size_t)(a * n_groups + g) * SP + s1) * 8 + v];
-  }
+  for (uint32_t g = gl; g < ng; g += 32) acc += part[((size_t)(a * n_groups + g) * SP + s1) * 8 + v];
   red[gl][v] = acc;
   __syncthreads();
   if (gl == 0) {
@@ -426,6 +429,10 @@ struct mvo_hip_tracks_context {
   double* d_frames = nullptr;      // fused fold: the window's frame records (it starts before the solver's upload)
   double* h_frames_pin = nullptr;  // pinned staging for them
   hipEvent_t ev_counts = nullptr;  // the pair counts have reached h_counts
+  // the fused refine counts nothing; residual_blocks of mvo_hip_tracks_get_timing is counted when asked for
+  uint64_t version = 0;            // bumped by push / append / reset
+  uint64_t counted_version = ~0ull;
+  uint32_t counted_M = 0, counted_N = 0, last_M = 0, last_N = 0;
   double* d_rays_in = nullptr;  // staging of the caller's rays
   uint32_t g_groups = 0, g_sp = 0;  // shape of d_cnt at the last count
   uint32_t* h_total = nullptr;      // pinned: number of three-frame tracks
@@ -484,7 +491,8 @@ TracksDev dev_view(const mvo_hip_tracks_context* t) {
 // k_tracks_count / k_tracks_scan and the copy of the P pair counts to the host, queued; count_finish waits
 // for that copy alone (an event, not the stream: the fused fold is queued behind it and keeps running
 // while the host builds the solver's tables)
-int count_launch(mvo_hip_tracks_context* t, uint32_t M, uint32_t N) {
+// argument checks of a window on the table, the pair buffers and the shape of the per-group tables
+int window_shape(mvo_hip_tracks_context* t, uint32_t M, uint32_t N) {
   if (M == 0 || N <= M) return MVO_HIP_ERR_INVALID_ARGUMENT;            // IterativeRefinement.cpp:29-30
   if (M > MVO_HIP_MAX_REFINE || N > MVO_HIP_MAX_FRAMES) return MVO_HIP_ERR_UNSUPPORTED;
   if (N > t->n_pushed || N > t->max_frames) return MVO_HIP_ERR_STATE;  // not enough keyframes in the table
@@ -506,19 +514,32 @@ int count_launch(mvo_hip_tracks_context* t, uint32_t M, uint32_t N) {
     TR_TRY(hipHostMalloc((void**)&t->h_offsets, sizeof(uint64_t) * (P + 1), hipHostMallocDefault));
     t->cap_pairs = P;
   }
-  hipStream_t s = t->stream;
-  t->count_timed = t->fill_timed = false;
+  // feature groups of the widest of the M newest frames; the per-group tables hold [M][groups][SP] entries
+  uint32_t groups = 0;
+  for (uint32_t a = 0; a < M; ++a)
+    groups = std::max(groups, (t->h_nfeat[(t->head + t->max_frames - a) % t->max_frames] + 63) / 64);
+  t->g_groups = groups;
+  t->g_sp = (N - 1 + 63) / 64 * 64;
+  return MVO_HIP_OK;
+}
+
+int ensure_events(mvo_hip_tracks_context* t) {
   if (t->profiling && !t->events_ready) {
     for (auto& e : t->ev) TR_TRY(hipEventCreate(&e));
     t->events_ready = true;
   }
-  // feature groups of the widest of the M newest frames; d_cnt holds [M][groups][SP] counts
-  uint32_t groups = 0;
-  for (uint32_t a = 0; a < M; ++a)
-    groups = std::max(groups, (t->h_nfeat[(t->head + t->max_frames - a) % t->max_frames] + 63) / 64);
-  const uint32_t SP = (N - 1 + 63) / 64 * 64;
-  t->g_groups = groups;
-  t->g_sp = SP;
+  return MVO_HIP_OK;
+}
+
+int count_launch(mvo_hip_tracks_context* t, uint32_t M, uint32_t N) {
+  const int rc_shape = window_shape(t, M, N);
+  if (rc_shape != MVO_HIP_OK) return rc_shape;
+  const uint32_t P = num_pairs(M, N);
+  hipStream_t s = t->stream;
+  t->count_timed = false;
+  const int rc_ev = ensure_events(t);
+  if (rc_ev != MVO_HIP_OK) return rc_ev;
+  const uint32_t groups = t->g_groups, SP = t->g_sp;
   const size_t cnt_elems = (size_t)M * groups * SP;
   if (cnt_elems > t->cap_cnt) {
     if (t->d_cnt) (void)mvo_device_free(t->d_cnt);
@@ -561,6 +582,9 @@ int count_finish(mvo_hip_tracks_context* t, uint32_t M, uint32_t N) {
     t->last_feature_bytes = bytes;
     t->last_fill_bytes = bytes + 76ull * t->last_blocks;
   }
+  t->counted_version = t->version;
+  t->counted_M = M;
+  t->counted_N = N;
   TR_TRY(hipMemcpyAsync(t->d_offsets, t->h_offsets, sizeof(uint64_t) * (P + 1), hipMemcpyHostToDevice, s));
   return MVO_HIP_OK;
 }
@@ -574,6 +598,7 @@ int count_pairs(mvo_hip_tracks_context* t, uint32_t M, uint32_t N) {
 int fill_pairs(mvo_hip_tracks_context* t, uint32_t M, uint32_t N, double* m0, double* m1) {
   const uint32_t P = num_pairs(M, N);
   t->last_fused = false;
+  t->fill_timed = false;
   if (t->h_offsets[P] == 0) return MVO_HIP_OK;
   if (t->profiling) TR_TRY(hipEventRecord(t->ev[2], t->stream));
   uint32_t seg = 0, n_seg = 0;
@@ -589,12 +614,15 @@ int fill_pairs(mvo_hip_tracks_context* t, uint32_t M, uint32_t N, double* m0, do
 }
 
 // fused gather-and-fold (no loss), first half: k_tracks_fold, per (frame a, feature group, step) partial
-// moments straight from the track tables into d_part.  Needs the frame records on the device and the
-// shape count_launch left (g_groups, g_sp) -- not the pair counts: it is queued before the host has them.
+// moments straight from the track tables into d_part.  Needs the tables, the frame records on the device
+// and the shape window_shape left (g_groups, g_sp) -- no counts, nothing from the host.
 int fold_launch(mvo_hip_tracks_context* t, uint32_t M, uint32_t N, const double* frames) {
   t->last_fused = true;
+  t->fill_timed = false;
   hipStream_t s = t->stream;
   if (t->g_groups == 0) return MVO_HIP_OK;
+  const int rc_ev = ensure_events(t);
+  if (rc_ev != MVO_HIP_OK) return rc_ev;
   const size_t part_elems = (size_t)M * t->g_groups * t->g_sp * 8;
   if (part_elems > t->cap_part) {
     if (t->d_part) (void)mvo_device_free(t->d_part);
@@ -616,18 +644,17 @@ int fold_launch(mvo_hip_tracks_context* t, uint32_t M, uint32_t N, const double*
   return MVO_HIP_OK;
 }
 
-// second half: k_tracks_reduce adds the groups up into pair_sums (device, 8 doubles per pair); after
-// count_finish (the bytes it reports) and on the stream behind fold_launch
+// second half: k_tracks_reduce adds the groups up into pair_sums (device, 8 doubles per pair), on the
+// stream behind fold_launch
 int reduce_launch(mvo_hip_tracks_context* t, uint32_t M, uint32_t N, double* pair_sums) {
   const uint32_t P = num_pairs(M, N);
-  t->last_fill_bytes = t->last_feature_bytes + 28ull * t->last_blocks;  // per block: predecessor index + ray read
   hipStream_t s = t->stream;
   if (t->g_groups == 0) {
     TR_TRY(hipMemsetAsync(pair_sums, 0, sizeof(double) * 8 * P, s));
     return MVO_HIP_OK;
   }
-  hipLaunchKernelGGL(k_tracks_reduce, dim3(N - 1, M), dim3(256), 0, s, dev_view(t), N, t->g_groups, t->g_sp, t->d_cnt,
-                     t->d_counts, t->d_part, pair_sums);
+  hipLaunchKernelGGL(k_tracks_reduce, dim3(N - 1, M), dim3(256), 0, s, dev_view(t), N, t->g_groups, t->g_sp, t->d_part,
+                     pair_sums);
   TR_TRY(hipGetLastError());
   return MVO_HIP_OK;
 }
@@ -704,6 +731,7 @@ int mvo_hip_tracks_reset(mvo_hip_tracks_handle t) {
   TR_TRY(hipSetDevice(t->device));
   TR_TRY(hipStreamSynchronize(t->stream));
   t->n_pushed = 0;
+  ++t->version;
   t->head = 0;
   return MVO_HIP_OK;
 }
@@ -736,6 +764,7 @@ int mvo_hip_tracks_push(mvo_hip_tracks_handle t, uint32_t n_features, const doub
   t->h_nfeat[slot] = n_features;
   t->head = slot;
   if (t->n_pushed < 0xFFFFFFFFu) ++t->n_pushed;
+  ++t->version;
   return MVO_HIP_OK;
 }
 
@@ -761,6 +790,7 @@ int mvo_hip_tracks_append(mvo_hip_tracks_handle t, uint32_t n_features, const do
   TR_TRY(hipMemcpyAsync(t->d_nfeat + slot, &n_new, sizeof(uint32_t), hipMemcpyHostToDevice, s));
   TR_TRY(hipStreamSynchronize(s));
   t->h_nfeat[slot] = n_new;
+  ++t->version;
   return MVO_HIP_OK;
 }
 
@@ -798,37 +828,41 @@ int mvo_hip_tracks_refine(mvo_hip_tracks_handle t, mvo_hip_frame* frames, uint32
                           const mvo_hip_options* options, mvo_hip_summary* summary) {
   if (!t || !frames || !options) return MVO_HIP_ERR_INVALID_ARGUMENT;
   // Without a loss the LM loop reads nothing but 8 sums per pair: they are formed straight from the
-  // tables (k_tracks_fold) and the residual blocks never reach HBM.  With a loss (or per-evaluation
-  // passes) the blocks are gathered into the solver's ray buffers as before.
+  // tables (k_tracks_fold) and the residual blocks never reach HBM -- nor are they counted: nothing on
+  // this path waits for the device before the solve is queued.  With a loss (or per-evaluation passes)
+  // the blocks are counted, their offsets summed up on the host, and gathered into the solver's ray
+  // buffers as before.
   const bool fused = !options->use_loss_function && !(options->assembly_mode & MVO_HIP_ASSEMBLY_PASSES) &&
                      !std::getenv("MVO_HIP_TRACKS_NO_FUSE");
-  int rc = count_launch(t, M, N);
-  if (rc != MVO_HIP_OK) return rc;
-  if (fused) {
-    // the fold needs the tables and the frame records only: it runs while the host waits for the pair
-    // counts, sums them up and builds the solver's tables
-    rc = stage_frames(t, frames, N);
-    if (rc != MVO_HIP_OK) return rc;
-    rc = fold_launch(t, M, N, t->d_frames);
-    if (rc != MVO_HIP_OK) return rc;
-  }
-  rc = count_finish(t, M, N);
-  if (rc != MVO_HIP_OK) return rc;
   static double placeholder[3] = {0.0, 0.0, 1.0};  // never read: the rays are written on the device
   mvo_hip_observations obs;
   obs.n_pairs = num_pairs(M, N);
   obs.reserved = 0;
-  obs.pair_offsets = t->h_offsets;
   obs.m0 = placeholder;
   obs.m1 = placeholder;
+  int rc;
   if (fused) {
+    rc = window_shape(t, M, N);
+    if (rc != MVO_HIP_OK) return rc;
+    rc = stage_frames(t, frames, N);
+    if (rc != MVO_HIP_OK) return rc;
+    rc = fold_launch(t, M, N, t->d_frames);
+    if (rc != MVO_HIP_OK) return rc;
+    // the solver is told of no residual blocks: it builds no tile tables and reads the sums it is handed
+    for (uint32_t p = 0; p <= obs.n_pairs; ++p) t->h_offsets[p] = 0;
+    obs.pair_offsets = t->h_offsets;
     const double* frames_dev = nullptr;
     double* sums = nullptr;
     rc = mvo_hip_internal_upload_pair_sums(t->solver, frames, M, N, options, &obs, &frames_dev, &sums);
     if (rc != MVO_HIP_OK) return rc;
     rc = reduce_launch(t, M, N, sums);
     if (rc != MVO_HIP_OK) return rc;
+    t->last_M = M;
+    t->last_N = N;
   } else {
+    rc = count_pairs(t, M, N);
+    if (rc != MVO_HIP_OK) return rc;
+    obs.pair_offsets = t->h_offsets;
     double *m0 = nullptr, *m1 = nullptr;
     rc = mvo_hip_internal_upload_device_rays(t->solver, frames, M, N, options, &obs, &m0, &m1);
     if (rc != MVO_HIP_OK) return rc;
@@ -929,8 +963,19 @@ int mvo_hip_tracks_get_timing(mvo_hip_tracks_handle t, mvo_hip_tracks_timing* ou
     TR_TRY(hipEventElapsedTime(&ms, t->ev[2], t->ev[3]));
     out->fill_seconds = ms * 1e-3;
   }
+  if (t->last_fused && t->last_N != 0 &&
+      (t->counted_version != t->version || t->counted_M != t->last_M || t->counted_N != t->last_N)) {
+    // the fused refine did not count its residual blocks; the caller wants to know: count them now
+    const bool prof = t->profiling;
+    t->profiling = false;  // not part of the refine that was timed
+    const int rc = count_pairs(t, t->last_M, t->last_N);
+    t->profiling = prof;
+    if (rc != MVO_HIP_OK) return rc;
+    TR_TRY(hipStreamSynchronize(t->stream));
+  }
   out->residual_blocks = t->last_blocks;
-  out->fill_bytes = t->last_fill_bytes;
+  out->fill_bytes = t->last_fused ? t->last_feature_bytes + 28ull * t->last_blocks  // per block: predecessor index + ray
+                                  : t->last_fill_bytes;
   return MVO_HIP_OK;
 }
 

@@ -409,3 +409,25 @@ def test_refine_sequence_on_a_sliding_ring_with_changing_shapes(solver):
             assert gs.iterations == es.iterations and gs.termination == es.termination, k
             assert abs(gs.initial_cost - es.initial_cost) <= 1e-12 * max(es.initial_cost, 1e-300), k
             assert np.abs(got - exp).max() < 1e-8, k
+
+
+def test_fused_refine_reports_its_blocks_when_asked(solver):
+    """The fused refine (no loss) neither counts its residual blocks nor waits for the device before the
+    solve is queued; mvo_hip_tracks_get_timing counts them on demand -- the number the gather reports --
+    and again after the table has changed."""
+    w = scene.make_window(12, 4, 300, seed=4901, span=("sliding", 7), keep_tracks=True)
+    frames = scene.track_frames(w)
+    opt = capi.make_options(max_num_iterations=3)
+    with tracks_capi.TrackTable(solver, max_frames=16, max_features=max(len(p) for _, p in frames)) as table:
+        _push_all(table, frames[:-1])
+        table.refine(w.frames[1:], 4, opt)                    # the 11 keyframes pushed so far
+        offs, _, _ = table.gather(4, 11)
+        table.refine(w.frames[1:], 4, opt)
+        tt = table.timing()
+        assert tt["residual_blocks"] == int(offs[-1]) > 0 and tt["count_seconds"] == 0.0
+        assert tt["fill_bytes"] > 28 * tt["residual_blocks"]
+        table.push(*frames[-1])
+        table.refine(w.frames, 4, opt)
+        offs2, _, _ = table.gather(4, 12)
+        table.refine(w.frames, 4, opt)
+        assert table.timing()["residual_blocks"] == int(offs2[-1]) == int(w.pair_offsets[-1])
