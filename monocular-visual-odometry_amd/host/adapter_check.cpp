@@ -183,6 +183,22 @@ int main(int argc, char **argv) {
       const std::chrono::steady_clock::time_point b = std::chrono::steady_clock::now();
       if (it >= 20) t_call.push_back(std::chrono::duration<double, std::micro>(b - a).count());
     }
+    // ... and the same window through the device-resident track tables (TrackMirror::refine)
+    std::vector<double> t_mirror;
+    {
+      std::size_t widest = 1;
+      for (unsigned int i = 0; i < N; i++) widest = frames[i].features.size() > widest ? frames[i].features.size() : widest;
+      mvo_hip_adapter::TrackMirror<Vec3, Frame> mirror;
+      if (rc == MVO_HIP_OK) rc = mirror.create(h, N + 1, static_cast<unsigned int>(widest));
+      for (unsigned int k = N; rc == MVO_HIP_OK && k-- > 0;) rc = mirror.keyframe(frames[k], k + 1 < N ? &frames[k + 1] : 0);
+      for (int it = 0; it < 320 && rc == MVO_HIP_OK; it++) {
+        data = data0;
+        const std::chrono::steady_clock::time_point a = std::chrono::steady_clock::now();
+        rc = mirror.refine(data, M, N, 4, hdr[2], tol[0], tol[1], tol[2], hdr[3] != 0, tol[3], tol[4], hdr[4] != 0, &s);
+        const std::chrono::steady_clock::time_point b = std::chrono::steady_clock::now();
+        if (it >= 20) t_mirror.push_back(std::chrono::duration<double, std::micro>(b - a).count());
+      }
+    }
     mvo_hip_destroy(h);
     if (rc != MVO_HIP_OK) {
       std::fprintf(stderr, "latency: %s\n", mvo_hip_status_string(rc));
@@ -190,9 +206,11 @@ int main(int argc, char **argv) {
     }
     std::sort(t_all.begin(), t_all.end());
     std::sort(t_call.begin(), t_call.end());
-    std::fprintf(o, "adapter refine (gather + mvo_hip_refine): median %.1f us, p90 %.1f us; mvo_hip_refine alone: median %.1f us, p90 %.1f us; %d iterations, %u residual blocks\n",
+    std::sort(t_mirror.begin(), t_mirror.end());
+    std::fprintf(o, "adapter refine (gather + mvo_hip_refine): median %.1f us, p90 %.1f us; mvo_hip_refine alone: median %.1f us, p90 %.1f us; TrackMirror::refine (device-resident tracks): median %.1f us, p90 %.1f us; %d iterations, %u residual blocks\n",
                  t_all[t_all.size() / 2], t_all[t_all.size() * 9 / 10], t_call[t_call.size() / 2],
-                 t_call[t_call.size() * 9 / 10], s.iterations, static_cast<unsigned int>(g.m0.size() / 3));
+                 t_call[t_call.size() * 9 / 10], t_mirror[t_mirror.size() / 2], t_mirror[t_mirror.size() * 9 / 10],
+                 s.iterations, static_cast<unsigned int>(g.m0.size() / 3));
   } else if (mode == "tracks") {
     mvo_hip_handle h = 0;
     int rc = mvo_hip_create(0, 1, N, 0, &h);
