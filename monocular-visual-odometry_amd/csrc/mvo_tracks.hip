@@ -844,10 +844,15 @@ int mvo_hip_tracks_refine(mvo_hip_tracks_handle t, mvo_hip_frame* frames, uint32
   if (fused) {
     rc = window_shape(t, M, N);
     if (rc != MVO_HIP_OK) return rc;
-    rc = stage_frames(t, frames, N);
-    if (rc != MVO_HIP_OK) return rc;
-    rc = fold_launch(t, M, N, t->d_frames);
-    if (rc != MVO_HIP_OK) return rc;
+    // A long fold (many walker wavefronts) is queued first, on a copy of the frame records of its own,
+    // and runs while the host builds the solver's tables; a short one is not worth the second copy.
+    const bool fold_first = (uint64_t)t->g_groups * M * ((N + TR_SEG - 2) / TR_SEG) > 256;
+    if (fold_first) {
+      rc = stage_frames(t, frames, N);
+      if (rc != MVO_HIP_OK) return rc;
+      rc = fold_launch(t, M, N, t->d_frames);
+      if (rc != MVO_HIP_OK) return rc;
+    }
     // the solver is told of no residual blocks: it builds no tile tables and reads the sums it is handed
     for (uint32_t p = 0; p <= obs.n_pairs; ++p) t->h_offsets[p] = 0;
     obs.pair_offsets = t->h_offsets;
@@ -855,6 +860,10 @@ int mvo_hip_tracks_refine(mvo_hip_tracks_handle t, mvo_hip_frame* frames, uint32
     double* sums = nullptr;
     rc = mvo_hip_internal_upload_pair_sums(t->solver, frames, M, N, options, &obs, &frames_dev, &sums);
     if (rc != MVO_HIP_OK) return rc;
+    if (!fold_first) {
+      rc = fold_launch(t, M, N, frames_dev);
+      if (rc != MVO_HIP_OK) return rc;
+    }
     rc = reduce_launch(t, M, N, sums);
     if (rc != MVO_HIP_OK) return rc;
     t->last_M = M;
