@@ -110,23 +110,7 @@ __device__ __forceinline__ double row0_max(double v) {
   return bcast_lane(v, 0);
 }
 
-// ---- 64-lane reductions without LDS (gfx950: v_permlane32_swap / v_permlane16_swap) ------------
-// swap32(a, b): a keeps its lanes 0..31 and receives b's lanes 0..31 in its lanes 32..63; b receives
-// a's lanes 32..63 in its lanes 0..31 and keeps its lanes 32..63.  Hence (a + b) after the swap holds,
-// in lanes 0..31, a(l) + a(l + 32) and, in lanes 32..63, b(l - 32) + b(l): the halving step of a
-// butterfly that trades half of the VALUES for half of the LANES.  swap16 does the same with the odd
-// and even 16-lane rows.
-__device__ __forceinline__ double swap_add32(double a, double b) {
-  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
-  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
-  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
-}
-__device__ __forceinline__ double swap_add16(double a, double b) {
-  const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
-  const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
-  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
-}
-
+// (swap_add32 / swap_add16: mvo_wave.h)
 // 10 values x 64 lanes -> 10 totals.  After the call lane L holds the total of value
 //   v(L) = ((L >> 5) & 1) * 4 + ((L >> 4) & 1) * 2 + ((L >> 3) & 1)        in `t8` (values 0..7) and of
 //   value 8 + ((L >> 5) & 1)                                               in `t2` (values 8, 9),

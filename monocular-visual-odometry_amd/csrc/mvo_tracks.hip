@@ -62,6 +62,11 @@ __device__ __forceinline__ uint32_t tr_slot(const TracksDev& t, uint32_t age) { 
   return (t.head + t.max_frames - age) % t.max_frames;
 }
 
+// slot of the next older keyframe (the ring walked one step back: no division per step)
+__device__ __forceinline__ uint32_t tr_older(const TracksDev& t, uint32_t slot) {
+  return slot ? slot - 1 : t.max_frames - 1;
+}
+
 // index of pair (a, a) in the reference's loop order: for a < M: for b in [a, N-1)
 __host__ __device__ __forceinline__ uint32_t tr_pair_start(uint32_t N, uint32_t a) {
   return a * (N - 1) - (a * (a - 1)) / 2;
@@ -234,15 +239,17 @@ __global__ __launch_bounds__(64) void k_tracks_fill(TracksDev t, uint32_t N, uin
   const unsigned long long below = (1ull << lane) - 1ull;
   // Frame.hpp:283-289: follow _preFeature; idx is the feature's index in frame a + s - 1
   uint32_t idx = (uint32_t)cur;
-  int32_t nxt = c ? t.pre[(size_t)tr_slot(t, a + s_lo) * t.max_features + idx] : -1;
+  uint32_t slot_s = tr_slot(t, a + s_lo);  // wave-uniform: the keyframe the walk stands in
+  int32_t nxt = c ? t.pre[(size_t)slot_s * t.max_features + idx] : -1;
   const uint32_t s_hi = s_lo + seg;
   for (uint32_t s = s_lo + 1; s <= s_hi; ++s) {
     const bool alive = c >= s;
     const unsigned long long bal = __ballot(alive);
     if (!bal) break;
+    slot_s = tr_older(t, slot_s);
     if (alive) {
       idx = min((uint32_t)nxt, t.max_features - 1);  // a valid link is in range; the clamp only keeps a broken table from faulting
-      const size_t cell = (size_t)tr_slot(t, a + s) * t.max_features + idx;
+      const size_t cell = (size_t)slot_s * t.max_features + idx;
       const double* __restrict__ r1 = t.rays + cell * 3;
       const double x = r1[0], y = r1[1], z = r1[2];
       if (c > s) nxt = t.pre[cell];  // in flight together with the ray
@@ -302,17 +309,19 @@ __global__ __launch_bounds__(64) void k_tracks_fold(TracksDev t, uint32_t N, uin
     pz = R0[6] * x + R0[7] * y + R0[8] * z;
   }
   uint32_t idx = (uint32_t)cur;
-  int32_t nxt = c ? t.pre[(size_t)tr_slot(t, a + s_lo) * t.max_features + idx] : -1;
+  uint32_t slot_s = tr_slot(t, a + s_lo);  // wave-uniform: the keyframe the walk stands in
+  int32_t nxt = c ? t.pre[(size_t)slot_s * t.max_features + idx] : -1;
   for (uint32_t s = s_lo + 1; s <= s_hi; ++s) {
     const bool alive = c >= s;
     if (!__ballot(alive)) {
       zero_from(s);
       break;
     }
+    slot_s = tr_older(t, slot_s);
     double S[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (alive) {
       idx = min((uint32_t)nxt, t.max_features - 1);  // see k_tracks_fill
-      const size_t cell = (size_t)tr_slot(t, a + s) * t.max_features + idx;
+      const size_t cell = (size_t)slot_s * t.max_features + idx;
       const double* __restrict__ r1 = t.rays + cell * 3;
       const double x = r1[0], y = r1[1], z = r1[2];
       if (c > s) nxt = t.pre[cell];  // in flight together with the ray

@@ -5,7 +5,7 @@
 
 // ---------------------------------------------------------------------------------------
 // 8 values x 64 lanes -> 8 totals with 7 + 3 exchange steps instead of 8 x 6: every halving step
-// trades half of the values with the partner lane (xor 32, 16 through the LDS crossbar; xor 8 and
+// trades half of the values with the partner lane (xor 32, 16 as v_permlane32/16_swap; xor 8 and
 // the in-group steps through DPP).  On return lane L holds the total of value
 // ((L>>5)&1)*4 + ((L>>4)&1)*2 + ((L>>3)&1), identical in the 8 lanes of its group.
 // Fixed pairing order => bitwise reproducible.
@@ -17,19 +17,33 @@ __device__ __forceinline__ double dpp_mov_f64(double v) {
   return __hiloint2double(hi, lo);
 }
 
+// ---- 64-lane reductions without LDS (gfx950: v_permlane32_swap / v_permlane16_swap) ------------
+// swap32(a, b): a keeps its lanes 0..31 and receives b's lanes 0..31 in its lanes 32..63; b receives
+// a's lanes 32..63 in its lanes 0..31 and keeps its lanes 32..63.  Hence (a + b) after the swap holds,
+// in lanes 0..31, a(l) + a(l + 32) and, in lanes 32..63, b(l - 32) + b(l): the halving step of a
+// butterfly that trades half of the VALUES for half of the LANES.  swap16 does the same with the odd
+// and even 16-lane rows.
+__device__ __forceinline__ double swap_add32(double a, double b) {
+  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ double swap_add16(double a, double b) {
+  const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+
 __device__ __forceinline__ double wave_reduce8(const double (&v)[8], int lane) {
-  const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8;
+  const bool b3 = lane & 8;
   double w4[4], w2[2], w1;
+  // the two halving steps across rows as register swaps (the same operands in the same order as the
+  // shuffle-and-select form they replace -- bit-identical totals --, a third of its instructions and no
+  // trip through the LDS crossbar)
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const double keep = b5 ? v[j + 4] : v[j], send = b5 ? v[j] : v[j + 4];
-    w4[j] = keep + __shfl_xor(send, 32, 64);
-  }
+  for (int j = 0; j < 4; ++j) w4[j] = swap_add32(v[j], v[j + 4]);
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const double keep = b4 ? w4[j + 2] : w4[j], send = b4 ? w4[j] : w4[j + 2];
-    w2[j] = keep + __shfl_xor(send, 16, 64);
-  }
+  for (int j = 0; j < 2; ++j) w2[j] = swap_add16(w4[j], w4[j + 2]);
   {
     const double keep = b3 ? w2[1] : w2[0], send = b3 ? w2[0] : w2[1];
     w1 = keep + dpp_mov_f64<0x128>(send);  // row_ror:8 == lane xor 8
