@@ -149,14 +149,24 @@ __device__ __host__ __forceinline__ uint32_t ba_blk(uint32_t M, uint32_t f, uint
   return f * M - (f * (f - 1)) / 2 + (f2 - f);
 }
 
+// 64-lane butterflies in registers: v_permlane32/16_swap across the rows, DPP inside a row (no trip
+// through the LDS crossbar); every lane ends with the same total
 __device__ __forceinline__ double ba_wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  v = swap_add32(v, v);
+  v = swap_add16(v, v);
+  v += dpp_mov_f64<0x128>(v);  // row_ror:8
+  v += dpp_mov_f64<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov_f64<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov_f64<0x141>(v);  // row_half_mirror
   return v;
 }
 __device__ __forceinline__ double ba_wave_max(double v) {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  for (int o = 32; o > 8; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  v = fmax(v, dpp_mov_f64<0x128>(v));
+  v = fmax(v, dpp_mov_f64<0xB1>(v));
+  v = fmax(v, dpp_mov_f64<0x4E>(v));
+  v = fmax(v, dpp_mov_f64<0x141>(v));
   return v;
 }
 

@@ -15,7 +15,7 @@ _SOURCES = {
     "k_lm4": ["mvo_lm4.h", "mvo_lm.h", "mvo_kernels.h", "mvo_wave.h", "mvo_device.h"],
     "k_lm": ["mvo_lm.h", "mvo_kernels.h", "mvo_wave.h", "mvo_device.h"],
     "k_scaler": ["mvo_scaler.hip", "mvo_wave.h"],
-    "k_tracks": ["mvo_tracks.hip"],
+    "k_tracks": ["mvo_tracks.hip", "mvo_wave.h"],
     "k_ba": ["mvo_ba.hip", "mvo_wave.h"],
     "k_epi": ["mvo_epipolar.hip", "mvo_eig3.h"],
 }
