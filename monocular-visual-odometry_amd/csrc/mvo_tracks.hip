@@ -267,93 +267,103 @@ __global__ __launch_bounds__(64) void k_tracks_fill(TracksDev t, uint32_t N, uin
 // ---- fused gather-and-fold (no loss): the chain walk of k_tracks_fill, but instead of writing the two
 // rays of a residual block (48 B) for k_fold to read back (48 B), the block's c = (R_a m0) x (R_{a+s} m1)
 // is formed on the spot and c c^T summed per (frame a, feature group, step): 6 sums per step and
-// wavefront (wave_reduce8), parked in `part`; k_tracks_reduce adds the groups up in group order into the
-// solver's per-pair sums, which is all k_lm reads without a loss.  The residual blocks never exist in HBM.
-// part[((a * n_groups + g) * SP + s - 1) * 8 + v]
-// grid (groups, M, segments) as k_tracks_fill: a step's partial sum is formed by the same 64 lanes in the
-// same order whichever wavefront takes the step.
-__global__ __launch_bounds__(64) void k_tracks_fold(TracksDev t, uint32_t N, uint32_t n_groups, uint32_t SP,
-                                                   uint32_t seg, const double* __restrict__ frames,
-                                                   double* __restrict__ part) {
-  const uint32_t g = blockIdx.x, a = blockIdx.y, lane = threadIdx.x;
+// wavefront (wave_reduce8), kept in LDS for the segment's steps; at the end the workgroup's four wavefronts
+// (four consecutive feature groups) are added up in group order and parked in `part`; k_tracks_reduce adds
+// the workgroups up in order into the solver's per-pair sums, which is all k_lm reads without a loss.  The
+// residual blocks never exist in HBM.
+// part[((a * n_groups4 + g4) * SP + s - 1) * 8 + v]
+// grid (groups / 4, M, segments): a step's partial sum is formed by the same lanes in the same order
+// whichever wavefront takes the step.
+#define TR_FOLD_WAVES 4  // wavefronts (64-feature groups) per k_tracks_fold workgroup: one stored partial for the four
+__global__ __launch_bounds__(64 * TR_FOLD_WAVES) void k_tracks_fold(TracksDev t, uint32_t N, uint32_t n_groups4,
+                                                                   uint32_t SP, uint32_t seg,
+                                                                   const double* __restrict__ frames,
+                                                                   double* __restrict__ part) {
+  extern __shared__ double lp[];  // [TR_FOLD_WAVES][seg][8]: the wavefronts' partial sums of this segment's steps
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t g = blockIdx.x * TR_FOLD_WAVES + wave, a = blockIdx.y;
   const uint32_t slot_a = tr_slot(t, a), n = t.n_feat[slot_a];
-  if (g * 64 >= n) return;
   const uint32_t i = g * 64 + lane;
   const bool have = i < n;
   const uint32_t s_lo = blockIdx.z * seg;
+  const uint32_t s_hi = min(s_lo + seg, N - 1 - a);  // the pairs (a, a + s - 1) exist for s <= N - 1 - a
+  double* __restrict__ mine = lp + (size_t)wave * seg * 8;
+  // k_tracks_reduce adds up EVERY group's entry of a step: a step no feature of these groups reaches is a
+  // stored zero, not a hole (no count pass, no host in front of the fold)
+  for (uint32_t e = lane; e < seg * 8; e += 64) mine[e] = 0.0;
   uint32_t c = have ? min(t.counter[(size_t)slot_a * t.max_features + i], N - 1 - a) : 0u;
   if (c <= s_lo) c = 0;  // nothing to do in this segment
-  double* __restrict__ prow = part + (size_t)(a * n_groups + g) * SP * 8;
-  const uint32_t s_hi = min(s_lo + seg, N - 1 - a);  // the pairs (a, a + s - 1) exist for s <= N - 1 - a
-  // k_tracks_reduce adds up EVERY group's entry of a step: a step no feature of the group reaches is a
-  // stored zero, not a hole (no count pass, no host in front of the fold)
-  auto zero_from = [&](uint32_t s_first) {
-    for (uint32_t s = s_first + (lane >> 3); s <= s_hi; s += 8) prow[(size_t)(s - 1) * 8 + (lane & 7)] = 0.0;
-  };
-  if (!__ballot(c != 0)) {
-    zero_from(s_lo + 1);
-    return;
-  }
-  int32_t cur = (int32_t)i;
-  if (s_lo && c) {
-    cur = tr_seek(t, a, blockIdx.z, i);
-    if (cur < 0) c = 0;
-  }
-  double px = 0.0, py = 0.0, pz = 0.0;  // R_a m0 (IterativeRefinement.cpp:172)
-  if (c) {
-    const double* __restrict__ r0 = t.rays + ((size_t)slot_a * t.max_features + i) * 3;
-    const double* __restrict__ R0 = frames + (size_t)MVO_FRAME_DOUBLES * a;
-    const double x = r0[0], y = r0[1], z = r0[2];
-    px = R0[0] * x + R0[1] * y + R0[2] * z;
-    py = R0[3] * x + R0[4] * y + R0[5] * z;
-    pz = R0[6] * x + R0[7] * y + R0[8] * z;
-  }
-  uint32_t idx = (uint32_t)cur;
-  uint32_t slot_s = tr_slot(t, a + s_lo);  // wave-uniform: the keyframe the walk stands in
-  int32_t nxt = c ? t.pre[(size_t)slot_s * t.max_features + idx] : -1;
-  for (uint32_t s = s_lo + 1; s <= s_hi; ++s) {
-    const bool alive = c >= s;
-    if (!__ballot(alive)) {
-      zero_from(s);
-      break;
+  if (__ballot(c != 0)) {  // wave-uniform
+    int32_t cur = (int32_t)i;
+    if (s_lo && c) {
+      cur = tr_seek(t, a, blockIdx.z, i);
+      if (cur < 0) c = 0;
     }
-    slot_s = tr_older(t, slot_s);
-    double S[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (alive) {
-      idx = min((uint32_t)nxt, t.max_features - 1);  // see k_tracks_fill
-      const size_t cell = (size_t)slot_s * t.max_features + idx;
-      const double* __restrict__ r1 = t.rays + cell * 3;
-      const double x = r1[0], y = r1[1], z = r1[2];
-      if (c > s) nxt = t.pre[cell];  // in flight together with the ray
-      const double* __restrict__ R1 = frames + (size_t)MVO_FRAME_DOUBLES * (a + s);  // frames[b + 1], IR.cpp:171
-      const double qx = R1[0] * x + R1[1] * y + R1[2] * z;
-      const double qy = R1[3] * x + R1[4] * y + R1[5] * z;
-      const double qz = R1[6] * x + R1[7] * y + R1[8] * z;
-      const double vx = py * qz - pz * qy, vy = pz * qx - px * qz, vz = px * qy - py * qx;
-      S[0] = vx * vx;
-      S[1] = vx * vy;
-      S[2] = vx * vz;
-      S[3] = vy * vy;
-      S[4] = vy * vz;
-      S[5] = vz * vz;
+    double px = 0.0, py = 0.0, pz = 0.0;  // R_a m0 (IterativeRefinement.cpp:172)
+    if (c) {
+      const double* __restrict__ r0 = t.rays + ((size_t)slot_a * t.max_features + i) * 3;
+      const double* __restrict__ R0 = frames + (size_t)MVO_FRAME_DOUBLES * a;
+      const double x = r0[0], y = r0[1], z = r0[2];
+      px = R0[0] * x + R0[1] * y + R0[2] * z;
+      py = R0[3] * x + R0[4] * y + R0[5] * z;
+      pz = R0[6] * x + R0[7] * y + R0[8] * z;
     }
-    const double tot = wave_reduce8(S, (int)lane);
-    if ((lane & 7) == 0) prow[(size_t)(s - 1) * 8 + reduce8_value_of_lane((int)lane)] = tot;
+    uint32_t idx = (uint32_t)cur;
+    uint32_t slot_s = tr_slot(t, a + s_lo);  // wave-uniform: the keyframe the walk stands in
+    int32_t nxt = c ? t.pre[(size_t)slot_s * t.max_features + idx] : -1;
+    for (uint32_t s = s_lo + 1; s <= s_hi; ++s) {
+      const bool alive = c >= s;
+      if (!__ballot(alive)) break;
+      slot_s = tr_older(t, slot_s);
+      double S[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (alive) {
+        idx = min((uint32_t)nxt, t.max_features - 1);  // see k_tracks_fill
+        const size_t cell = (size_t)slot_s * t.max_features + idx;
+        const double* __restrict__ r1 = t.rays + cell * 3;
+        const double x = r1[0], y = r1[1], z = r1[2];
+        if (c > s) nxt = t.pre[cell];  // in flight together with the ray
+        const double* __restrict__ R1 = frames + (size_t)MVO_FRAME_DOUBLES * (a + s);  // frames[b + 1], IR.cpp:171
+        const double qx = R1[0] * x + R1[1] * y + R1[2] * z;
+        const double qy = R1[3] * x + R1[4] * y + R1[5] * z;
+        const double qz = R1[6] * x + R1[7] * y + R1[8] * z;
+        const double vx = py * qz - pz * qy, vy = pz * qx - px * qz, vz = px * qy - py * qx;
+        S[0] = vx * vx;
+        S[1] = vx * vy;
+        S[2] = vx * vz;
+        S[3] = vy * vy;
+        S[4] = vy * vz;
+        S[5] = vz * vz;
+      }
+      const double tot = wave_reduce8(S, (int)lane);
+      if ((lane & 7) == 0) mine[(size_t)(s - 1 - s_lo) * 8 + reduce8_value_of_lane((int)lane)] = tot;
+    }
+  }
+  __syncthreads();
+  // the four wavefronts' partial sums of a step, added in wavefront (= feature group) order: one entry
+  // per workgroup and step
+  double* __restrict__ prow = part + (size_t)(a * n_groups4 + blockIdx.x) * SP * 8;
+  for (uint32_t e = threadIdx.x; e < seg * 8; e += 64 * TR_FOLD_WAVES) {
+    const uint32_t s = s_lo + 1 + (e >> 3);
+    if (s > s_hi) break;
+    double sum = lp[e];
+#pragma unroll
+    for (int w = 1; w < TR_FOLD_WAVES; ++w) sum += lp[(size_t)w * seg * 8 + e];
+    prow[(size_t)(s - 1) * 8 + (e & 7)] = sum;
   }
 }
 
-// pair (a, s): sum of the groups' partial sums in group order (k_tracks_fold stored one for every group
-// of the frame, zeros included).  grid (N - 1, M), 256 threads = 32 group lanes x 8 values.
-__global__ __launch_bounds__(256) void k_tracks_reduce(TracksDev t, uint32_t N, uint32_t n_groups, uint32_t SP,
+// pair (a, s): sum of the workgroups' partial sums in group order (k_tracks_fold stored one for every
+// four feature groups of the frame, zeros included).  grid (N - 1, M), 256 threads = 32 group lanes x 8 values.
+__global__ __launch_bounds__(256) void k_tracks_reduce(TracksDev t, uint32_t N, uint32_t n_groups4, uint32_t SP,
                                                       const double* __restrict__ part, double* __restrict__ pair_sums) {
   __shared__ double red[32][8];
   const uint32_t s1 = blockIdx.x, a = blockIdx.y;  // s - 1
   if (s1 >= N - 1 - a) return;
   const uint32_t v = threadIdx.x & 7, gl = threadIdx.x >> 3;
-  const uint32_t ng = (t.n_feat[tr_slot(t, a)] + 63) / 64;
+  const uint32_t ng = ((t.n_feat[tr_slot(t, a)] + 63) / 64 + TR_FOLD_WAVES - 1) / TR_FOLD_WAVES;
   const uint32_t p = tr_pair_start(N, a) + s1;
   double acc = 0.0;
-  for (uint32_t g = gl; g < ng; g += 32) acc += part[((size_t)(a * n_groups + g) * SP + s1) * 8 + v];
+  for (uint32_t g = gl; g < ng; g += 32) acc += part[((size_t)(a * n_groups4 + g) * SP + s1) * 8 + v];
   red[gl][v] = acc;
   __syncthreads();
   if (gl == 0) {
@@ -632,7 +642,8 @@ int fold_launch(mvo_hip_tracks_context* t, uint32_t M, uint32_t N, const double*
   if (t->g_groups == 0) return MVO_HIP_OK;
   const int rc_ev = ensure_events(t);
   if (rc_ev != MVO_HIP_OK) return rc_ev;
-  const size_t part_elems = (size_t)M * t->g_groups * t->g_sp * 8;
+  const uint32_t groups4 = (t->g_groups + TR_FOLD_WAVES - 1) / TR_FOLD_WAVES;
+  const size_t part_elems = (size_t)M * groups4 * t->g_sp * 8;
   if (part_elems > t->cap_part) {
     if (t->d_part) (void)mvo_device_free(t->d_part);
     t->d_part = nullptr;
@@ -643,8 +654,9 @@ int fold_launch(mvo_hip_tracks_context* t, uint32_t M, uint32_t N, const double*
   if (t->profiling) TR_TRY(hipEventRecord(t->ev[2], s));
   uint32_t seg = 0, n_seg = 0;
   walk_shape(N, &seg, &n_seg);
-  hipLaunchKernelGGL(k_tracks_fold, dim3(t->g_groups, M, n_seg), dim3(64), 0, s, dev_view(t), N, t->g_groups, t->g_sp,
-                     seg, frames, t->d_part);
+  hipLaunchKernelGGL(k_tracks_fold, dim3(groups4, M, n_seg), dim3(64 * TR_FOLD_WAVES),
+                     sizeof(double) * 8 * TR_FOLD_WAVES * seg, s, dev_view(t), N, groups4, t->g_sp, seg, frames,
+                     t->d_part);
   TR_TRY(hipGetLastError());
   if (t->profiling) {
     TR_TRY(hipEventRecord(t->ev[3], s));
@@ -662,8 +674,8 @@ int reduce_launch(mvo_hip_tracks_context* t, uint32_t M, uint32_t N, double* pai
     TR_TRY(hipMemsetAsync(pair_sums, 0, sizeof(double) * 8 * P, s));
     return MVO_HIP_OK;
   }
-  hipLaunchKernelGGL(k_tracks_reduce, dim3(N - 1, M), dim3(256), 0, s, dev_view(t), N, t->g_groups, t->g_sp, t->d_part,
-                     pair_sums);
+  hipLaunchKernelGGL(k_tracks_reduce, dim3(N - 1, M), dim3(256), 0, s, dev_view(t), N,
+                     (t->g_groups + TR_FOLD_WAVES - 1) / TR_FOLD_WAVES, t->g_sp, t->d_part, pair_sums);
   TR_TRY(hipGetLastError());
   return MVO_HIP_OK;
 }
