@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "mvo_eig3.h"
+#include "mvo_wave.h"
 
 __global__ __launch_bounds__(256) void k_epi_hypotheses(uint32_t K, const double* __restrict__ mhi,
                                                        const double* __restrict__ mt,
@@ -136,15 +137,18 @@ __global__ __launch_bounds__(256) void k_epi_score_tiled(uint32_t N, uint32_t K,
         }
     }
   }
+  {
+    // 8 sums and 8 counts over the wavefront as two transposing register butterflies (mvo_wave.h) instead
+    // of 8 x 2 shuffle butterflies through the LDS crossbar; the counts ride as doubles (exact: < 2^53)
+    static_assert(EP_HB == 8, "wave_reduce8 takes the workgroup's eight hypotheses at once");
+    double cd[8];
 #pragma unroll
-  for (int h = 0; h < EP_HB; ++h) {
-    for (int o = 32; o > 0; o >>= 1) {
-      prob[h] += __shfl_xor(prob[h], o, 64);
-      cnt[h] += __shfl_xor(cnt[h], o, 64);
-    }
-    if ((threadIdx.x & 63) == 0) {
-      wp[threadIdx.x >> 6][h] = prob[h];
-      wc[threadIdx.x >> 6][h] = cnt[h];
+    for (int h = 0; h < 8; ++h) cd[h] = (double)cnt[h];
+    const int lane = (int)(threadIdx.x & 63);
+    const double tp = wave_reduce8(prob, lane), tc = wave_reduce8(cd, lane);
+    if ((lane & 7) == 0) {
+      wp[threadIdx.x >> 6][reduce8_value_of_lane(lane)] = tp;
+      wc[threadIdx.x >> 6][reduce8_value_of_lane(lane)] = (uint32_t)tc;
     }
   }
   __syncthreads();

@@ -17,7 +17,7 @@ _SOURCES = {
     "k_scaler": ["mvo_scaler.hip", "mvo_wave.h"],
     "k_tracks": ["mvo_tracks.hip", "mvo_wave.h"],
     "k_ba": ["mvo_ba.hip", "mvo_wave.h"],
-    "k_epi": ["mvo_epipolar.hip", "mvo_eig3.h"],
+    "k_epi": ["mvo_epipolar.hip", "mvo_eig3.h", "mvo_wave.h"],
 }
 
 
