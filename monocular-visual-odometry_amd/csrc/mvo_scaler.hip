@@ -141,7 +141,7 @@ __device__ __forceinline__ void sc_hist_add(uint32_t* lh, uint32_t digit, bool v
   for (int r = 0; r < 2; ++r) {
     if (!todo) break;
     const int leader = __ffsll((long long)todo) - 1;
-    const uint32_t d = (uint32_t)__shfl((int)digit, leader, 64);
+    const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)digit, leader)  /* leader is wave-uniform: no trip through the LDS crossbar */;
     const unsigned long long same = __ballot(valid && digit == d) & todo;
     if (lane == leader) atomicAdd(&lh[d], (uint32_t)__popcll(same));
     todo &= ~same;
@@ -166,7 +166,7 @@ __device__ __forceinline__ void sc_hist_add_rep(uint32_t* lh, uint32_t digit, bo
   unsigned long long todo = __ballot(valid);
   if (todo) {
     const int leader = __ffsll((long long)todo) - 1;
-    const uint32_t d = (uint32_t)__shfl((int)digit, leader, 64);
+    const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)digit, leader)  /* leader is wave-uniform: no trip through the LDS crossbar */;
     const unsigned long long same = __ballot(valid && digit == d);
     if (lane == leader) atomicAdd(&lh[d], (uint32_t)__popcll(same));
     todo &= ~same;
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256) void k_scaler_compact(uint64_t n, const double
         const int leader = __ffsll((long long)bal) - 1;
         uint32_t wpos = 0;
         if (lane == leader) wpos = atomicAdd(&n_stage, (uint32_t)__popcll(bal));
-        wpos = (uint32_t)__shfl((int)wpos, leader, 64);
+        wpos = (uint32_t)__builtin_amdgcn_readlane((int)wpos, leader);
         if (match) stage[wpos + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = k[j];
         sc_hist_add(lh, (uint32_t)((k[j] >> shift) & dm), match);
       }
