@@ -305,10 +305,13 @@ __device__ __forceinline__ void gj_row_update(double (&a)[MVO_MAXC], double f) {
 // Look-ahead order: step J updates column J+1 first and starts the reciprocal of the NEXT pivot
 // (readlane -> v_rcp -> two Newton steps, a ~100-cycle dependent chain) before it touches the
 // remaining columns, whose independent updates then fill that latency.
+// n (wave-uniform): the active rows; the steps from n on would run on identity padding (the reference's
+// shipped window refines two frames: 6 of 15) and are skipped by one scalar branch.
 template <int J>
 __device__ __forceinline__ void gj_eliminate(double (&a)[MVO_MAXC], double& rhs, double& myrinv, unsigned& phimax,
-                                             int lane, double ddl, double piv, double rinv) {
+                                             int lane, double ddl, double piv, double rinv, int n) {
   if constexpr (J < MVO_MAXC) {
+    if (J >= n) return;
     // largest high word of the pivots, as unsigned: a negative pivot (sign bit), an infinite one or a NaN
     // (exponent 0x7ff) all end up >= 0x7ff00000 -- one scalar max per step
     const unsigned hi = (unsigned)__double2hiint(piv);
@@ -328,7 +331,7 @@ __device__ __forceinline__ void gj_eliminate(double (&a)[MVO_MAXC], double& rhs,
       gj_row_update<J, J + 2>(a, f);
     }
     rhs -= f * row_bcast<J>(rhs);
-    gj_eliminate<J + 1>(a, rhs, myrinv, phimax, lane, ddl, piv_next, rinv_next);
+    gj_eliminate<J + 1>(a, rhs, myrinv, phimax, lane, ddl, piv_next, rinv_next, n);
   }
 }
 
@@ -591,7 +594,7 @@ __device__ __forceinline__ int lm_step(LmRegs& r, LmShared& sh, const SolveParam
     unsigned phimax = 0;
     {
       const double piv0 = bcast_lane(a[0] + ddl, 0);
-      gj_eliminate<0>(a, rhs, myrinv, phimax, lane, ddl, piv0, fast_rcp(piv0));
+      gj_eliminate<0>(a, rhs, myrinv, phimax, lane, ddl, piv0, fast_rcp(piv0), n);
     }
     MVO_ASTAMP(11);
     const double step = lane < n ? -(rhs * myrinv) : 0.0;
