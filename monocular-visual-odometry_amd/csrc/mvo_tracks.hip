@@ -278,7 +278,8 @@ __global__ __launch_bounds__(64) void k_tracks_fill(TracksDev t, uint32_t N, uin
 __global__ __launch_bounds__(64 * TR_FOLD_WAVES) void k_tracks_fold(TracksDev t, uint32_t N, uint32_t n_groups4,
                                                                    uint32_t SP, uint32_t seg,
                                                                    const double* __restrict__ frames,
-                                                                   double* __restrict__ part) {
+                                                                   double* __restrict__ part,
+                                                                   double* __restrict__ pair_sums) {
   extern __shared__ double lp[];  // [TR_FOLD_WAVES][seg][8]: the wavefronts' partial sums of this segment's steps
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t g = blockIdx.x * TR_FOLD_WAVES + wave, a = blockIdx.y;
@@ -341,14 +342,17 @@ __global__ __launch_bounds__(64 * TR_FOLD_WAVES) void k_tracks_fold(TracksDev t,
   __syncthreads();
   // the four wavefronts' partial sums of a step, added in wavefront (= feature group) order: one entry
   // per workgroup and step
-  double* __restrict__ prow = part + (size_t)(a * n_groups4 + blockIdx.x) * SP * 8;
+  // pair_sums != nullptr: ONE workgroup holds all the features of a frame (n_groups4 == 1), its sums are
+  // the pairs' sums -- straight into the solver's table, no k_tracks_reduce launch
+  double* __restrict__ prow = pair_sums ? pair_sums + (size_t)tr_pair_start(N, a) * 8
+                                        : part + (size_t)(a * n_groups4 + blockIdx.x) * SP * 8;
   for (uint32_t e = threadIdx.x; e < seg * 8; e += 64 * TR_FOLD_WAVES) {
     const uint32_t s = s_lo + 1 + (e >> 3);
     if (s > s_hi) break;
     double sum = lp[e];
 #pragma unroll
     for (int w = 1; w < TR_FOLD_WAVES; ++w) sum += lp[(size_t)w * seg * 8 + e];
-    prow[(size_t)(s - 1) * 8 + (e & 7)] = sum;
+    prow[(size_t)(s - 1) * 8 + (e & 7)] = sum;  // entries 6 and 7 are sums of zeros
   }
 }
 
@@ -447,6 +451,7 @@ struct mvo_hip_tracks_context {
   size_t cap_part = 0;
   double* d_frames = nullptr;      // fused fold: the window's frame records (it starts before the solver's upload)
   double* h_frames_pin = nullptr;  // pinned staging for them
+  bool fold_wrote_sums = false;    // the last fold wrote the pairs' sums itself (one workgroup per frame)
   hipEvent_t ev_counts = nullptr;  // the pair counts have reached h_counts
   // the fused refine counts nothing; residual_blocks of mvo_hip_tracks_get_timing is counted when asked for
   uint64_t version = 0;            // bumped by push / append / reset
@@ -635,9 +640,10 @@ int fill_pairs(mvo_hip_tracks_context* t, uint32_t M, uint32_t N, double* m0, do
 // fused gather-and-fold (no loss), first half: k_tracks_fold, per (frame a, feature group, step) partial
 // moments straight from the track tables into d_part.  Needs the tables, the frame records on the device
 // and the shape window_shape left (g_groups, g_sp) -- no counts, nothing from the host.
-int fold_launch(mvo_hip_tracks_context* t, uint32_t M, uint32_t N, const double* frames) {
+int fold_launch(mvo_hip_tracks_context* t, uint32_t M, uint32_t N, const double* frames, double* pair_sums = nullptr) {
   t->last_fused = true;
   t->fill_timed = false;
+  t->fold_wrote_sums = false;
   hipStream_t s = t->stream;
   if (t->g_groups == 0) return MVO_HIP_OK;
   const int rc_ev = ensure_events(t);
@@ -656,7 +662,8 @@ int fold_launch(mvo_hip_tracks_context* t, uint32_t M, uint32_t N, const double*
   walk_shape(N, &seg, &n_seg);
   hipLaunchKernelGGL(k_tracks_fold, dim3(groups4, M, n_seg), dim3(64 * TR_FOLD_WAVES),
                      sizeof(double) * 8 * TR_FOLD_WAVES * seg, s, dev_view(t), N, groups4, t->g_sp, seg, frames,
-                     t->d_part);
+                     t->d_part, groups4 == 1 ? pair_sums : (double*)nullptr);
+  t->fold_wrote_sums = groups4 == 1 && pair_sums != nullptr;
   TR_TRY(hipGetLastError());
   if (t->profiling) {
     TR_TRY(hipEventRecord(t->ev[3], s));
@@ -674,6 +681,7 @@ int reduce_launch(mvo_hip_tracks_context* t, uint32_t M, uint32_t N, double* pai
     TR_TRY(hipMemsetAsync(pair_sums, 0, sizeof(double) * 8 * P, s));
     return MVO_HIP_OK;
   }
+  if (t->fold_wrote_sums) return MVO_HIP_OK;  // one workgroup per frame: the fold's sums are the pairs' sums
   hipLaunchKernelGGL(k_tracks_reduce, dim3(N - 1, M), dim3(256), 0, s, dev_view(t), N,
                      (t->g_groups + TR_FOLD_WAVES - 1) / TR_FOLD_WAVES, t->g_sp, t->d_part, pair_sums);
   TR_TRY(hipGetLastError());
@@ -882,7 +890,7 @@ int mvo_hip_tracks_refine(mvo_hip_tracks_handle t, mvo_hip_frame* frames, uint32
     rc = mvo_hip_internal_upload_pair_sums(t->solver, frames, M, N, options, &obs, &frames_dev, &sums);
     if (rc != MVO_HIP_OK) return rc;
     if (!fold_first) {
-      rc = fold_launch(t, M, N, frames_dev);
+      rc = fold_launch(t, M, N, frames_dev, sums);
       if (rc != MVO_HIP_OK) return rc;
     }
     rc = reduce_launch(t, M, N, sums);
