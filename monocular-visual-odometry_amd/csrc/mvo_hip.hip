@@ -174,6 +174,11 @@ struct mvo_hip_context {
   char* h_arena = nullptr;
   size_t h_arena_cap = 0;
   bool copy_pending = false;  // an async copy out of h_arena may still be in flight
+  // experiment switches, read from the environment ONCE, at mvo_hip_create (a getenv is a walk through
+  // the whole environment: four of them were ~1 us of a 33-us default-size refine)
+  uint32_t env_waves_per_cu = 16;
+  int env_overlap_chunks = 0;  // 0: the default (kOverlapChunks)
+  bool env_no_host_results = false, env_no_poll = false;
   // d_ctl = [window status: W int32, padded][done counter: 4 int32][results: W LmResult];
   // the last two are mirrored in pinned host memory by one copy
   int32_t* d_status = nullptr;
@@ -409,19 +414,11 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
   // One chunk of consecutive residual blocks per wavefront, all wavefronts resident at once:
   // waves_per_cu * 256 CUs of them, but at least kMinChunk blocks each so that small problems
   // do not pay one reduction per handful of blocks.
-  uint32_t waves_per_cu = 16;
-  if (const char* e = std::getenv("MVO_HIP_WAVES_PER_CU")) {  // tuning knob for experiments
-    const int t = std::atoi(e);
-    if (t >= 1 && t <= 64) waves_per_cu = (uint32_t)t;
-  }
+  const uint32_t waves_per_cu = h->env_waves_per_cu;  // MVO_HIP_WAVES_PER_CU, tuning knob for experiments
   const uint64_t kMinChunk = 256, kMaxWaveTiles = 255;
   // Batched windows without a loss run the fold in kMaxOverlapChunks launches next to the LM loops of
   // the chunks before (do_solve): every one of those launches must fill the chip by itself.
-  int overlap_chunks = kOverlapChunks;
-  if (const char* e = std::getenv("MVO_HIP_OVERLAP_CHUNKS")) {  // tuning knob for experiments
-    const int t = std::atoi(e);
-    if (t >= 2 && t <= kMaxOverlapChunks) overlap_chunks = t;
-  }
+  const int overlap_chunks = h->env_overlap_chunks ? h->env_overlap_chunks : kOverlapChunks;  // MVO_HIP_OVERLAP_CHUNKS
   const bool want_overlap = !h->pass_mode && !h->inline_eval && W >= 256 && P <= 256 && !lm4_eligible(h) &&
                             n_obs >= (uint64_t)kMinChunk * 256 * waves_per_cu * overlap_chunks &&
                             !std::getenv("MVO_HIP_NO_OVERLAP");
@@ -968,7 +965,7 @@ int do_solve(mvo_hip_context* h) {
   const uint32_t done_base = h->done_base;
   // Up to 64 windows the result records (208 B each) are written by k_lm straight into the pinned host
   // mirror: one command less on the stream (~4 us of a 45-us default-size solve).
-  h->results_on_host = h->W <= 64 && !std::getenv("MVO_HIP_NO_HOST_RESULTS");
+  h->results_on_host = h->W <= 64 && !h->env_no_host_results;  // MVO_HIP_NO_HOST_RESULTS
   if (h->results_on_host)
     for (uint32_t w = 0; w < h->W; ++w) h->h_results[w].pad = 0;
 
@@ -1086,7 +1083,7 @@ int do_solve(mvo_hip_context* h) {
     // the stream (config 2: 75.9 -> 74.2 us per solve).  What is still queued behind the marks (the
     // kernel's end) is ordered before anything the next call queues on the same stream.
     bool seen = false;
-    if (!prof && !std::getenv("MVO_HIP_NO_POLL")) {
+    if (!prof && !h->env_no_poll) {  // MVO_HIP_NO_POLL
       const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(500);
       for (uint32_t spins = 0; !seen; ++spins) {
         seen = true;
@@ -1215,6 +1212,16 @@ int mvo_hip_create(int device_ordinal, uint32_t max_windows, uint32_t max_frames
   mvo_hip_context* h = new (std::nothrow) mvo_hip_context();
   if (!h) return MVO_HIP_ERR_OUT_OF_MEMORY;
   h->device = device_ordinal;
+  if (const char* e = std::getenv("MVO_HIP_WAVES_PER_CU")) {
+    const int t = std::atoi(e);
+    if (t >= 1 && t <= 64) h->env_waves_per_cu = (uint32_t)t;
+  }
+  if (const char* e = std::getenv("MVO_HIP_OVERLAP_CHUNKS")) {
+    const int t = std::atoi(e);
+    if (t >= 2 && t <= kMaxOverlapChunks) h->env_overlap_chunks = t;
+  }
+  h->env_no_host_results = std::getenv("MVO_HIP_NO_HOST_RESULTS") != nullptr;
+  h->env_no_poll = std::getenv("MVO_HIP_NO_POLL") != nullptr;
   if (hipSetDevice(device_ordinal) != hipSuccess ||
       hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
       mvo_noalloc_resolve(device_ordinal) != hipSuccess) {  // the library's set-up call: scratch address, once per device
