@@ -250,6 +250,14 @@ int mvo_hip_debug_set_point(mvo_hip_handle h, uint32_t window, const double *poi
  * upload, window-major, n_windows * n_pairs * 6 doubles. */
 int mvo_hip_pair_moments(mvo_hip_handle h, double *moments);
 
+/* Debug/parity: the per-pair sums the LM loop last read (8 doubles per pair: S xx,xy,xz,yy,yz,zz,
+ * sum rho or sum r^2, sum w r^2), n_windows * n_pairs * 8 doubles to host memory.  After a solve of the
+ * tiled path these are what the observation pass's own tail (or, with MVO_HIP_NO_TAILS set when the handle
+ * was created, a k_reduce_slots launch) added up from the workgroups' slots -- the tests compare the two
+ * bit for bit.  Replaces nothing in the reference (its accumulation is Ceres' AddResidualBlock loop,
+ * IterativeRefinement.cpp:369-455). */
+int mvo_hip_debug_pair_sums(mvo_hip_handle h, double *sums);
+
 /* Iteration trace of window 0 of the next solves: capacity rows are recorded (0 disables). */
 int mvo_hip_set_trace(mvo_hip_handle h, int32_t capacity);
 int mvo_hip_get_trace(mvo_hip_handle h, mvo_hip_iteration *rows, int32_t capacity, int32_t *n_rows);

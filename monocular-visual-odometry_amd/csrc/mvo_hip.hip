@@ -179,6 +179,7 @@ struct mvo_hip_context {
   uint32_t env_waves_per_cu = 16;
   int env_overlap_chunks = 0;  // 0: the default (kOverlapChunks)
   bool env_no_host_results = false, env_no_poll = false;
+  bool env_no_tails = false;  // MVO_HIP_NO_TAILS: per-pair sums by k_reduce_slots launches instead of the passes' ticket tails
   // d_ctl = [window status: W int32, padded][done counter: 4 int32][results: W LmResult];
   // the last two are mirrored in pinned host memory by one copy
   int32_t* d_status = nullptr;
@@ -669,10 +670,14 @@ size_t pass_lds(const mvo_hip_context* h) { return sizeof(double) * 8 * (size_t)
 // observation pass #0: c = (R0 m0) x (R1 m1); stores c (pass mode) or sums the moments (no loss).
 // fused: the last workgroup leaves the per-pair sums in d_pairsum (k_lm then runs from_pair_sums), and
 // in pass mode the fold is the evaluation pass at the starting point as well (pair_u0).
+hipError_t launch_reduce_slots(mvo_hip_context* h);
 hipError_t launch_fold(mvo_hip_context* h, bool write_c, bool fused = false) {
   const uint32_t blocks = pass_blocks(h);
   if (!blocks) return hipSuccess;
-  int32_t* ticket = fused ? h->d_pticket.as<int32_t>() : nullptr;
+  // fused: the per-pair sums are wanted in d_pairsum -- by the ticket tail of the kernel itself, or
+  // (MVO_HIP_NO_TAILS, the tail's bit-for-bit reference in the tests) by a k_reduce_slots launch behind it
+  const bool tails = fused && !h->env_no_tails;
+  int32_t* ticket = tails ? h->d_pticket.as<int32_t>() : nullptr;
   double* pairsum = h->d_pairsum.as<double>();
 #define MVO_FOLD_ARGS(cbuf, celems) \
   h->t.tiles, h->t.wave_tiles, h->n_waves, h->t.frames, h->t.m0, h->t.m1, cbuf, celems, h->d_partial.as<double>(), \
@@ -690,14 +695,17 @@ hipError_t launch_fold(mvo_hip_context* h, bool write_c, bool fused = false) {
     hipLaunchKernelGGL((k_fold<false, true, 0>), dim3(blocks), dim3(FOLD_THREADS), pass_lds(h), h->stream,
                        MVO_FOLD_ARGS((double*)nullptr, (size_t)0));
 #undef MVO_FOLD_ARGS
-  return hipGetLastError();
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess && fused && !tails) e = launch_reduce_slots(h);
+  return e;
 }
 
 // one evaluation pass over the folded c at the unit baselines in d_pair_u
 hipError_t launch_pass(mvo_hip_context* h, bool fused = false) {
   const uint32_t blocks = pass_blocks(h);
   if (!blocks) return hipSuccess;
-  int32_t* ticket = fused ? h->d_pticket.as<int32_t>() : nullptr;
+  const bool tails = fused && !h->env_no_tails;
+  int32_t* ticket = tails ? h->d_pticket.as<int32_t>() : nullptr;
   if (h->opt.use_loss_function)
     hipLaunchKernelGGL((k_pass<true>), dim3(blocks), dim3(FOLD_THREADS), pass_lds(h), h->stream,
                        h->t.tiles, h->t.wave_tiles, h->n_waves, h->d_c.as<double>(),
@@ -708,7 +716,9 @@ hipError_t launch_pass(mvo_hip_context* h, bool fused = false) {
                        h->t.tiles, h->t.wave_tiles, h->n_waves, h->d_c.as<double>(),
                        (size_t)h->c_elems, h->d_pair_u.as<double>(), h->d_status,
                        h->d_partial.as<double>(), ticket, h->t.pairs, h->d_pairsum.as<double>());
-  return hipGetLastError();
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess && fused && !tails) e = launch_reduce_slots(h);
+  return e;
 }
 
 template <int NT>
@@ -1222,6 +1232,7 @@ int mvo_hip_create(int device_ordinal, uint32_t max_windows, uint32_t max_frames
   }
   h->env_no_host_results = std::getenv("MVO_HIP_NO_HOST_RESULTS") != nullptr;
   h->env_no_poll = std::getenv("MVO_HIP_NO_POLL") != nullptr;
+  h->env_no_tails = std::getenv("MVO_HIP_NO_TAILS") != nullptr;
   if (hipSetDevice(device_ordinal) != hipSuccess ||
       hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
       mvo_noalloc_resolve(device_ordinal) != hipSuccess) {  // the library's set-up call: scratch address, once per device
@@ -1402,6 +1413,16 @@ int mvo_hip_pair_moments(mvo_hip_handle h, double* moments) {
       for (int v = 0; v < 6; ++v) S[v] += part[(size_t)sl * 8 + v];
     std::memcpy(moments + 6 * p, S, sizeof S);
   }
+  return MVO_HIP_OK;
+}
+
+int mvo_hip_debug_pair_sums(mvo_hip_handle h, double* sums) {
+  if (!h || !sums) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  if (!h->uploaded || !h->d_pairsum.p) return MVO_HIP_ERR_STATE;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipMemcpyAsync(sums, h->d_pairsum.p, sizeof(double) * 8 * (size_t)h->W * h->P, hipMemcpyDeviceToHost,
+                         h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
   return MVO_HIP_OK;
 }
 

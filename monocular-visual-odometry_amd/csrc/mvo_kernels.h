@@ -46,6 +46,13 @@ __device__ __forceinline__ void block_store_partials(const TileDev* __restrict__
       else partial[(size_t)slot * 8 + v] = acc;
     }
   }
+  // A tail follows: EVERY wavefront waits here until its own slot stores have been acknowledged by the
+  // memory system (write-through stores are acknowledged once they are visible device-wide).  A
+  // workgroup-scope release fence does not do that on gfx950 -- it emits no s_waitcnt vmcnt(0) -- and the
+  // wavefront that takes the tickets (block_finish_pairs) only waits for its OWN stores; without this wait
+  // another workgroup could draw a pair's last ticket and read a slot that wavefronts 1..3 of this
+  // workgroup still have in flight.
+  if (coherent) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // One residual block of the evaluation pass.  ROBUST = ceres::CauchyLoss(0.5): b = 0.25, c = 4,
@@ -89,7 +96,9 @@ __device__ __forceinline__ void block_finish_pairs(int32_t* pair_ticket, const T
                                                    const double* partial, double* __restrict__ pair_sums) {
   if (pair_ticket == nullptr) return;
   __shared__ uint32_t n_todo;
-  // the slot stores above are device-coherent; they have completed (vmcnt = 0) before a ticket is taken
+  // The slot stores above are device-coherent (written through the XCD's L2) and every wavefront has
+  // waited for its own (s_waitcnt vmcnt(0) at the end of block_store_partials); the barrier below
+  // therefore orders ALL slot stores of this workgroup before any ticket it takes.
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   if (threadIdx.x == 0) n_todo = 0;
   __syncthreads();

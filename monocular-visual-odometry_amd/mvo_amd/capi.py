@@ -37,7 +37,7 @@ EXPORTED_SYMBOLS = [
     "mvo_hip_num_pairs", "mvo_hip_status_string", "mvo_hip_version", "mvo_hip_partial_begin",
     "mvo_hip_partial_pass", "mvo_hip_partial_advance", "mvo_hip_partial_sums", "mvo_hip_debug_poison_lds",
     "mvo_hip_debug_check_guards", "mvo_hip_refine_noalloc", "mvo_hip_eval_at", "mvo_hip_debug_set_point",
-    "mvo_hip_comm_unique_id", "mvo_hip_comm_init", "mvo_hip_comm_destroy", "mvo_hip_solve_partitioned",
+    "mvo_hip_debug_pair_sums", "mvo_hip_comm_unique_id", "mvo_hip_comm_init", "mvo_hip_comm_destroy", "mvo_hip_solve_partitioned",
 ]
 
 
@@ -146,6 +146,7 @@ def load():
         L.mvo_hip_solve_partitioned.argtypes = [C.c_void_p]
         L.mvo_hip_debug_set_point.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         L.mvo_hip_pair_moments.argtypes = [C.c_void_p, C.c_void_p]
+        L.mvo_hip_debug_pair_sums.argtypes = [C.c_void_p, C.c_void_p]
         L.mvo_hip_set_trace.argtypes = [C.c_void_p, C.c_int32]
         L.mvo_hip_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.mvo_hip_debug_poison_lds.argtypes = [C.c_int]
@@ -371,6 +372,14 @@ class Solver:
         rc = self._lib.mvo_hip_pair_moments(self._h, out.ctypes.data)
         if rc != OK:
             raise MvoHipError(rc, "mvo_hip_pair_moments")
+        return out
+
+    def pair_sums(self):
+        """The 8 per-pair sums the LM loop last read (include/mvo_hip.h: mvo_hip_debug_pair_sums)."""
+        out = np.zeros((self._W * num_pairs(self._M, self._N), 8))
+        rc = self._lib.mvo_hip_debug_pair_sums(self._h, out.ctypes.data)
+        if rc != OK:
+            raise MvoHipError(rc, "mvo_hip_debug_pair_sums")
         return out
 
     def set_profiling(self, enabled):
