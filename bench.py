@@ -14,6 +14,16 @@ Default workload = BASELINE.json configs[1]: one synthetic 30-keyframe window, 5
 ~100k bearing observations, fp64, exactly 10 LM iterations (tolerances 0).  With N > 1 every rank
 owns one such window (independent windows, no data-path collective): weak scaling.
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts its N ranks ITSELF: the
+parent spawns `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same flags>` as a
+fresh child process before anything in the parent has touched the GPU (or imported torch), relays the
+child's output and exits with its code.  Launched by torch.distributed.run directly (WORLD_SIZE set) it is
+a rank.  The N > 1 default workload is BASELINE configs[2] (the same 4096 windows sharded, no collective);
+`--workload config3|config4|config4r` runs that one workload at any N, N = 1 included, so that a 1/2/4/8
+curve of one workload can be taken; the N = 1 default line (configs[1]) carries `scaling_base`, the
+N > 1 default workload measured on this one GPU, and every N > 1 line carries `same_workload_one_gpu` and
+`efficiency_vs_one_gpu`.
+
 One JSON line on stdout (rank 0).  `roofline` describes the dominant observation-pass kernel of
 the workload, timed with HIP events on the library's own stream inside the timed region;
 `roofline_large` is the same kernel measured at config-4 size (~9.7M residual blocks, larger than
@@ -31,6 +41,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "monocular-visual-odometry_amd"))
+
+BK_DEVICE = "cuda"  # where the bench's own bookkeeping tensors live ("cpu" in a gloo rehearsal)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 achievable
 
@@ -212,7 +224,7 @@ def bench_epipolar(args, rank, local_rank, world, barrier, dist, torch):
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dev], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dev], dtype=torch.float64, device=BK_DEVICE)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dev = float(tt.item())
     # pInlier: ~40 fp64 flops per (hypothesis, correspondence); the 4.8 MB of rays stay in L2
@@ -272,7 +284,7 @@ def bench_scaler(args, rank, local_rank, world, barrier, dist, torch):
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=BK_DEVICE)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     gbs = tbytes / (tdev / args.steps) / 1e9 if tdev > 0 else 0.0
@@ -342,7 +354,7 @@ def bench_ba(args, rank, local_rank, world, barrier, dist, torch):
     solver.upload(sc, ba_capi.make_options(**kw))
     upload_s = time.perf_counter() - t0
     if partitioned:
-        buf = torch.zeros(18 * sc.M * (sc.M + 1) + 18 * sc.M + 1, dtype=torch.float64, device="cuda")
+        buf = torch.zeros(18 * sc.M * (sc.M + 1) + 18 * sc.M + 1, dtype=torch.float64, device="cuda")  # read by the library
 
         def ar(op):
             def f(t):
@@ -371,7 +383,7 @@ def bench_ba(args, rank, local_rank, world, barrier, dist, torch):
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=BK_DEVICE)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     units = 1 if partitioned else world
@@ -492,7 +504,7 @@ def bench_tracks(args, rank, local_rank, world, barrier, dist, torch):
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=BK_DEVICE)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -576,6 +588,24 @@ def bench_tracks(args, rank, local_rank, world, barrier, dist, torch):
     solver.close()
 
 
+def self_launch(argv, gpus):
+    """N > 1 without WORLD_SIZE: become the launcher.  Nothing in this process has imported torch or
+    made a HIP call; the ranks are a fresh child process tree (never an exec of a process that touched
+    the GPU).  Returns the child's exit code; its stdout (rank 0's one JSON line) and stderr pass through."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:  # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # RCCL across processes: dmabuf IPC only on this pool
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print(f"bench.py: starting {gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env, cwd=ROOT)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -587,6 +617,10 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-large", action="store_true", help="skip the config-4-size roofline leg")
     args = ap.parse_args()
+    global BK_DEVICE
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(sys.argv[1:], args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -595,8 +629,6 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libmvo_hip has no CPU fallback")
@@ -610,14 +642,8 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearse:
+            BK_DEVICE = "cpu"  # the bookkeeping tensors go through gloo on the host
             dist.init_process_group("gloo")
-            _tensor = torch.tensor
-
-            def _cpu_tensor(*a, **kw):  # the bookkeeping tensors go through gloo on the host
-                if kw.get("device") == "cuda":
-                    kw["device"] = "cpu"
-                return _tensor(*a, **kw)
-            torch.tensor = _cpu_tensor
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -628,6 +654,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    default_workload = args.workload is None
     args.workload, mode = plan(args.workload, world, args.weak)
     if args.workload == "epipolar":
         bench_epipolar(args, rank, local_rank, world, barrier, dist, torch)
@@ -702,7 +729,7 @@ def main():
     solver.set_profiling(True)
     tm = tm_prof
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=BK_DEVICE)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -713,7 +740,7 @@ def main():
     units = 1 if partitioned else world   # a partitioned window is one job, not `world` jobs
     strong = mode in ("partitioned", "strong_windows")
     if world > 1 and not partitioned:   # the ranks' shares differ in size: whole-job totals
-        tot = torch.tensor([float(its_per_step), float(blocks), float(bearings), float(n_windows)], dtype=torch.float64, device="cuda")
+        tot = torch.tensor([float(its_per_step), float(blocks), float(bearings), float(n_windows)], dtype=torch.float64, device=BK_DEVICE)
         dist.all_reduce(tot)
         job_its, job_blocks, job_bearings, job_windows = (float(x) for x in tot.tolist())
     else:
@@ -768,11 +795,14 @@ def main():
         for _ in range(k):
             solver.refine(ws[0], opt)
         out["refine_ms_pcie_inclusive"] = round((time.perf_counter() - t1) / k * 1e3, 5)
-    if mode == "strong_windows":
-        # the efficiency baseline in the same line: ALL windows of the job on rank 0's GPU alone
-        # (the other ranks wait); the driver's own N = 1 run measures config2, a different workload
+    if strong and world > 1:
+        # the efficiency baseline in the same line: the WHOLE job on rank 0's GPU alone (the other ranks
+        # wait) -- all windows of config 3, or the unsplit config-4 window through the plain mvo_hip_solve
         if rank == 0:
-            all_ws, _, _ = build_workload(args.workload, 0, 1, "single")
+            if partitioned:
+                all_ws = [full]
+            else:
+                all_ws, _, _ = build_workload(args.workload, 0, 1, "single")
             solver.upload(all_ws, opt)
             for _ in range(2):
                 solver.solve()
@@ -782,8 +812,11 @@ def main():
                 solver.solve()
                 _, s1 = solver.download(copy=False)
             e1 = (time.perf_counter() - t1) / k
-            out["same_workload_one_gpu"] = {"value": round(sum(x.iterations for x in s1) / e1, 3), "unit": "LM iterations/s",
+            one = sum(x.iterations for x in s1) / e1
+            out["same_workload_one_gpu"] = {"value": round(one, 3), "unit": "LM iterations/s",
                                             "ms_per_step": round(e1 * 1e3, 5), "windows": len(all_ws)}
+            # strong scaling: (one-GPU time / N-GPU time) / N
+            out["efficiency_vs_one_gpu"] = round(out["value"] / (one * world), 4)
             del all_ws
         barrier()
 
@@ -811,6 +844,24 @@ def main():
         rl["ms_per_solve"] = round(big_elapsed / k * 1e3, 4)
         out["roofline_large"] = rl
         del big_ws
+
+    if rank == 0 and world == 1 and not args.no_large and default_workload:
+        # The driver's 1 -> 8 sequence runs `bench.py --gpus N` without a workload: N = 1 measures configs[1]
+        # (above), N > 1 configs[2].  So that the sequence still holds ONE curve, this line also carries the
+        # N > 1 default workload measured on this one GPU (same code path as `--workload config3`).
+        base_ws, base_opt, base_desc = build_workload("config3", 0, 1, "single")
+        solver.upload(base_ws, base_opt)
+        for _ in range(2):
+            solver.solve()
+        k = 5
+        t1 = time.perf_counter()
+        for _ in range(k):
+            solver.solve()
+            _, sb = solver.download(copy=False)
+        eb = (time.perf_counter() - t1) / k
+        out["scaling_base"] = {"workload": base_desc, "n_gpus": 1, "value": round(sum(x.iterations for x in sb) / eb, 3),
+                               "unit": "LM iterations/s", "ms_per_step": round(eb * 1e3, 5), "windows": len(base_ws)}
+        del base_ws
 
     if rank == 0 and world == 1 and not args.no_cpu:
         kw = dict(max_num_iterations=10, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)

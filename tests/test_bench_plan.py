@@ -52,3 +52,23 @@ def test_traffic_figures_go_stale_with_the_kernel_source(tmp_path, monkeypatch):
     assert bench.measured_traffic("config4", "k_fold<false, true>") == 105
     assert bench.measured_traffic("config4", "k_pass<true>") is None      # measured on another source: stale
     assert bench.measured_traffic("config2", "k_fold<false, true>") is None
+
+
+def test_gpus_n_without_a_launcher_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE (the round driver's command) spawns the two ranks itself and
+    relays their exit code.  Without a GPU every rank stops at "bench.py needs a GPU" -- which shows that the
+    ranks were started with WORLD_SIZE = 2 (a lone process would have got past that check's precondition
+    differently: `--gpus 2 but WORLD_SIZE=1`), and that the parent neither hides the failure nor touches torch."""
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["HIP_VISIBLE_DEVICES"] = ""  # also on a GPU box: this test is about the launcher, not the GPU
+    env["CUDA_VISIBLE_DEVICES"] = ""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert out.returncode != 0
+    assert "starting 2 ranks" in out.stderr and "torch.distributed.run" in out.stderr
+    assert "bench.py needs a GPU" in out.stderr
+    assert "WORLD_SIZE=1" not in out.stderr
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]  # no line was faked
