@@ -192,17 +192,25 @@ int mvo_hip_download(mvo_hip_handle h, mvo_hip_frame *frames, mvo_hip_summary *s
 
 /* Observation-partitioned solve of ONE large window over several GPUs (no reference counterpart:
  * the reference is single-process).  Every rank uploads the same frames and
- * options and ITS share of each pair's residual blocks.  The per-pair sums (8 doubles per pair:
- * S xx,xy,xz,yy,yz,zz, sum rho, sum w r^2) are additive over ranks; the caller all-reduces them
- * (RCCL/torch.distributed) between the calls below, after which every rank takes the identical
- * LM step.  Each call drains the library's stream before returning.
- *   no loss : begin -> [all-reduce sums] -> advance (whole LM loop, done = 1)
- *   loss    : begin -> { pass -> [all-reduce sums] -> advance } until done
- * partial_sums copies the sums to (direction 0) or from (direction 1) a caller-owned DEVICE
- * buffer of 8 * n_windows * n_pairs doubles. */
+ * options and ITS share of each pair's residual blocks.  What the ranks exchange is additive over
+ * ranks; the caller all-reduces it (RCCL/torch.distributed) between the calls below, after which
+ * every rank takes the identical LM step.  Each call drains the library's stream before returning.
+ *   no loss : begin -> [all-reduce] -> advance (whole LM loop in one launch, done = 1).
+ *             Exchanged: the per-pair sums, 8 doubles per pair (S xx,xy,xz,yy,yz,zz, sum r^2, unused),
+ *             ONCE per solve -- S_p does not depend on the evaluation point.
+ *   loss    : begin -> { [all-reduce] -> advance -> done ? stop : pass } ...
+ *             begin folds the observations and is the evaluation pass at the starting point; `pass` is
+ *             the pass at the candidate `advance` published.  Exchanged: the CONTRACTED form, the class
+ *             totals of the pairs' projected moments P S P, P S u, 1/2 sum rho (MVO_HIP_CLASS_DOUBLES =
+ *             352 doubles per window and evaluation, linear in every rank's share), so that no rank
+ *             repeats the per-pair stage of the step.
+ * mvo_hip_partial_sums_count returns the number of doubles exchanged for the current upload;
+ * partial_sums copies them to (direction 0) or from (direction 1) a caller-owned DEVICE buffer. */
+#define MVO_HIP_CLASS_DOUBLES 352
 int mvo_hip_partial_begin(mvo_hip_handle h);
 int mvo_hip_partial_pass(mvo_hip_handle h);
 int mvo_hip_partial_advance(mvo_hip_handle h, int32_t *done);
+uint64_t mvo_hip_partial_sums_count(mvo_hip_handle h);
 int mvo_hip_partial_sums(mvo_hip_handle h, void *device_buffer, uint64_t n_doubles, int direction);
 
 /* The same partitioned solve with the collective INSIDE the library (north_star: "partial
@@ -211,10 +219,12 @@ int mvo_hip_partial_sums(mvo_hip_handle h, void *device_buffer, uint64_t n_doubl
  * the other ranks by whatever means the application has (MPI, a file, a socket); every rank then calls
  * mvo_hip_comm_init on its handle (ncclCommInitRank on the handle's device: collective, blocks until
  * all ranks have arrived).  After mvo_hip_upload of this rank's shard (same frames and options on every
- * rank), mvo_hip_solve_partitioned runs fold / pass -> per-pair sums -> ncclAllReduce(sum, 8 fp64 per
- * pair) -> LM step entirely on the handle's stream -- no host round trip per pass; results as after
+ * rank), mvo_hip_solve_partitioned runs fold / pass -> this rank's sums -> ncclAllReduce(sum; 8 fp64 per
+ * pair once per solve without a loss, MVO_HIP_CLASS_DOUBLES fp64 per window and evaluation with one) ->
+ * LM step entirely on the handle's stream -- no host round trip per pass; results as after
  * mvo_hip_solve, identical on every rank (mvo_hip_download).  Every rank must make the same calls in
- * the same order.  librccl.so.1 is opened on the first of these calls (MVO_HIP_ERR_UNSUPPORTED when it
+ * the same order.  Fail-stop: a rank whose HIP or RCCL call fails returns an error while the others wait
+ * in their next collective -- tear the job down, as after any failed collective.  librccl.so.1 is opened on the first of these calls (MVO_HIP_ERR_UNSUPPORTED when it
  * cannot be found), so single-GPU users never load it.  mvo_hip_comm_destroy (or mvo_hip_destroy)
  * releases the communicator. */
 #define MVO_HIP_COMM_ID_BYTES 128

@@ -49,7 +49,12 @@ struct SolveParams {
   int32_t win_base;     // k_lm: window of workgroup 0 (launches over a range of the windows)
   int32_t M, N, P;      // every window of an upload has the same shape
   int32_t x0_ready;     // pass mode: the sums of the evaluation at x0 exist already (fused fold)
+  int32_t proj_ready;   // pass mode, passes as launches of their own: their tails left every pair's projected moments
+                        // in `proj` (project_pair8, mvo_kernels.h)
+  int32_t cls_ready;    // ... observation-partitioned: the class totals of the evaluation, summed over the ranks, are
+                        // in `cls_in` (k_class_sums + all-reduce)
 };
+#define MVO_CLS_DOUBLES 352  // per window: cls[MAXM * (MAXM + 1)][10], kk[MAXM][10], padded to a multiple of 4
 
 struct TraceRec {  // == mvo_hip_iteration
   double cost, cost_change, gradient_max_norm, step_norm, relative_decrease, trust_region_radius;

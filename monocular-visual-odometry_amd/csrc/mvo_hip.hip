@@ -156,7 +156,9 @@ struct mvo_hip_context {
   hipStream_t stream = nullptr;
   hipError_t last_hip_error = hipSuccess;
   // device buffers
-  DevBuf d_arena, d_m0, d_m1, d_c, d_partial, d_pair_u, d_states, d_ctl, d_trace, d_res, d_jac, d_pairsum, d_pticket;
+  DevBuf d_arena, d_m0, d_m1, d_c, d_partial, d_pair_u, d_states, d_ctl, d_trace, d_res, d_jac, d_pairsum, d_pticket,
+      d_proj,  // pass mode: T(6) q(3) cost(1) per pair, left by the passes' tails (project_pair8)
+      d_cls;   // partitioned pass mode: MVO_CLS_DOUBLES class totals per window (k_class_sums), what the ranks all-reduce
   // The tables of one upload (and the rays of a small one) are staged in ONE pinned block and
   // reach the device in ONE copy into d_arena; these point into it (rays: or into d_m0 / d_m1).
   struct {
@@ -217,6 +219,7 @@ struct mvo_hip_context {
   bool pass_mode = false;
   bool inline_eval = false;  // k_lm runs the observation passes itself (small or many windows)
   bool tickets_clean = false;  // d_pticket is all zero (it is after every completed launch)
+  bool pairsum_foreign = false;  // d_pairsum holds all-reduced sums (partitioned no-loss solve): rows of pairs that are empty HERE are not zero
   std::vector<mvo_hip_frame> h_frames;  // copy of the uploaded frames (write-back base)
   std::vector<PairDev> h_pairs;
   // trace
@@ -593,6 +596,12 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
     bool empty_pair = false;
     for (const PairDev& pd : pairs) empty_pair |= pd.count == 0;
     if (empty_pair) HIP_TRY(hipMemsetAsync(h->d_pairsum.p, 0, sizeof(double) * 8 * pairs.size(), h->stream));
+    if (h->pass_mode) {
+      HIP_TRY(h->d_proj.reserve(sizeof(double) * 10 * pairs.size()));
+      // a pair without residual blocks is never projected: zeros from here on
+      if (empty_pair) HIP_TRY(hipMemsetAsync(h->d_proj.p, 0, sizeof(double) * 10 * pairs.size(), h->stream));
+    }
+    h->pairsum_foreign = false;
   }
   HIP_TRY(h->d_states.reserve(sizeof(LmState) * W));
   {
@@ -669,8 +678,9 @@ size_t pass_lds(const mvo_hip_context* h) { return sizeof(double) * 8 * (size_t)
 
 // observation pass #0: c = (R0 m0) x (R1 m1); stores c (pass mode) or sums the moments (no loss).
 // fused: the last workgroup leaves the per-pair sums in d_pairsum (k_lm then runs from_pair_sums), and
-// in pass mode the fold is the evaluation pass at the starting point as well (pair_u0).
-hipError_t launch_reduce_slots(mvo_hip_context* h);
+// in pass mode the fold is the evaluation pass at the starting point as well (pair_u0), its tails project
+// every pair (d_proj).
+hipError_t launch_reduce_slots(mvo_hip_context* h, const double* upairs = nullptr);
 hipError_t launch_fold(mvo_hip_context* h, bool write_c, bool fused = false) {
   const uint32_t blocks = pass_blocks(h);
   if (!blocks) return hipSuccess;
@@ -679,13 +689,15 @@ hipError_t launch_fold(mvo_hip_context* h, bool write_c, bool fused = false) {
   const bool tails = fused && !h->env_no_tails;
   int32_t* ticket = tails ? h->d_pticket.as<int32_t>() : nullptr;
   double* pairsum = h->d_pairsum.as<double>();
+  const bool pass0 = write_c && fused;
+  const PassOut po{h->t.pair_u0, pass0 ? h->d_proj.as<double>() : nullptr};
 #define MVO_FOLD_ARGS(cbuf, celems) \
   h->t.tiles, h->t.wave_tiles, h->n_waves, h->t.frames, h->t.m0, h->t.m1, cbuf, celems, h->d_partial.as<double>(), \
-      h->t.pair_u0, ticket, h->t.pairs, pairsum
-  if (write_c && fused && h->opt.use_loss_function)
+      ticket, h->t.pairs, pairsum, po
+  if (pass0 && h->opt.use_loss_function)
     hipLaunchKernelGGL((k_fold<true, false, 2>), dim3(blocks), dim3(FOLD_THREADS), pass_lds(h), h->stream,
                        MVO_FOLD_ARGS(h->d_c.as<double>(), (size_t)h->c_elems));
-  else if (write_c && fused)
+  else if (pass0)
     hipLaunchKernelGGL((k_fold<true, false, 1>), dim3(blocks), dim3(FOLD_THREADS), pass_lds(h), h->stream,
                        MVO_FOLD_ARGS(h->d_c.as<double>(), (size_t)h->c_elems));
   else if (write_c)
@@ -696,28 +708,29 @@ hipError_t launch_fold(mvo_hip_context* h, bool write_c, bool fused = false) {
                        MVO_FOLD_ARGS((double*)nullptr, (size_t)0));
 #undef MVO_FOLD_ARGS
   hipError_t e = hipGetLastError();
-  if (e == hipSuccess && fused && !tails) e = launch_reduce_slots(h);
+  if (e == hipSuccess && fused && !tails) e = launch_reduce_slots(h, pass0 ? h->t.pair_u0 : nullptr);
   return e;
 }
 
-// one evaluation pass over the folded c at the unit baselines in d_pair_u
+// one evaluation pass over the folded c at the unit baselines k_lm published (d_pair_u)
 hipError_t launch_pass(mvo_hip_context* h, bool fused = false) {
   const uint32_t blocks = pass_blocks(h);
   if (!blocks) return hipSuccess;
   const bool tails = fused && !h->env_no_tails;
   int32_t* ticket = tails ? h->d_pticket.as<int32_t>() : nullptr;
+  const PassOut po{h->d_pair_u.as<double>(), fused ? h->d_proj.as<double>() : nullptr};
   if (h->opt.use_loss_function)
     hipLaunchKernelGGL((k_pass<true>), dim3(blocks), dim3(FOLD_THREADS), pass_lds(h), h->stream,
                        h->t.tiles, h->t.wave_tiles, h->n_waves, h->d_c.as<double>(),
-                       (size_t)h->c_elems, h->d_pair_u.as<double>(), h->d_status,
-                       h->d_partial.as<double>(), ticket, h->t.pairs, h->d_pairsum.as<double>());
+                       (size_t)h->c_elems, h->d_status,
+                       h->d_partial.as<double>(), ticket, h->t.pairs, h->d_pairsum.as<double>(), po);
   else
     hipLaunchKernelGGL((k_pass<false>), dim3(blocks), dim3(FOLD_THREADS), pass_lds(h), h->stream,
                        h->t.tiles, h->t.wave_tiles, h->n_waves, h->d_c.as<double>(),
-                       (size_t)h->c_elems, h->d_pair_u.as<double>(), h->d_status,
-                       h->d_partial.as<double>(), ticket, h->t.pairs, h->d_pairsum.as<double>());
+                       (size_t)h->c_elems, h->d_status,
+                       h->d_partial.as<double>(), ticket, h->t.pairs, h->d_pairsum.as<double>(), po);
   hipError_t e = hipGetLastError();
-  if (e == hipSuccess && fused && !tails) e = launch_reduce_slots(h);
+  if (e == hipSuccess && fused && !tails) e = launch_reduce_slots(h, h->d_pair_u.as<double>());
   return e;
 }
 
@@ -730,8 +743,8 @@ hipError_t launch_lm(mvo_hip_context* h, const SolveParams& prm, bool from_pair_
                      from_pair_sums ? h->d_pairsum.as<double>() : h->d_partial.as<double>(),
                      h->t.m0, h->t.m1, h->d_pairsum.as<double>(),
                      h->d_states.as<LmState>(), h->results_on_host ? h->h_results : h->d_results,
-                     h->d_pair_u.as<double>(), h->d_status, h->d_trace.as<TraceRec>(),
-                     h->d_done);
+                     h->d_status, h->d_trace.as<TraceRec>(),
+                     h->d_done, h->d_proj.as<double>(), h->d_cls.as<double>(), h->d_pair_u.as<double>());
   return hipGetLastError();
 }
 
@@ -741,8 +754,7 @@ hipError_t launch_fold_range(mvo_hip_context* h, uint32_t b0, uint32_t b1) {
   if (w1 <= w0) return hipSuccess;
   hipLaunchKernelGGL((k_fold<false, true, 0>), dim3(b1 - b0), dim3(FOLD_THREADS), pass_lds(h), h->stream, h->t.tiles,
                      h->t.wave_tiles + w0, w1 - w0, h->t.frames, h->t.m0, h->t.m1, (double*)nullptr, (size_t)0,
-                     h->d_partial.as<double>(), (const double*)nullptr, (int32_t*)nullptr, (const PairDev*)nullptr,
-                     (double*)nullptr);
+                     h->d_partial.as<double>(), (int32_t*)nullptr, (const PairDev*)nullptr, (double*)nullptr, PassOut{});
   return hipGetLastError();
 }
 
@@ -753,8 +765,9 @@ hipError_t launch_lm_range(mvo_hip_context* h, SolveParams prm, uint32_t win0, u
   prm.win_base = (int32_t)win0;
   hipLaunchKernelGGL(k_lm<NT>, dim3(win1 - win0), dim3(NT), 0, stream, prm, 0, h->t.wins, h->t.frames,
                      h->t.initx, h->t.pairs, h->d_partial.as<double>(), h->t.m0, h->t.m1, h->d_pairsum.as<double>(),
-                     h->d_states.as<LmState>(), h->d_results, h->d_pair_u.as<double>(), h->d_status,
-                     h->d_trace.as<TraceRec>(), h->d_done);
+                     h->d_states.as<LmState>(), h->d_results, h->d_status,
+                     h->d_trace.as<TraceRec>(), h->d_done, (const double*)nullptr, (const double*)nullptr,
+                     (double*)nullptr);
   return hipGetLastError();
 }
 
@@ -795,11 +808,44 @@ hipError_t launch_lm_any(mvo_hip_context* h, SolveParams prm, bool from_pair_sum
 
 // ---- observation-partitioned mode: fold / pass -> per-pair sums -> caller's
 // all-reduce -> LM step from the summed moments.  Every call drains the stream before returning.
-hipError_t launch_reduce_slots(mvo_hip_context* h) {
+// upairs != nullptr (pass sums at those unit baselines): the pairs' projected moments as well (d_proj) -- the
+// launch-of-its-own form of the passes' tails (MVO_HIP_NO_TAILS)
+hipError_t launch_reduce_slots(mvo_hip_context* h, const double* upairs) {
   const uint32_t n = h->W * h->P;
+  const PassOut po{upairs, upairs ? h->d_proj.as<double>() : nullptr};
   hipLaunchKernelGGL(k_reduce_slots, dim3((n * 8 + 255) / 256), dim3(256), 0, h->stream,
-                     h->t.pairs, n, h->d_partial.as<double>(), h->d_pairsum.as<double>());
+                     h->t.pairs, n, h->d_partial.as<double>(), h->d_pairsum.as<double>(), po);
   return hipGetLastError();
+}
+
+// partitioned pass mode: this rank's class totals (MVO_CLS_DOUBLES per window) from its pairs' projections
+hipError_t launch_class_sums(mvo_hip_context* h) {
+  hipLaunchKernelGGL(k_class_sums, dim3(h->W), dim3(64 * MVO_MAXM), 0, h->stream, (int)h->M, (int)h->N, (int)h->P,
+                     h->d_proj.as<double>(), h->d_cls.as<double>());
+  return hipGetLastError();
+}
+
+// Pass mode: what the ranks exchange is the CONTRACTED form -- the class totals of the projected
+// moments, MVO_CLS_DOUBLES per window (k_class_sums), linear in each rank's share of the residual blocks --
+// and k_lm starts at the prefix sums of the classes (SolveParams::cls_ready): no rank repeats the
+// per-pair stage.  No loss: S_p never changes, ONE exchange of the 8 sums per pair per solve, then the
+// whole LM loop in one launch (a contracted exchange would cost one collective per EVALUATION there --
+// 10 more latencies of a collective to save a 3-us per-pair stage).
+size_t partial_count(const mvo_hip_context* h) {
+  return h->pass_mode ? (size_t)MVO_CLS_DOUBLES * h->W : 8 * (size_t)h->W * h->P;
+}
+// (in place: k_class_sums rewrites every entry of d_cls before each exchange; d_pairsum see pairsum_foreign)
+void* partial_buffer(const mvo_hip_context* h) { return h->pass_mode ? h->d_cls.p : h->d_pairsum.p; }
+int partial_reserve(mvo_hip_context* h) {
+  if (h->pass_mode) HIP_TRY(h->d_cls.reserve(sizeof(double) * MVO_CLS_DOUBLES * h->W));
+  return MVO_HIP_OK;
+}
+int clean_tickets(mvo_hip_context* h) {
+  if (h->tickets_clean) return MVO_HIP_OK;
+  // the whole blocks: later uploads may use more of them
+  HIP_TRY(hipMemsetAsync(h->d_pticket.p, 0, h->d_pticket.cap, h->stream));
+  h->tickets_clean = true;
+  return MVO_HIP_OK;
 }
 
 int partial_begin(mvo_hip_context* h) {
@@ -815,36 +861,43 @@ int partial_begin(mvo_hip_context* h) {
   h->done_base = 0;
   h->done_ready = false;  // until this partitioned solve has been seen to complete (it may be abandoned)
   h->solved = false;
-  HIP_TRY(hipMemsetAsync(h->d_pairsum.p, 0, sizeof(double) * 8 * (size_t)n, s));
+  {
+    int rc = clean_tickets(h);
+    if (rc == MVO_HIP_OK) rc = partial_reserve(h);
+    if (rc != MVO_HIP_OK) return rc;
+  }
   if (!h->pass_mode) {
+    HIP_TRY(hipMemsetAsync(h->d_pairsum.p, 0, sizeof(double) * 8 * (size_t)n, s));
     HIP_TRY(launch_fold(h, false));
     HIP_TRY(launch_reduce_slots(h));
+    h->pairsum_foreign = true;  // the caller's all-reduced sums come back into d_pairsum
   } else {
-    HIP_TRY(launch_fold(h, true));
-    SolveParams prm = make_params(h);
-    prm.inline_eval = 0;  // the passes are separate launches here: their sums get all-reduced
-    HIP_TRY(launch_lm_any(h, prm, true));  // PH_START: publishes u(x0)
+    // the fold is the pass at the starting point; its tails project this rank's share of every pair
+    HIP_TRY(launch_fold(h, true, true));
+    HIP_TRY(launch_class_sums(h));
   }
   HIP_TRY(hipStreamSynchronize(s));
   return MVO_HIP_OK;
 }
 
 int partial_pass(mvo_hip_context* h) {
-  if (!h->uploaded || !h->pass_mode || !h->d_pairsum.p) return MVO_HIP_ERR_STATE;
+  if (!h->uploaded || !h->pass_mode || !h->d_proj.p || !h->lm_started) return MVO_HIP_ERR_STATE;
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t s = h->stream;
-  HIP_TRY(launch_pass(h));
-  HIP_TRY(launch_reduce_slots(h));
+  HIP_TRY(launch_pass(h, true));
+  HIP_TRY(launch_class_sums(h));
   HIP_TRY(hipStreamSynchronize(s));
   return MVO_HIP_OK;
 }
 
 int partial_advance(mvo_hip_context* h, int32_t* done) {
-  if (!h->uploaded || !h->d_pairsum.p) return MVO_HIP_ERR_STATE;
+  if (!h->uploaded || !partial_buffer(h)) return MVO_HIP_ERR_STATE;
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t s = h->stream;
   SolveParams prm = make_params(h);
   prm.inline_eval = 0;
+  prm.x0_ready = 1;  // pass mode: the fold evaluated the starting point
+  prm.cls_ready = h->pass_mode ? 1 : 0;
   HIP_TRY(launch_lm_any(h, prm, true));
   HIP_TRY(hipMemcpyAsync(h->h_done, h->d_done, sizeof(int32_t), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
@@ -860,11 +913,16 @@ int partial_advance(mvo_hip_context* h, int32_t* done) {
   return MVO_HIP_OK;
 }
 
-// The whole partitioned solve with the collective ON THE STREAM: fold / pass -> per-pair sums ->
-// ncclAllReduce (sum, 8 fp64 per pair) -> the identical LM step on every rank.  No host round trip per
-// pass: the done counter is looked at every 12 evaluations, as in the single-GPU robust path.  Every
-// rank issues the same sequence of collectives: the summed moments are bitwise identical on all ranks,
-// so every rank takes the same decisions and finishes at the same evaluation.
+// The whole partitioned solve with the collective ON THE STREAM: fold / pass -> this rank's sums ->
+// ncclAllReduce -> the identical LM step on every rank.  No host round trip per pass: the done counter is
+// looked at every 12 evaluations, as in the single-GPU robust path.  Every rank issues the same sequence
+// of collectives: the summed values are bitwise identical on all ranks, so every rank takes the same
+// decisions and finishes at the same evaluation.  What travels: no loss -- 8 fp64 per pair, once per
+// solve; pass mode -- MVO_CLS_DOUBLES fp64 per window and evaluation (see partial_count).
+// FAIL-STOP: when a HIP or RCCL call fails in the middle of the sequence this rank returns an error and the
+// OTHER ranks stay blocked in their next collective; the caller must tear the job down (mvo_hip_destroy /
+// process exit), as after any failed collective.  N > 1 has only run in a world of one and as two handles on
+// one GPU (tests/test_gpu_rccl.py, tests/test_gpu_partitioned.py): unverified on several GPUs.
 int do_solve_partitioned(mvo_hip_context* h) {
   if (!h->uploaded || !h->comm) return MVO_HIP_ERR_STATE;
   h->results_on_host = false;
@@ -872,18 +930,24 @@ int do_solve_partitioned(mvo_hip_context* h) {
   HIP_TRY(hipSetDevice(h->device));
   const MvoRccl& rc = mvo_rccl();
   hipStream_t s = h->stream;
-  const uint32_t n = h->W * h->P;
   if (h->trace_cap > 0) HIP_TRY(h->d_trace.reserve(sizeof(TraceRec) * (size_t)h->trace_cap));
   h->lm_started = false;
   h->solved = false;
   HIP_TRY(hipMemsetAsync(h->d_status, 0, (size_t)((char*)h->d_done - (char*)h->d_status) + 16, s));
   h->done_base = 0;
   h->done_ready = false;
+  {
+    int rc = clean_tickets(h);
+    if (rc == MVO_HIP_OK) rc = partial_reserve(h);
+    if (rc != MVO_HIP_OK) return rc;
+  }
   SolveParams prm = make_params(h);
   prm.inline_eval = 0;  // the passes are launches of their own: their sums are what gets all-reduced
+  prm.x0_ready = 1;
+  prm.cls_ready = h->pass_mode ? 1 : 0;
   auto allreduce = [&]() -> int {
-    HIP_TRY(launch_reduce_slots(h));
-    const ncclResult_t r = rc.AllReduce(h->d_pairsum.p, h->d_pairsum.p, 8 * (size_t)n, ncclDouble, ncclSum, h->comm, s);
+    void* buf = partial_buffer(h);
+    const ncclResult_t r = rc.AllReduce(buf, buf, partial_count(h), ncclDouble, ncclSum, h->comm, s);
     if (r != ncclSuccess) {
       h->last_rccl_error = r;
       return MVO_HIP_ERR_DEVICE;
@@ -895,24 +959,25 @@ int do_solve_partitioned(mvo_hip_context* h) {
     // S_p never changes without a loss: ONE collective per solve, then the whole LM loop in one launch
     HIP_TRY(launch_fold(h, false));
     ++asm_launches;
+    HIP_TRY(launch_reduce_slots(h));
+    h->pairsum_foreign = true;
     int rcode = allreduce();
     if (rcode != MVO_HIP_OK) return rcode;
     ++collectives;
     HIP_TRY(launch_lm_any(h, prm, true));
     ++lm_launches;
   } else {
-    HIP_TRY(launch_fold(h, true));
-    ++asm_launches;
-    HIP_TRY(launch_lm_any(h, prm, true));  // PH_START: publishes u(x0)
-    ++lm_launches;
+    // evaluation 0 is the fold (the pass at the starting point); then one pass per candidate
     const int total_evals = h->opt.max_num_iterations + 1;
     const int chunk = 12;
     int issued = 0;
     while (issued < total_evals) {
       const int m = (total_evals - issued) < chunk ? (total_evals - issued) : chunk;
       for (int i = 0; i < m; ++i) {
-        HIP_TRY(launch_pass(h));
+        if (issued + i == 0) HIP_TRY(launch_fold(h, true, true));
+        else HIP_TRY(launch_pass(h, true));
         ++asm_launches;
+        HIP_TRY(launch_class_sums(h));
         int rcode = allreduce();
         if (rcode != MVO_HIP_OK) return rcode;
         ++collectives;
@@ -966,9 +1031,15 @@ int do_solve(mvo_hip_context* h) {
     h->done_base = 0;
     h->tickets_clean = false;  // an abandoned solve may have left a pass half counted
   }
-  if (!h->tickets_clean) {
-    HIP_TRY(hipMemsetAsync(h->d_pticket.p, 0, h->d_pticket.cap, s));  // the whole block: later uploads may use more of it
-    h->tickets_clean = true;
+  {
+    int rc = clean_tickets(h);
+    if (rc != MVO_HIP_OK) return rc;
+  }
+  if (h->pairsum_foreign) {
+    // a partitioned no-loss solve all-reduced into d_pairsum: the rows of pairs that are empty on this rank
+    // hold the other ranks' sums, and no fold rewrites a pair without slots
+    HIP_TRY(hipMemsetAsync(h->d_pairsum.p, 0, sizeof(double) * 8 * (size_t)h->W * h->P, s));
+    h->pairsum_foreign = false;
   }
   h->done_ready = false;  // until this solve has been seen to complete
   h->solved = false;
@@ -1056,13 +1127,17 @@ int do_solve(mvo_hip_context* h) {
       HIP_TRY(launch_fold(h, true, true));
       HIP_TRY(timed_end());
       ++asm_launches;
-      pp.x0_ready = 1;
     }
-    HIP_TRY(launch_lm_any(h, pp, fused));  // fused: evaluates x0 and takes the first step; else publishes u(x0)
+    // The fold is the pass at the starting point; fold and passes leave every pair projected in d_proj (their
+    // tails) and k_lm the unit baselines of the next point in d_pair_u.  Without any residual block there
+    // is no pass at all: the projections are the zeros the upload left.
+    pp.x0_ready = 1;
+    pp.proj_ready = 1;
+    HIP_TRY(launch_lm_any(h, pp, true));  // evaluates x0 and takes the first step
     ++lm_launches;
     // enqueue the evaluations in chunks without any host round-trip inside a chunk, and look at the done
     // counter between
-    const int total_evals = h->opt.max_num_iterations + (fused ? 0 : 1);
+    const int total_evals = h->opt.max_num_iterations;
     const int chunk = 12;
     int issued = 0;
     while (issued < total_evals) {
@@ -1074,7 +1149,7 @@ int do_solve(mvo_hip_context* h) {
           HIP_TRY(timed_end());
           ++asm_launches;
         }
-        HIP_TRY(launch_lm_any(h, pp, fused));
+        HIP_TRY(launch_lm_any(h, pp, true));
         ++lm_launches;
       }
       issued += n;
@@ -1256,7 +1331,7 @@ void mvo_hip_destroy(mvo_hip_handle h) {
   if (h->comm) (void)mvo_rccl().CommDestroy(h->comm);
   h->comm = nullptr;
   DevBuf* bufs[] = {&h->d_arena, &h->d_m0, &h->d_m1, &h->d_c, &h->d_partial, &h->d_pair_u, &h->d_states,
-                    &h->d_ctl, &h->d_trace, &h->d_res, &h->d_jac, &h->d_pairsum, &h->d_pticket};
+                    &h->d_ctl, &h->d_trace, &h->d_res, &h->d_jac, &h->d_pairsum, &h->d_pticket, &h->d_proj, &h->d_cls};
   for (DevBuf* b : bufs) b->release();
   if (h->h_arena) (void)hipHostFree(h->h_arena);
   if (h->h_ctl) (void)hipHostFree(h->h_ctl);
@@ -1436,16 +1511,18 @@ int mvo_hip_partial_advance(mvo_hip_handle h, int32_t* done) {
 
 int mvo_hip_partial_sums(mvo_hip_handle h, void* device_buffer, uint64_t n_doubles, int direction) {
   if (!h || !device_buffer) return MVO_HIP_ERR_INVALID_ARGUMENT;
-  if (!h->uploaded || !h->d_pairsum.p) return MVO_HIP_ERR_STATE;
-  if (n_doubles != 8ull * h->W * h->P) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  if (!h->uploaded || !partial_buffer(h)) return MVO_HIP_ERR_STATE;
+  if (n_doubles != partial_count(h)) return MVO_HIP_ERR_INVALID_ARGUMENT;
   HIP_TRY(hipSetDevice(h->device));
   if (direction == 0)
-    HIP_TRY(hipMemcpyAsync(device_buffer, h->d_pairsum.p, sizeof(double) * n_doubles, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(device_buffer, partial_buffer(h), sizeof(double) * n_doubles, hipMemcpyDeviceToDevice, h->stream));
   else
-    HIP_TRY(hipMemcpyAsync(h->d_pairsum.p, device_buffer, sizeof(double) * n_doubles, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(partial_buffer(h), device_buffer, sizeof(double) * n_doubles, hipMemcpyDeviceToDevice, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return MVO_HIP_OK;
 }
+
+uint64_t mvo_hip_partial_sums_count(mvo_hip_handle h) { return h && h->uploaded ? (uint64_t)partial_count(h) : 0; }
 
 int mvo_hip_comm_unique_id(void* id_out) {
   if (!id_out) return MVO_HIP_ERR_INVALID_ARGUMENT;
@@ -1795,8 +1872,8 @@ int mvo_hip_refine_noalloc(int device_ordinal, void* stream, mvo_hip_frame* fram
     hipLaunchKernelGGL(kernel, dim3(1), dim3(nt), 0, s, prm, 1, wins, fr,
                        reinterpret_cast<const double*>(sc + kNaInitX), pairs, (const double*)sums, m0_device,
                        m1_device, sums, reinterpret_cast<LmState*>(sc + kNaState),
-                       reinterpret_cast<LmResult*>(sc + kNaResult), (double*)nullptr, ctl, (TraceRec*)nullptr,
-                       ctl + 16);
+                       reinterpret_cast<LmResult*>(sc + kNaResult), ctl, (TraceRec*)nullptr,
+                       ctl + 16, (const double*)nullptr, (const double*)nullptr, (double*)nullptr);
   };
   if (small) launch(k_lm<64>, 64);
   else launch(k_lm<MVO_LM_NT_LARGE>, MVO_LM_NT_LARGE);

@@ -84,6 +84,74 @@ __device__ __forceinline__ void pass_accum(double cx, double cy, double cz, doub
   S[5] = fma(wz, cz, S[5]);
 }
 
+// ---------------------------------------------------------------------------------------
+// Pass mode (a loss, or assembly_mode = PASSES): what an observation pass leaves for the LM step.
+// k_lm publishes the unit baseline (u, |baseline|) of every pair at the point under evaluation; the
+// workgroup that completes a pair (the ticket tails below) also PROJECTS the pair's sums.  A relaunched
+// k_lm -- one evaluation per launch -- then reads ten numbers per pair and adds its classes up instead of
+// running its per-pair stage (sqrt, reciprocal, ~100 flops per pair, up to eight pairs per lane) as ONE
+// workgroup per window while the chip idles.  The projections are linear in the sums: in the
+// observation-partitioned solve every rank projects its share, adds its classes up (k_class_sums) and the
+// ranks all-reduce MVO_CLS_DOUBLES numbers per window (the "already-contracted" form).
+// Measured and dropped (profiles/r3/NOTES.md): a second ticket level in the tails that also adds the
+// classes up (three more dependent L2 round trips at the end of every pass), and passes that form the
+// unit baselines themselves from a 20-number point (registers and a square root per tile).
+// ---------------------------------------------------------------------------------------
+constexpr int MVO_MCX = MVO_MAXM + 1;  // classes per frame a: j = min(b, M) in 0..M   (== MCX of mvo_lm.h)
+
+struct PassOut {
+  const double* upairs;  // [W * P][4]: (u, |baseline|) per pair at the point under evaluation
+  double* proj;          // [W * P][10]: T(6) q(3) cost(1) per pair (project_pair8); nullptr: sums only
+};
+
+// Projected moments of one frame pair from its 8 pass sums, by the 8 consecutive lanes that hold them
+// (lane v of the group: sum v).  With u = the pair's unit baseline, nb its length and P = (I - u u^T) / nb:
+//   o[0..5] = P S P (xx,xy,xz,yy,yz,zz)   o[6..8] = P S u   o[9] = 1/2 sum rho
+// -- what k_lm's per-pair stage (pair_eval, mvo_lm.h) computes from the sums.  Lane v returns o[v]; lanes
+// 0 and 1 also o[8], o[9] in `extra`.  Linear in S: ranks that hold a share of the pair's residual blocks
+// project their share.
+__device__ __forceinline__ double project_pair8(double acc, int lane, const double (&u)[3], double nb, double& extra) {
+#pragma clang fp contract(off)
+  const int base = lane & ~7, v = lane & 7;
+  double S[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) S[j] = __shfl(acc, base + j, 64);
+  const double u0 = u[0], u1 = u[1], u2 = u[2];
+  const double inb = fast_rcp(nb), inb2 = inb * inb;
+  const double Su0 = fma(S[2], u2, fma(S[1], u1, S[0] * u0));
+  const double Su1 = fma(S[4], u2, fma(S[3], u1, S[1] * u0));
+  const double Su2 = fma(S[5], u2, fma(S[4], u1, S[2] * u0));
+  const double uSu = fma(u2, Su2, fma(u1, Su1, u0 * Su0));
+  double o[10];
+  o[0] = fma(u0 * u0, uSu, fma(-2.0 * u0, Su0, S[0])) * inb2;
+  o[1] = fma(u0 * u1, uSu, fma(-Su0, u1, fma(-u0, Su1, S[1]))) * inb2;
+  o[2] = fma(u0 * u2, uSu, fma(-Su0, u2, fma(-u0, Su2, S[2]))) * inb2;
+  o[3] = fma(u1 * u1, uSu, fma(-2.0 * u1, Su1, S[3])) * inb2;
+  o[4] = fma(u1 * u2, uSu, fma(-Su1, u2, fma(-u1, Su2, S[4]))) * inb2;
+  o[5] = fma(u2 * u2, uSu, fma(-2.0 * u2, Su2, S[5])) * inb2;
+  o[6] = fma(-u0, uSu, Su0) * inb;
+  o[7] = fma(-u1, uSu, Su1) * inb;
+  o[8] = fma(-u2, uSu, Su2) * inb;
+  o[9] = 0.5 * S[6];
+  double mine = o[0];
+#pragma unroll
+  for (int j = 1; j < 8; ++j) mine = v == j ? o[j] : mine;
+  extra = v ? o[9] : o[8];
+  return mine;
+}
+
+// The 8 lanes holding pair p's sums (acc; lane v: sum v) project the pair and store the projection.
+__device__ __forceinline__ void pair_project_store(const PassOut& po, uint32_t p, double acc, int lane) {
+  const double* __restrict__ up = po.upairs + 4 * (size_t)p;
+  const double u[3] = {up[0], up[1], up[2]};
+  double extra;
+  const double mine = project_pair8(acc, lane, u, up[3], extra);
+  const int v = lane & 7;
+  double* __restrict__ out = po.proj + 10 * (size_t)p;
+  out[v] = mine;
+  if (v < 2) out[8 + v] = extra;
+}
+
 // The workgroup that stores the LAST slot of a frame pair adds that pair's slots up (what k_reduce_slots
 // does as a launch of its own): k_lm then reads 8 sums per pair instead of walking slot lists, a chain
 // of dependent L2 round trips per slot.  "Last" is decided by one ticket counter per pair -- the only
@@ -91,9 +159,12 @@ __device__ __forceinline__ void pass_accum(double cx, double cy, double cz, doub
 // it, bit for bit what k_reduce_slots gives.  No workgroup waits for another one.
 // pair_ticket == nullptr: no tail (launches over a range of the workgroups, partitioned mode).
 // `red` (the workgroup's reduction buffer, free after block_store_partials) holds the to-do list.
+// po.proj != nullptr (the sums are those of a pass at the unit baselines po.upairs): the finishing workgroup
+// also projects the pair (project_pair8).
 __device__ __forceinline__ void block_finish_pairs(int32_t* pair_ticket, const TileDev* __restrict__ tiles, uint32_t bt0,
                                                    uint32_t bt1, const PairDev* __restrict__ pairs, double* red,
-                                                   const double* partial, double* __restrict__ pair_sums) {
+                                                   const double* partial, double* __restrict__ pair_sums,
+                                                   const PassOut& po) {
   if (pair_ticket == nullptr) return;
   __shared__ uint32_t n_todo;
   // The slot stores above are device-coherent (written through the XCD's L2) and every wavefront has
@@ -118,6 +189,7 @@ __device__ __forceinline__ void block_finish_pairs(int32_t* pair_ticket, const T
   }
   __syncthreads();
   const uint32_t nq = n_todo;
+  const bool project = po.proj != nullptr;
   for (uint32_t item = threadIdx.x; item < nq * 8; item += FOLD_THREADS) {
     const uint32_t p = todo[item >> 3], v = item & 7;
     const PairDev pd = pairs[p];
@@ -125,6 +197,8 @@ __device__ __forceinline__ void block_finish_pairs(int32_t* pair_ticket, const T
     for (uint32_t sl = pd.slot_begin; sl < pd.slot_end; ++sl)
       acc += __hip_atomic_load(partial + (size_t)sl * 8 + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     pair_sums[(size_t)p * 8 + v] = acc;
+    // (the 8 items of a pair are 8 consecutive lanes, all inside the loop together: 8 | FOLD_THREADS)
+    if (project) pair_project_store(po, p, acc, (int)(threadIdx.x & 63));
   }
 }
 
@@ -142,9 +216,9 @@ __global__ __launch_bounds__(FOLD_THREADS) void k_fold(const TileDev* __restrict
                                                        const double* __restrict__ m0,
                                                        const double* __restrict__ m1,
                                                        double* __restrict__ cbuf, size_t cstride,
-                                                       double* partial, const double* __restrict__ pair_u0,
-                                                       int32_t* pair_ticket, const PairDev* __restrict__ pairs,
-                                                       double* __restrict__ pair_sums) {
+                                                       double* partial, int32_t* pair_ticket,
+                                                       const PairDev* __restrict__ pairs,
+                                                       double* __restrict__ pair_sums, PassOut po) {
   static_assert(!(MOMENTS && PASS0), "either the plain moments or the pass sums");
   extern __shared__ double red[];  // [tiles of this workgroup][8]
   const int lane = threadIdx.x & 63;
@@ -165,9 +239,9 @@ __global__ __launch_bounds__(FOLD_THREADS) void k_fold(const TileDev* __restrict
                    b7 = R1[7], b8 = R1[8];
       double u0 = 0.0, u1 = 0.0, u2 = 0.0;
       if (PASS0) {
-        u0 = pair_u0[4 * (size_t)tl.pair];
-        u1 = pair_u0[4 * (size_t)tl.pair + 1];
-        u2 = pair_u0[4 * (size_t)tl.pair + 2];
+        u0 = po.upairs[4 * (size_t)tl.pair];
+        u1 = po.upairs[4 * (size_t)tl.pair + 1];
+        u2 = po.upairs[4 * (size_t)tl.pair + 2];
       }
       // (two rays per lane through 16-byte loads were tried: 7 % slower than one 8-byte load per component,
       // profiles/r2b/NOTES.md -- the fold runs at 5.1 TB/s, 81 % of what a plain copy reaches on this chip)
@@ -224,7 +298,7 @@ __global__ __launch_bounds__(FOLD_THREADS) void k_fold(const TileDev* __restrict
   }
   if (MOMENTS || PASS0) {
     block_store_partials(tiles, bt0, bt1, red, partial, pair_ticket != nullptr);
-    block_finish_pairs(pair_ticket, tiles, bt0, bt1, pairs, red, partial, pair_sums);
+    block_finish_pairs(pair_ticket, tiles, bt0, bt1, pairs, red, partial, pair_sums, po);
   }
 }
 
@@ -237,11 +311,10 @@ template <bool ROBUST>
 __global__ __launch_bounds__(FOLD_THREADS) void k_pass(const TileDev* __restrict__ tiles,
                                                        const uint32_t* __restrict__ wave_tiles, uint32_t n_waves,
                                                        const double* __restrict__ cbuf, size_t cstride,
-                                                       const double* __restrict__ pair_u,
                                                        const int32_t* __restrict__ win_status,
                                                        double* partial, int32_t* pair_ticket,
                                                        const PairDev* __restrict__ pairs,
-                                                       double* __restrict__ pair_sums) {
+                                                       double* __restrict__ pair_sums, PassOut po) {
   extern __shared__ double red[];
   const int lane = threadIdx.x & 63;
   const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -255,8 +328,8 @@ __global__ __launch_bounds__(FOLD_THREADS) void k_pass(const TileDev* __restrict
       const TileDev tl = tiles[t];
       double S[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       if (win_status[tl.win] == 0) {
-        const double u0 = pair_u[4 * (size_t)tl.pair], u1 = pair_u[4 * (size_t)tl.pair + 1],
-                     u2 = pair_u[4 * (size_t)tl.pair + 2];
+        const double u0 = po.upairs[4 * (size_t)tl.pair], u1 = po.upairs[4 * (size_t)tl.pair + 1],
+                     u2 = po.upairs[4 * (size_t)tl.pair + 2];
         // 16-byte loads need an even start: step back one element when the tile starts odd
         const uint32_t head = tl.c_start & 1u;
         const double* __restrict__ cx = cbuf + (tl.c_start - head);
@@ -289,23 +362,26 @@ __global__ __launch_bounds__(FOLD_THREADS) void k_pass(const TileDev* __restrict
     }
   }
   block_store_partials(tiles, bt0, bt1, red, partial, pair_ticket != nullptr);
-  block_finish_pairs(pair_ticket, tiles, bt0, bt1, pairs, red, partial, pair_sums);
+  block_finish_pairs(pair_ticket, tiles, bt0, bt1, pairs, red, partial, pair_sums, po);
 }
 
 // ---------------------------------------------------------------------------------------
 // k_reduce_slots: per-pair sums of the slot partials (observation-partitioned mode: these 8
 // numbers per pair are what the ranks all-reduce before the identical LM step).
 // ---------------------------------------------------------------------------------------
+// po.proj != nullptr: also the pairs' projected moments -- the launch-of-its-own form of the passes' tails
+// (MVO_HIP_NO_TAILS: the tails' bit-for-bit reference).
 __global__ __launch_bounds__(256) void k_reduce_slots(const PairDev* __restrict__ pairs, uint32_t n_pairs,
                                                       const double* __restrict__ partial,
-                                                      double* __restrict__ pair_sums) {
+                                                      double* __restrict__ pair_sums, PassOut po) {
   const uint32_t item = blockIdx.x * 256 + threadIdx.x;
-  if (item >= n_pairs * 8) return;
+  if (item >= n_pairs * 8) return;  // (whole groups of 8 lanes leave together)
   const uint32_t p = item >> 3, v = item & 7;
   const PairDev pd = pairs[p];
   double acc = 0.0;
   for (uint32_t sl = pd.slot_begin; sl < pd.slot_end; ++sl) acc += partial[(size_t)sl * 8 + v];
   pair_sums[item] = acc;
+  if (po.proj != nullptr) pair_project_store(po, p, acc, (int)(threadIdx.x & 63));
 }
 
 // ---------------------------------------------------------------------------------------

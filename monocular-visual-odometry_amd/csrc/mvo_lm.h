@@ -25,6 +25,8 @@
 #include "mvo_device.h"
 #include "mvo_kernels.h"
 
+#include <stddef.h>
+
 #define MVO_LM_NT_LARGE 256
 
 // Diagnostic build only (-DMVO_LM_STAMPS): thread 0 of window 0 accumulates the shader-clock
@@ -173,6 +175,10 @@ struct LmShared {
   double gmn_z;                                 // k_lm<256>: gradient max norm at z (helper wavefront)
   int32_t go, phase, hsel, pad_;
 };
+
+static_assert(offsetof(LmShared, kk) == offsetof(LmShared, cls) + sizeof(double) * MVO_MAXM * MCX * 10,
+              "cls and kk are copied in as one block (SolveParams::cls_ready)");
+static_assert((MVO_MAXM * MCX + MVO_MAXM) * 10 <= MVO_CLS_DOUBLES, "class totals per window");
 
 // The solver state in wavefront 0's registers.
 struct LmRegs {
@@ -850,6 +856,17 @@ __device__ __forceinline__ void pair_eval(const PairIn& in, const double (&beta)
   o[9] = pass_mode ? 0.5 * S[6] : 0.5 * uSu;  // 1/2 sum rho from the pass, or the moment form
 }
 
+// the pair's projected moments as the pass's tail left them (project_pair8): ten doubles, 16-byte loads
+__device__ __forceinline__ void proj_load(const double* __restrict__ proj, size_t pair, double (&o)[10]) {
+  const double2* __restrict__ q = reinterpret_cast<const double2*>(proj + 10 * pair);
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const double2 t = q[j];
+    o[2 * j] = t.x;
+    o[2 * j + 1] = t.y;
+  }
+}
+
 // symmetric 3x3 stored as (xx,xy,xz,yy,yz,zz)
 __device__ __forceinline__ int sym6(int r, int c) {
   const int lo = r < c ? r : c, hi = r < c ? c : r;
@@ -967,7 +984,71 @@ __device__ __forceinline__ void lm_class_wave(LmShared& sh, const SolveParams& p
                                               bool& need_pass, int unit_slots, const PairDev* __restrict__ wp,
                                               const double* partial, uint32_t pair_off, const double* __restrict__ fr,
                                               const double* __restrict__ m0, const double* __restrict__ m1,
-                                              double* my_sums) {
+                                              double* my_sums, const double* __restrict__ proj) {
+  if (prm.proj_ready) {
+    // Pass mode with the passes as launches of their own: this launch is ONE evaluation long and the pass's
+    // tails left every pair projected (project_pair8, mvo_kernels.h).  Wavefront cw adds up the long classes
+    // of frames cw and cw + 3: lanes over b, all loads of both frames requested before the first use (one
+    // memory latency), then one register butterfly per frame.  Same barriers as the loop below.
+    constexpr int ROUNDS = 4;
+    const int n_pairs_a = N - 1 > M ? N - 1 - M : 0;
+    const int n_rounds = (n_pairs_a + 63) >> 6;  // wave-uniform
+    const double* __restrict__ pw = proj + 10 * (size_t)pair_off;
+    double o[2][ROUNDS][10];
+    bool ok[2][ROUNDS];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int rr = 0; rr < ROUNDS; ++rr) {
+        const int a = cw + 3 * q, b = M + lane + 64 * rr;
+        ok[q][rr] = a < M && b <= N - 2;
+        if (rr < n_rounds && (q == 0 || cw + 3 < M))  // wave-uniform: rounds and frames that exist
+          proj_load(pw, (size_t)(ok[q][rr] ? pair_index(N, a, b) : 0), o[q][rr]);
+      }
+    const BlockRole br = block_role(M, lane);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int a = cw + 3 * q;
+      if (a < M) {  // wave-uniform
+        double acc[10];
+#pragma unroll
+        for (int v = 0; v < 10; ++v) {
+          acc[v] = 0.0;
+#pragma unroll
+          for (int rr = 0; rr < ROUNDS; ++rr)
+            if (rr < n_rounds) acc[v] += ok[q][rr] ? o[q][rr][v] : 0.0;
+        }
+        double t8, t2;
+        wave_reduce10(acc, lane, t8, t2);
+        if ((lane & 7) == 0) sh.cls[a * MCX + M][reduce8_value_of_lane(lane)] = t8;
+        if ((lane & 31) == 0) sh.cls[a * MCX + M][8 + (lane >> 5)] = t2;
+      }
+    }
+    __syncthreads();  // B1
+    __syncthreads();  // B1b
+    if (cw == 0) lm_block_rows<1>(sh, br, lane, sh.hsel ? sh.st.H : sh.Hz);
+    else if (cw == 1) lm_gradient_and_norm(sh, M, prm.fix_length, lane);
+    else lm_block_rows<2>(sh, br, lane, sh.hsel ? sh.st.H : sh.Hz);
+    __syncthreads();  // B1c
+    __syncthreads();  // B2
+    if (sh.go) need_pass = true;
+    return;
+  }
+  if (prm.cls_ready) {
+    // Observation-partitioned pass mode: the class totals arrive ready-made, summed over all ranks
+    // (k_class_sums + all-reduce), and this launch is one evaluation long -- the class wavefronts only
+    // multiply out the system.  Same barriers as below.
+    const BlockRole br = block_role(M, lane);
+    __syncthreads();  // B1
+    __syncthreads();  // B1b
+    if (cw == 0) lm_block_rows<1>(sh, br, lane, sh.hsel ? sh.st.H : sh.Hz);
+    else if (cw == 1) lm_gradient_and_norm(sh, M, prm.fix_length, lane);
+    else lm_block_rows<2>(sh, br, lane, sh.hsel ? sh.st.H : sh.Hz);
+    __syncthreads();  // B1c
+    __syncthreads();  // B2
+    if (sh.go) need_pass = true;
+    return;
+  }
   constexpr int ROUNDS = 4;  // class (a, M) has at most MVO_HIP_MAX_FRAMES - 1 - M <= 256 pairs
   constexpr int NA = 2;      // frames per class wavefront: cw and cw + 3
   const int n_pairs_a = N - 1 > M ? N - 1 - M : 0;
@@ -1087,13 +1168,20 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
                                            double* pair_sums,  // may alias `partial` (inline evaluation)
                                            LmState* __restrict__ states,
                                            LmResult* __restrict__ results,
-                                           double* __restrict__ pair_u, int32_t* __restrict__ win_status,
-                                           TraceRec* __restrict__ trace, int32_t* __restrict__ done_count) {
+                                           int32_t* __restrict__ win_status,
+                                           TraceRec* __restrict__ trace, int32_t* __restrict__ done_count,
+                                           const double* __restrict__ proj,    // prm.proj_ready: 10 doubles per pair
+                                           const double* __restrict__ cls_in,  // prm.cls_ready: MVO_CLS_DOUBLES per window
+                                           double* __restrict__ pair_u) {      // pass mode: (u, |baseline|) per pair for the next pass
   constexpr bool LARGE = NT > 64;
   static_assert(NT == 64 || NT == MVO_LM_NT_LARGE, "one wavefront, or three class wavefronts + one for the short pairs and the LM step");
   __shared__ LmShared sh;
   __shared__ double pairbuf[LARGE ? 1 : 64 * 10];  // k_lm<64>: P x 10: T(6) q(3) cost(1)
   __shared__ double inl_sums[LARGE ? 1 : 64 * 8];   // k_lm<64>, inline evaluation: the passes' 8 sums per pair
+  // pass mode with the passes as launches of their own: the fixed-frame offsets n_b v_b (IR.cpp:137-144) that
+  // the epilogue's unit baselines need, requested in the launch's first instructions together with the state
+  constexpr int FOFF_FRAMES = LARGE ? MVO_HIP_MAX_FRAMES : 72;  // k_lm<64>: P <= 64, hence N <= 65
+  __shared__ double sfoff[3 * FOFF_FRAMES];
   const int w = (int)blockIdx.x + prm.win_base, tid = threadIdx.x;
 #ifdef MVO_LM_STAMPS
   const unsigned long long stamp_entry_ = __builtin_amdgcn_s_memtime();
@@ -1128,6 +1216,14 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
   // are identity rows) -- so the second buffer starts from zero like the first.
   for (int i = tid; i < MVO_MAXC * MVO_MAXC; i += NT) sh.Hz[i] = 0.0;
   if (tid == 0) sh.hsel = 0;
+  if (prm.pass_mode && !prm.inline_eval)  // (uniform) this launch ends by publishing every pair's unit baseline
+    for (int b = tid; b < N && b < FOFF_FRAMES; b += NT) {
+      const double* __restrict__ f = fr + MVO_FRAME_DOUBLES * b;
+      const double nb = f[12];
+      sfoff[3 * b] = nb * f[9];
+      sfoff[3 * b + 1] = nb * f[10];
+      sfoff[3 * b + 2] = nb * f[11];
+    }
   __syncthreads();
   if (sh.st.status != 0) return;  // a window that has terminated (uniform)
   LmRegs r;      // wavefront 0: the solver state, in registers until the launch ends
@@ -1177,7 +1273,7 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
   // k_lm<64>:  lane p evaluates pair p.
   // k_lm<256>: wavefronts 1..3 take the pairs (a, b >= M) (lm_class_wave); wavefront 0's lane i the
   //            i-th pair with b < M (a = 0: b = 0..M-1, a = 1: b = 1..M-1, ...), then the LM step.
-  if (LARGE && !wave0) lm_class_wave<NT>(sh, prm, wv - 1, lane, M, N, P, need_pass, unit_slots, wp, partial, win.pair_off, fr, m0, m1, my_sums);
+  if (LARGE && !wave0) lm_class_wave<NT>(sh, prm, wv - 1, lane, M, N, P, need_pass, unit_slots, wp, partial, win.pair_off, fr, m0, m1, my_sums, proj);
   int my_p0 = lane < P ? lane : 0;
   bool my_ok0 = lane < P;
   int my_a = 0, my_j = 0;  // k_lm<256>: the short pair's (a, b)
@@ -1206,22 +1302,46 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
     // (1) per frame pair: projected moments.  Without a loss the moments never change: the inputs are
     // loaded once and stay in registers.  Loads are unconditional, at a clamped pair index: a load
     // inside a divergent `if` is waited for on the spot, which would serialise the L2 latencies.
-    if (!have_in) {
-      if (!LARGE && prm.inline_eval) pair_load_lds(in0, my_p0, N, M, inl_sums, fr);
-      else pair_load(in0, my_p0, N, M, unit_slots != 0, wp, partial, win.pair_off, fr);
-      have_in = !prm.pass_mode;
-    }
-    {
+    if (prm.cls_ready) {
+      // observation-partitioned pass mode: the class totals of this evaluation arrive ready-made, summed over
+      // all ranks (k_class_sums + all-reduce); cls and kk are contiguous in LmShared
+      double* __restrict__ dst = &sh.cls[0][0];
+      const double2* __restrict__ src = reinterpret_cast<const double2*>(cls_in + (size_t)w * MVO_CLS_DOUBLES);
+      constexpr int NV = (MVO_MAXM * MCX + MVO_MAXM) * 10 / 2;  // 175 16-byte pieces: three loads per lane, issued together
+      double2 t[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) t[q] = src[lane + 64 * q < NV ? lane + 64 * q : 0];
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        if (lane + 64 * q < NV) {  // (8-byte LDS stores: LmShared::cls is not 16-byte aligned)
+          dst[2 * (lane + 64 * q)] = t[q].x;
+          dst[2 * (lane + 64 * q) + 1] = t[q].y;
+        }
+    } else {
       double o[10], beta[3];
-      free_baseline(sh, in0.a, in0.b < M - 1 ? in0.b : M - 1, beta);
-      pair_eval(in0, beta, prm.pass_mode, o);
+      int pa, pb;
+      if (prm.proj_ready) {
+        // pass mode, passes as launches of their own: the pass's tail projected every pair -- nothing to evaluate
+        pair_ab(N, M, my_p0, pa, pb);
+        proj_load(proj, (size_t)win.pair_off + my_p0, o);
+      } else {
+        if (!have_in) {
+          if (!LARGE && prm.inline_eval) pair_load_lds(in0, my_p0, N, M, inl_sums, fr);
+          else pair_load(in0, my_p0, N, M, unit_slots != 0, wp, partial, win.pair_off, fr);
+          have_in = !prm.pass_mode;
+        }
+        free_baseline(sh, in0.a, in0.b < M - 1 ? in0.b : M - 1, beta);
+        pair_eval(in0, beta, prm.pass_mode, o);
+        pa = in0.a;
+        pb = in0.b;
+      }
       if (my_ok0) {
         double* __restrict__ dst = LARGE ? sh.cls[my_a * MCX + my_j] : pairbuf + lane * 10;
 #pragma unroll
         for (int v = 0; v < 10; ++v) dst[v] = o[v];
-        if (in0.a == in0.b) {
+        if (pa == pb) {
 #pragma unroll
-          for (int v = 0; v < 10; ++v) sh.kk[in0.a][v] = o[v];
+          for (int v = 0; v < 10; ++v) sh.kk[pa][v] = o[v];
         }
       }
     }
@@ -1235,7 +1355,7 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
       // exist (a > j, a >= M, j > M) count as zero, so every entry of C1 is defined.
       if (lane < MCX * 10) {
         double x[MVO_MAXM];
-        if (LARGE) {
+        if (LARGE || prm.cls_ready) {
 #pragma unroll
           for (int a = 0; a < MVO_MAXM; ++a) x[a] = sh.cls[a * MCX + jA][vA];  // reads issue back to back
         } else {
@@ -1306,15 +1426,27 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
   }
 
   if (need_pass) {
-    // publish the unit baselines of the point to evaluate; k_pass runs next on the stream
+    // publish the unit baselines of the point to evaluate; k_pass runs next on the stream.  (a, b) by
+    // arithmetic, the point and the fixed-frame offsets from LDS: no global load stands between a thread and
+    // its (up to five) pairs.  One reciprocal instead of three divisions: u differs from beta / |beta| by
+    // <= 1 ulp, and pass and projection both read THIS u.
     for (int p = tid; p < P; p += NT) {
-      const PairDev pd = wp[p];
-      double u[3], nb;
-      pair_unit_baseline(fr, M, (int)pd.a, (int)pd.b, sh.zvec, sh.zs, u, nb);
+      int a, b;
+      pair_ab(N, M, p, a, b);
+      double beta[3];
+      free_baseline(sh, a, b < M - 1 ? b : M - 1, beta);
+      if (b >= M) {  // IR.cpp:137-144: only frame b itself
+        const int bb = b < FOFF_FRAMES ? b : 0;
+        beta[0] += sfoff[3 * bb];
+        beta[1] += sfoff[3 * bb + 1];
+        beta[2] += sfoff[3 * bb + 2];
+      }
+      const double nb = sqrt(beta[0] * beta[0] + beta[1] * beta[1] + beta[2] * beta[2]);
+      const double inb = fast_rcp(nb);
       double* __restrict__ o = pair_u + 4 * (size_t)(win.pair_off + p);
-      o[0] = u[0];
-      o[1] = u[1];
-      o[2] = u[2];
+      o[0] = beta[0] * inb;
+      o[1] = beta[1] * inb;
+      o[2] = beta[2] * inb;
       o[3] = nb;
     }
   }
@@ -1368,5 +1500,60 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
       win_status[w] = 1;
       atomicAdd(done_count, 1);
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_class_sums (observation-partitioned pass mode): this rank's class totals from its pairs' projected
+// moments -- what k_lm's per-pair stage leaves in LmShared::cls / kk -- as MVO_CLS_DOUBLES per window in
+// HBM.  The projection is linear in the pair's sums and the class totals are sums of projections, so the
+// ranks' class totals add up to the window's: ONE all-reduce of 350 fp64 per window and evaluation
+// ("the already-contracted" form) instead of 8 per pair, and no rank repeats the per-pair
+// stage.  One workgroup per window, one wavefront per refined frame a: its long class (a, b >= M), lanes
+// over b (up to four rounds, loads requested together); the short pairs (a, b < M) are classes of their
+// own and are copied.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * MVO_MAXM) void k_class_sums(int M, int N, int P, const double* __restrict__ proj,
+                                                             double* __restrict__ cls_out) {
+  constexpr int ROUNDS = 4;
+  const int w = blockIdx.x, lane = threadIdx.x & 63;
+  const int a = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const double* __restrict__ pw = proj + 10 * (size_t)w * P;
+  double* __restrict__ out = cls_out + (size_t)w * MVO_CLS_DOUBLES;
+  // entries no class owns (a > j, a >= M) are never read by k_lm; they are zeroed because the all-reduce adds them
+  for (int i = threadIdx.x; i < MVO_CLS_DOUBLES; i += 64 * MVO_MAXM) {
+    const int row = i / 10, ra = row / MCX, rj = row - ra * MCX;
+    const bool owned = row < MVO_MAXM * MCX ? (ra < M && rj >= ra && rj <= M) : (row - MVO_MAXM * MCX < M);
+    if (!owned) out[i] = 0.0;
+  }
+  if (a >= M) return;
+  const int n_rounds = ((N - 1 > M ? N - 1 - M : 0) + 63) >> 6;
+  double o[ROUNDS][10];
+  bool ok[ROUNDS];
+#pragma unroll
+  for (int rr = 0; rr < ROUNDS; ++rr) {
+    const int b = M + lane + 64 * rr;
+    ok[rr] = b <= N - 2;
+    if (rr < n_rounds) proj_load(pw, (size_t)(ok[rr] ? pair_index(N, a, b) : 0), o[rr]);
+  }
+  double acc[10];
+#pragma unroll
+  for (int v = 0; v < 10; ++v) {
+    acc[v] = 0.0;
+#pragma unroll
+    for (int rr = 0; rr < ROUNDS; ++rr)
+      if (rr < n_rounds) acc[v] += ok[rr] ? o[rr][v] : 0.0;
+  }
+  double t8, t2;
+  wave_reduce10(acc, lane, t8, t2);
+  double* __restrict__ cm = out + (a * MCX + M) * 10;
+  if ((lane & 7) == 0) cm[reduce8_value_of_lane(lane)] = t8;
+  if ((lane & 31) == 0) cm[8 + (lane >> 5)] = t2;
+  // short pairs (a, j), a <= j < M: lane = (j - a) * 10 + v
+  const int jj = a + lane / 10, v = lane % 10;
+  if (jj < M && lane < 10 * MVO_MAXM) {
+    const double x = pw[10 * (size_t)pair_index(N, a, jj) + v];
+    out[(a * MCX + jj) * 10 + v] = x;
+    if (jj == a) out[(MVO_MAXM * MCX + a) * 10 + v] = x;  // kk[a]
   }
 }

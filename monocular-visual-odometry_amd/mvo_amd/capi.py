@@ -35,7 +35,7 @@ EXPORTED_SYMBOLS = [
     "mvo_hip_set_profiling",
     "mvo_hip_get_trace", "mvo_hip_get_timing", "mvo_hip_reverse_scale", "mvo_hip_scale",
     "mvo_hip_num_pairs", "mvo_hip_status_string", "mvo_hip_version", "mvo_hip_partial_begin",
-    "mvo_hip_partial_pass", "mvo_hip_partial_advance", "mvo_hip_partial_sums", "mvo_hip_debug_poison_lds",
+    "mvo_hip_partial_pass", "mvo_hip_partial_advance", "mvo_hip_partial_sums", "mvo_hip_partial_sums_count", "mvo_hip_debug_poison_lds",
     "mvo_hip_debug_check_guards", "mvo_hip_refine_noalloc", "mvo_hip_eval_at", "mvo_hip_debug_set_point",
     "mvo_hip_debug_pair_sums", "mvo_hip_comm_unique_id", "mvo_hip_comm_init", "mvo_hip_comm_destroy", "mvo_hip_solve_partitioned",
 ]
@@ -156,6 +156,8 @@ def load():
         L.mvo_hip_partial_pass.argtypes = [C.c_void_p]
         L.mvo_hip_partial_advance.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
         L.mvo_hip_partial_sums.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]
+        L.mvo_hip_partial_sums_count.argtypes = [C.c_void_p]
+        L.mvo_hip_partial_sums_count.restype = C.c_uint64
         L.mvo_hip_refine_noalloc.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(Options),
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         L.mvo_hip_get_trace.argtypes = [C.c_void_p, C.POINTER(Iteration), C.c_int32, C.POINTER(C.c_int32)]
@@ -294,9 +296,14 @@ class Solver:
         return frames.reshape(self._W, self._N, 13), (list(self._summ_out) if copy else self._summ_out)
 
     # -- observation-partitioned mode (one window over several GPUs) -------------------------
+    def partial_sums_count(self):
+        """Doubles the ranks exchange per all-reduce for the current upload: 8 per pair without a loss,
+        the contracted class totals (352 per window) with one."""
+        return int(self._lib.mvo_hip_partial_sums_count(self._h))
+
     def solve_partitioned(self, allreduce, sums):
         """Solve the uploaded SHARD together with the other ranks.  `sums` is a device tensor of
-        8 * n_windows * n_pairs float64 (anything with .data_ptr() and .numel()); `allreduce(sums)`
+        partial_sums_count() float64 (anything with .data_ptr() and .numel()); `allreduce(sums)`
         must sum it in place over all ranks and return after the result is usable by other streams
         (torch.distributed.all_reduce + torch.cuda.synchronize()).  Every rank ends with the same
         refined frames; fetch them with download()."""
@@ -313,14 +320,12 @@ class Solver:
 
         check(lib.mvo_hip_partial_begin(self._h), "mvo_hip_partial_begin")
         done = C.c_int32(0)
-        if not self._pass_mode:
+        for _ in range(100000):
             exchange()
             check(lib.mvo_hip_partial_advance(self._h, C.byref(done)), "mvo_hip_partial_advance")
-        else:
-            while not done.value:
-                check(lib.mvo_hip_partial_pass(self._h), "mvo_hip_partial_pass")
-                exchange()
-                check(lib.mvo_hip_partial_advance(self._h, C.byref(done)), "mvo_hip_partial_advance")
+            if done.value or not self._pass_mode:
+                break
+            check(lib.mvo_hip_partial_pass(self._h), "mvo_hip_partial_pass")
         if not done.value:
             raise MvoHipError(ERR_DEVICE, "partitioned solve did not terminate")
 
@@ -415,6 +420,7 @@ def refine_noalloc(device, stream, frames_ptr, M, N, options, offsets_ptr, m0_pt
 
 
 COMM_ID_BYTES = 128
+CLASS_DOUBLES = 352  # MVO_HIP_CLASS_DOUBLES
 
 
 def comm_unique_id() -> bytes:

@@ -41,6 +41,44 @@ def shard_observations(w: "scene.Window", rank: int, world: int) -> "scene.Windo
     )
 
 
+CLASS_DOUBLES = 352  # include/mvo_hip.h: MVO_HIP_CLASS_DOUBLES
+
+
+def contracted_class_totals(w: "scene.Window", use_loss: bool) -> np.ndarray:
+    """Numpy statement (host logic of the plan, used by the tests) of what the ranks all-reduce per
+    evaluation in the partitioned solve WITH a loss, at the window's starting point: per frame pair the
+    projected moments T = P S P (xx,xy,xz,yy,yz,zz), q = P S u and 1/2 sum rho, with S = sum_i w_i c_i c_i^T,
+    u the pair's unit baseline, P = (I - u u^T) / |baseline|, summed into classes
+    (a, j = min(b, M)); layout cls[5][6][10] then kk[5][10] (the pair (k, k) alone), 352 doubles.  Linear in
+    S, hence additive over any partition of the residual blocks."""
+    M, N = w.M, w.N
+    R = w.frames[:, :9].reshape(N, 3, 3)
+    vec, scale = w.frames[:, 9:12], w.frames[:, 12]
+    out = np.zeros(CLASS_DOUBLES)
+    cls, kk = out[:300].reshape(5, 6, 10), out[300:350].reshape(5, 10)
+    for p, (a, b) in enumerate(scene.pair_list(M, N)):
+        lo, hi = int(w.pair_offsets[p]), int(w.pair_offsets[p + 1])
+        c = np.cross(w.m0[lo:hi] @ R[a].T, w.m1[lo:hi] @ R[b + 1].T)
+        beta = sum(scale[k] * vec[k] for k in range(a, min(b, M - 1) + 1))
+        if b >= M:  # IterativeRefinement.cpp:137-144: only frame b itself
+            beta = beta + scale[b] * vec[b]
+        nb = np.linalg.norm(beta)
+        u = beta / nb
+        r = c @ u
+        if use_loss:  # ceres::CauchyLoss(0.5)
+            wgt, rho = 1.0 / (1.0 + 4.0 * r * r), 0.25 * np.log1p(4.0 * r * r)
+        else:
+            wgt, rho = np.ones_like(r), r * r
+        S = (c * wgt[:, None]).T @ c
+        P = (np.eye(3) - np.outer(u, u)) / nb
+        T, q = P @ S @ P, P @ S @ u
+        o = np.array([T[0, 0], T[0, 1], T[0, 2], T[1, 1], T[1, 2], T[2, 2], q[0], q[1], q[2], 0.5 * rho.sum()])
+        cls[a, min(b, M)] += o
+        if a == b:
+            kk[a] = o
+    return out
+
+
 def shard_landmarks(sc, rank: int, world: int):
     """Bundle-adjustment scene (ba_scene.BaScene) restricted to this rank's contiguous range of
     landmarks, cut so that every rank gets about the same number of observations; all poses stay.

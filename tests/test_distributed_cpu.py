@@ -42,6 +42,14 @@ def _worker(rank, world, port, q):
         full = orc.pair_moments(w)
         ok_moments = bool(np.abs(local.numpy() - full).max() <= 1e-12 * np.abs(full).max())
         ok_count = int(n_local.item()) == w.n_residual_blocks
+        # (1b) the same window under the Cauchy loss: the ranks exchange the CONTRACTED sums (class totals of
+        # the pairs' projected moments, 352 doubles) -- additive because the projection is linear in S
+        wl = scene.make_window(12, 4, 300, seed=78, span=("anchored", 2, 12), outlier_fraction=0.2)
+        mine_cls = torch.from_numpy(sharding.contracted_class_totals(sharding.shard_observations(wl, rank, world), True))
+        dist.all_reduce(mine_cls)
+        full_cls = sharding.contracted_class_totals(wl, True)
+        ok_moments = ok_moments and mine_cls.numel() == sharding.CLASS_DOUBLES and bool(
+            np.abs(mine_cls.numpy() - full_cls).max() <= 1e-12 * np.abs(full_cls).max())
         # (2) independent windows: block partition, results gathered
         ids = list(sharding.shard_windows(7, rank, world))
         opt = orc.make_options(max_num_iterations=5, function_tolerance=0.0, gradient_tolerance=0.0,

@@ -272,9 +272,17 @@ def test_download_before_upload_is_an_error():
         n = C.c_int32(0)
         assert capi.load().mvo_hip_get_trace(s2._h, None, 0, C.byref(n)) == capi.ERR_STATE
         lib = capi.load()
-        assert lib.mvo_hip_partial_begin(s2._h) == capi.OK and lib.mvo_hip_partial_pass(s2._h) == capi.OK
+        assert lib.mvo_hip_partial_begin(s2._h) == capi.OK
+        assert lib.mvo_hip_partial_pass(s2._h) == capi.ERR_STATE   # a pass needs the point a first advance publishes
         done = C.c_int32(0)
+        n_x = int(lib.mvo_hip_partial_sums_count(s2._h))
+        assert n_x == capi.CLASS_DOUBLES
+        import torch
+        buf = torch.zeros(n_x, dtype=torch.float64, device="cuda")
+        assert lib.mvo_hip_partial_sums(s2._h, buf.data_ptr(), n_x, 0) == capi.OK      # a world of one: what went out
+        assert lib.mvo_hip_partial_sums(s2._h, buf.data_ptr(), n_x, 1) == capi.OK      # comes back as the total
         assert lib.mvo_hip_partial_advance(s2._h, C.byref(done)) == capi.OK and done.value == 0
+        assert lib.mvo_hip_partial_pass(s2._h) == capi.OK
         with pytest.raises(capi.MvoHipError):
             s2.download()
         s2.solve()                                   # the abandoned run's done counter is not trusted
@@ -321,7 +329,7 @@ def test_handle_reuse_across_shapes_and_modes(oracle):
             opt = capi.make_options(**kw)
             if k == 3:  # a partitioned solve on the same handle in between
                 shared.upload(ws, opt)
-                sums = torch.zeros(8 * ws[0].n_pairs, dtype=torch.float64, device="cuda")
+                sums = torch.zeros(shared.partial_sums_count(), dtype=torch.float64, device="cuda")
                 shared.solve_partitioned(lambda t: torch.cuda.synchronize(), sums)
                 part_frames, part_summ = shared.download()
             shared.upload(ws, opt)

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 def _two_rank_solve(w, opt):
     world = 2
     solvers = [capi.Solver(0) for _ in range(world)]
-    sums = [torch.zeros(8 * w.n_pairs, dtype=torch.float64, device="cuda") for _ in range(world)]
+    sums = [None] * world  # what the ranks exchange: 8 doubles per pair, or the contracted class totals with a loss
     barrier = threading.Barrier(world)
     errors = []
 
@@ -35,6 +35,9 @@ def _two_rank_solve(w, opt):
     def run(rank):
         try:
             solvers[rank].upload([sharding.shard_observations(w, rank, world)], opt)
+            n = solvers[rank].partial_sums_count()
+            assert n == (capi.CLASS_DOUBLES if opt.use_loss_function else 8 * w.n_pairs)
+            sums[rank] = torch.zeros(n, dtype=torch.float64, device="cuda")
             solvers[rank].solve_partitioned(allreduce_for(rank), sums[rank])
         except Exception as e:  # pragma: no cover
             errors.append(e)
@@ -71,6 +74,26 @@ def test_two_shards_equal_single_solve(solver, oracle, use_loss):
         assert abs(s0[0].final_cost - so.final_cost) <= 1e-12 * so.final_cost
 
 
+@pytest.mark.parametrize("use_loss", [True, False])
+def test_contracted_class_totals_match_numpy(solver, use_loss):
+    """What a rank hands to the all-reduce in pass mode (k_fold tail -> project_pair8 -> k_class_sums) against
+    the numpy statement of the same sums at the starting point, for a window whose long classes span more
+    than one lane round (N - 1 - M > 64) and for a batch of short ones."""
+    mode = 0 if use_loss else capi.ASSEMBLY_PASSES
+    for ws in ([scene.make_window(80, 4, 300, seed=45, span=("anchored", 2, 80), outlier_fraction=0.1)],
+               [scene.config3_window(i) for i in range(5)]):
+        solver.upload(ws, capi.make_options(use_loss_function=use_loss, assembly_mode=mode, **FIXED10))
+        n = solver.partial_sums_count()
+        assert n == capi.CLASS_DOUBLES * len(ws)
+        buf = torch.zeros(n, dtype=torch.float64, device="cuda")
+        assert solver._lib.mvo_hip_partial_begin(solver._h) == capi.OK
+        assert solver._lib.mvo_hip_partial_sums(solver._h, buf.data_ptr(), n, 0) == capi.OK
+        got = buf.cpu().numpy().reshape(len(ws), capi.CLASS_DOUBLES)
+        for i, w in enumerate(ws):
+            ref = sharding.contracted_class_totals(w, use_loss)
+            assert np.abs(got[i] - ref).max() <= 1e-11 * np.abs(ref).max()
+
+
 def test_default_tolerances_terminate_on_all_ranks(oracle):
     w = scene.make_window(9, 3, 300, seed=42)
     out = _two_rank_solve(w, capi.make_options(use_loss_function=True))
@@ -96,13 +119,12 @@ def test_rccl_world1_call_path(solver):
         w = scene.config1()
         for use_loss in (False, True):
             opt = capi.make_options(use_loss_function=use_loss, **FIXED10)
-            sums = torch.zeros(8 * w.n_pairs, dtype=torch.float64, device="cuda")
-
             def allreduce(t):
                 dist.all_reduce(t)
                 torch.cuda.synchronize()
 
             solver.upload([w], opt)
+            sums = torch.zeros(solver.partial_sums_count(), dtype=torch.float64, device="cuda")
             solver.solve_partitioned(allreduce, sums)
             fp, sp = solver.download()
             fs, ss = solver.refine(w, opt)
