@@ -786,15 +786,25 @@ def main():
     }
 
     if rank == 0 and not partitioned and len(ws) == 1:
-        # the call the reference would actually make: mvo_hip_refine with HOST buffers in and out
-        # (upload over PCIe + solve + download) -- never part of `value`
+        # the call the reference would actually make: HOST buffers in and out (upload over PCIe + solve +
+        # download) -- never part of `value`.  Two forms: the gather loop wrote the rays into the handle's
+        # pinned staging block (mvo_hip_staging + mvo_hip_refine_staged: what the shipped adapter does), or
+        # into ordinary (pageable) memory handed to mvo_hip_refine.  The staging block is filled once,
+        # outside the timed calls, as the arrays of the pageable form are.
         k = 3 if blocks > 2_000_000 else 20
+        solver.stage(ws[0])
+        for _ in range(2):
+            solver.refine_staged(ws[0], opt)
+        t1 = time.perf_counter()
+        for _ in range(k):
+            solver.refine_staged(ws[0], opt)
+        out["refine_ms_pcie_inclusive"] = round((time.perf_counter() - t1) / k * 1e3, 5)
         for _ in range(2):
             solver.refine(ws[0], opt)
         t1 = time.perf_counter()
         for _ in range(k):
             solver.refine(ws[0], opt)
-        out["refine_ms_pcie_inclusive"] = round((time.perf_counter() - t1) / k * 1e3, 5)
+        out["refine_ms_pcie_inclusive_pageable"] = round((time.perf_counter() - t1) / k * 1e3, 5)
     if strong and world > 1:
         # the efficiency baseline in the same line: the WHOLE job on rank 0's GPU alone (the other ranks
         # wait) -- all windows of config 3, or the unsplit config-4 window through the plain mvo_hip_solve

@@ -173,6 +173,21 @@ int mvo_hip_refine(mvo_hip_handle h, mvo_hip_frame *frames, uint32_t M, uint32_t
                    const mvo_hip_options *options, const mvo_hip_observations *observations,
                    mvo_hip_summary *summary);
 
+/* The same call with the gathering loop (IterativeRefinement.cpp:116-165) writing straight into PINNED
+ * staging memory of the handle instead of into the reference's std::list<std::vector<Vector3d>> "features"
+ * (IterativeRefinement.cpp:111,147-165): the rays then cross PCIe from where the gather put them -- no
+ * pageable copy by the HIP runtime (0.195 of 0.29 ms at BASELINE configs[1]), no second copy by the library.
+ * mvo_hip_staging returns room for n_pairs + 1 offsets and capacity_blocks unit rays per side (3 doubles per
+ * block); the block only grows and keeps what it held when it does, so a gather loop that does not know its
+ * block count up front may ask again mid-way with a larger capacity (*capacity_out: blocks that fit now).
+ * The pointers stay valid until the next mvo_hip_staging call that grows the block, or mvo_hip_destroy.
+ * mvo_hip_refine_staged is mvo_hip_refine on what the staging block holds: pair_offsets[0 .. P] as written
+ * by the caller (P = M(N-1) - M(M-1)/2), rays for blocks [0, pair_offsets[P]).  Not re-entrant per handle. */
+int mvo_hip_staging(mvo_hip_handle h, uint32_t n_pairs, uint64_t capacity_blocks, uint64_t **pair_offsets,
+                    double **m0, double **m1, uint64_t *capacity_out);
+int mvo_hip_refine_staged(mvo_hip_handle h, mvo_hip_frame *frames, uint32_t M, uint32_t N,
+                          const mvo_hip_options *options, mvo_hip_summary *summary);
+
 /* n_windows independent refine() calls of identical (M, N) in one launch sequence
  * (multi-sequence replay; no reference counterpart beyond calling refine() in a loop).
  * frames: n_windows * N records, window-major.  observations / summaries: one per window. */

@@ -175,6 +175,12 @@ struct mvo_hip_context {
   } t;
   char* h_arena = nullptr;
   size_t h_arena_cap = 0;
+  // mvo_hip_staging: pinned buffers the caller's gather loop writes into (offsets, m0, m1)
+  uint64_t* h_st_offs = nullptr;
+  double* h_st_m0 = nullptr;
+  double* h_st_m1 = nullptr;
+  uint32_t st_pairs = 0;      // capacity in pairs (+1 offsets)
+  uint64_t st_blocks = 0;     // capacity in residual blocks
   bool copy_pending = false;  // an async copy out of h_arena may still be in flight
   // experiment switches, read from the environment ONCE, at mvo_hip_create (a getenv is a walk through
   // the whole environment: four of them were ~1 us of a 33-us default-size refine)
@@ -382,7 +388,7 @@ void host_pair_u0(const mvo_hip_context* h, uint32_t w, double* out) {
 // on h->stream after this call (the device-side gather of mvo_tracks.hip); pair_offsets are host memory.
 int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint32_t M, uint32_t N,
               const mvo_hip_options* opt, const mvo_hip_observations* obs, bool rays_on_device = false,
-              bool no_rays = false) {
+              bool no_rays = false, bool rays_pinned = false) {
   const auto t_begin = std::chrono::steady_clock::now();
   int rc = validate(W, frames, M, N, opt, obs);
   if (rc != MVO_HIP_OK) return rc;
@@ -579,7 +585,7 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
     h->h_arena_cap = want;
   }
   HIP_TRY(h->d_arena.reserve(arena_bytes));
-  if (!rays_in_arena && !no_rays) {
+  if (!rays_in_arena && !no_rays && !(rays_pinned && W == 1 && !std::getenv("MVO_HIP_STAGED_COPY"))) {
     HIP_TRY(h->d_m0.reserve(sizeof(double) * 3 * (n_obs + 1)));
     HIP_TRY(h->d_m1.reserve(sizeof(double) * 3 * (n_obs + 1)));
   }
@@ -647,10 +653,19 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
   h->t.wave_tiles = reinterpret_cast<uint32_t*>(da + o_wave);
   h->t.m0 = rays_in_arena ? reinterpret_cast<double*>(da + o_m0) : h->d_m0.as<double>();
   h->t.m1 = rays_in_arena ? reinterpret_cast<double*>(da + o_m1) : h->d_m1.as<double>();
+  // Rays in the handle's pinned staging block, too many for the arena: the fold reads them exactly once, so
+  // it reads them where they are, over PCIe (pinned host memory is mapped into the device's address
+  // space) -- no copy command at all; measured against hipMemcpyAsync from the same block in
+  // profiles/r3/NOTES.md.  (MVO_HIP_STAGED_COPY keeps the copy, for that comparison.)
+  const bool zero_copy = rays_pinned && !rays_in_arena && W == 1 && !std::getenv("MVO_HIP_STAGED_COPY");
+  if (zero_copy) {
+    h->t.m0 = const_cast<double*>(obs[0].m0);
+    h->t.m1 = const_cast<double*>(obs[0].m1);
+  }
   uint64_t pos = 0;
   for (uint32_t w = 0; w < W; ++w) {
     const uint64_t cnt = obs[w].pair_offsets[P];
-    if (cnt && !rays_on_device) {
+    if (cnt && !rays_on_device && !zero_copy) {
       if (rays_in_arena) {
         std::memcpy(ha + o_m0 + sizeof(double) * 3 * pos, obs[w].m0, sizeof(double) * 3 * cnt);
         std::memcpy(ha + o_m1 + sizeof(double) * 3 * pos, obs[w].m1, sizeof(double) * 3 * cnt);
@@ -662,7 +677,7 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
     pos += cnt;
   }
   HIP_TRY(hipMemcpyAsync(da, ha, rays_on_device && rays_in_arena ? o_m0 : arena_bytes, hipMemcpyHostToDevice, s));
-  if (rays_in_arena || rays_on_device) {
+  if (rays_in_arena || rays_on_device || rays_pinned) {
     h->copy_pending = true;  // pinned source: the copy is asynchronous and the solve is queued behind it
   } else {
     HIP_TRY(hipStreamSynchronize(s));  // the caller's ray arrays may change once this call returns
@@ -1335,6 +1350,9 @@ void mvo_hip_destroy(mvo_hip_handle h) {
   for (DevBuf* b : bufs) b->release();
   if (h->h_arena) (void)hipHostFree(h->h_arena);
   if (h->h_ctl) (void)hipHostFree(h->h_ctl);
+  if (h->h_st_offs) (void)hipHostFree(h->h_st_offs);
+  if (h->h_st_m0) (void)hipHostFree(h->h_st_m0);
+  if (h->h_st_m1) (void)hipHostFree(h->h_st_m1);
   if (h->events_ready)
     for (auto& e : h->ev) (void)hipEventDestroy(e);
   if (h->overlap_ready) {
@@ -1406,6 +1424,71 @@ int mvo_hip_refine(mvo_hip_handle h, mvo_hip_frame* frames, uint32_t M, uint32_t
                    const mvo_hip_options* options, const mvo_hip_observations* observations,
                    mvo_hip_summary* summary) {
   return mvo_hip_refine_batch(h, 1, frames, M, N, options, observations, summary);
+}
+
+// ---- pinned staging for the caller's gather loop (IR.cpp:116-165 writes here instead of into a
+// std::list of std::vectors): the rays cross PCIe straight from where the gather put them -- no pageable
+// copy by the runtime (0.195 of 0.29 ms at config 2), no second copy by the library.
+int mvo_hip_staging(mvo_hip_handle h, uint32_t n_pairs, uint64_t capacity_blocks, uint64_t** pair_offsets, double** m0,
+                    double** m1, uint64_t* capacity_out) {
+  if (!h || !pair_offsets || !m0 || !m1) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(h->device));
+  if (h->copy_pending) {  // an upload may still be reading the block
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->copy_pending = false;
+  }
+  auto grow = [&](void** p, size_t old_bytes, size_t new_bytes) -> hipError_t {
+    void* q = nullptr;
+    hipError_t e = hipHostMalloc(&q, new_bytes, hipHostMallocDefault);
+    if (e != hipSuccess) return e;
+    if (*p) {
+      std::memcpy(q, *p, old_bytes);  // what the gather loop wrote so far is kept: it may ask again mid-way
+      (void)hipHostFree(*p);
+    }
+    *p = q;
+    return hipSuccess;
+  };
+  if (n_pairs > h->st_pairs || !h->h_st_offs) {
+    const uint32_t want = n_pairs + n_pairs / 4 + 16;
+    HIP_TRY(grow(reinterpret_cast<void**>(&h->h_st_offs), sizeof(uint64_t) * (h->h_st_offs ? h->st_pairs + 1 : 0),
+                 sizeof(uint64_t) * ((size_t)want + 1)));
+    h->st_pairs = want;
+  }
+  if (capacity_blocks > h->st_blocks || !h->h_st_m0) {
+    const uint64_t want = capacity_blocks + capacity_blocks / 4 + 1024;
+    const size_t old_bytes = sizeof(double) * 3 * (h->h_st_m0 ? h->st_blocks : 0);
+    HIP_TRY(grow(reinterpret_cast<void**>(&h->h_st_m0), old_bytes, sizeof(double) * 3 * want));
+    HIP_TRY(grow(reinterpret_cast<void**>(&h->h_st_m1), old_bytes, sizeof(double) * 3 * want));
+    h->st_blocks = want;
+  }
+  *pair_offsets = h->h_st_offs;
+  *m0 = h->h_st_m0;
+  *m1 = h->h_st_m1;
+  if (capacity_out) *capacity_out = h->st_blocks;
+  return MVO_HIP_OK;
+}
+
+int mvo_hip_refine_staged(mvo_hip_handle h, mvo_hip_frame* frames, uint32_t M, uint32_t N, const mvo_hip_options* options,
+                          mvo_hip_summary* summary) {
+  if (!h) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  if (!h->h_st_offs || !h->h_st_m0) return MVO_HIP_ERR_STATE;  // mvo_hip_staging first
+  if (M == 0 || N <= M) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  const uint32_t P = num_pairs(M, N);
+  if (P > h->st_pairs || h->h_st_offs[P] > h->st_blocks) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  mvo_hip_observations obs;
+  obs.n_pairs = P;
+  obs.reserved = 0;
+  obs.pair_offsets = h->h_st_offs;
+  obs.m0 = h->h_st_m0;
+  obs.m1 = h->h_st_m1;
+  int rc = do_upload(h, 1, frames, M, N, options, &obs, false, false, true);
+  if (rc != MVO_HIP_OK) return rc;
+  rc = do_solve(h);
+  if (rc != MVO_HIP_OK) return rc;
+  rc = do_download(h, frames, summary);
+  // the upload may point into the staging block, which the caller's next gather overwrites: it is spent
+  h->uploaded = false;
+  return rc;
 }
 
 int mvo_hip_eval(mvo_hip_handle h, const mvo_hip_frame* frames, uint32_t M, uint32_t N,

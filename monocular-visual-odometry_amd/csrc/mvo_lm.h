@@ -1426,24 +1426,44 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
   }
 
   if (need_pass) {
-    // publish the unit baselines of the point to evaluate; k_pass runs next on the stream.  (a, b) by
-    // arithmetic, the point and the fixed-frame offsets from LDS: no global load stands between a thread and
-    // its (up to five) pairs.  One reciprocal instead of three divisions: u differs from beta / |beta| by
+    // Publish the unit baselines of the point to evaluate; k_pass runs next on the stream.  No global load
+    // stands between a thread and its pairs: point and fixed-frame offsets come from LDS, (a, b) from the
+    // loop counter.  A long pair (a, b >= M) has the baseline B_a + n_b v_b with B_a = s_a v_a + ... +
+    // s_{M-1} v_{M-1} (left to right, IR.cpp:466-577) -- five vectors per point, formed once.  One reciprocal instead of three divisions: u differs from beta / |beta| by
     // <= 1 ulp, and pass and projection both read THIS u.
-    for (int p = tid; p < P; p += NT) {
-      int a, b;
-      pair_ab(N, M, p, a, b);
+    __shared__ double sB[MVO_MAXM][3];
+    if (tid < M) {
       double beta[3];
-      free_baseline(sh, a, b < M - 1 ? b : M - 1, beta);
-      if (b >= M) {  // IR.cpp:137-144: only frame b itself
-        const int bb = b < FOFF_FRAMES ? b : 0;
-        beta[0] += sfoff[3 * bb];
-        beta[1] += sfoff[3 * bb + 1];
-        beta[2] += sfoff[3 * bb + 2];
-      }
+      free_baseline(sh, tid, M - 1, beta);
+      sB[tid][0] = beta[0];
+      sB[tid][1] = beta[1];
+      sB[tid][2] = beta[2];
+    }
+    __syncthreads();
+    double* __restrict__ pu = pair_u + 4 * (size_t)win.pair_off;
+    const int n_long = N - 1 > M ? N - 1 - M : 0;
+    for (int q = tid; q < n_long * M; q += NT) {  // long pairs, frame-major: q = a * n_long + (b - M)
+      const int a = q / n_long, b = M + (q - a * n_long);
+      const int bb = b < FOFF_FRAMES ? b : 0;
+      const double bx = sB[a][0] + sfoff[3 * bb], by = sB[a][1] + sfoff[3 * bb + 1], bz = sB[a][2] + sfoff[3 * bb + 2];
+      const double nb = sqrt(bx * bx + by * by + bz * bz);
+      const double inb = fast_rcp(nb);
+      double* __restrict__ o = pu + 4 * (size_t)pair_index(N, a, b);
+      o[0] = bx * inb;
+      o[1] = by * inb;
+      o[2] = bz * inb;
+      o[3] = nb;
+    }
+    // the pairs (a, b < M): their own partial sums of the refined frames, no fixed frame; the last lanes take them
+    const int ts = NT - 1 - tid, nshort = (M * (M + 1)) / 2;
+    if (ts < nshort) {
+      int a, b;
+      upper_block(M, ts, a, b);
+      double beta[3];
+      free_baseline(sh, a, b, beta);
       const double nb = sqrt(beta[0] * beta[0] + beta[1] * beta[1] + beta[2] * beta[2]);
       const double inb = fast_rcp(nb);
-      double* __restrict__ o = pair_u + 4 * (size_t)(win.pair_off + p);
+      double* __restrict__ o = pu + 4 * (size_t)pair_index(N, a, b);
       o[0] = beta[0] * inb;
       o[1] = beta[1] * inb;
       o[2] = beta[2] * inb;

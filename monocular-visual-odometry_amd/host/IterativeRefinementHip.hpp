@@ -69,15 +69,58 @@ inline void gather(const FrameT &nowFrame, unsigned int numberToRefine, unsigned
   }
 }
 
+// The same loops writing straight into the handle's PINNED staging block (mvo_hip_staging): the rays cross
+// PCIe from where this loop put them -- no pageable copy by the HIP runtime, no second copy by the library.
+// The block count is not known up front: room is asked for again (the block keeps what it holds) whenever
+// a pair would not fit.
+template <class RayT, class FrameT>
+inline int gatherStaged(mvo_hip_handle handle, const FrameT &nowFrame, unsigned int numberToRefine,
+                        unsigned int numberToNote) {
+  const uint32_t nPairs = mvo_hip_num_pairs(numberToRefine, numberToNote);
+  uint64_t *offsets = 0, capacity = 0, n = 0;
+  double *m0 = 0, *m1 = 0;
+  int rc = mvo_hip_staging(handle, nPairs, 0, &offsets, &m0, &m1, &capacity);
+  if (rc != MVO_HIP_OK) return rc;
+  uint32_t p = 0;
+  offsets[0] = 0;
+  for (unsigned int frame0 = 0; frame0 < numberToRefine; frame0++) {
+    for (unsigned int frame1 = frame0; frame1 < (numberToNote - 1); frame1++) {
+      std::vector<RayT> feature1, feature0;
+      nowFrame.getPreviousFrame(frame0).getCorrespondingFeatures((frame1 - frame0) + 1, feature1, feature0);
+      assert(feature0.size() == feature1.size());  // IterativeRefinement.cpp:379
+      if (n + feature0.size() > capacity) {
+        rc = mvo_hip_staging(handle, nPairs, 2 * (n + feature0.size()), &offsets, &m0, &m1, &capacity);
+        if (rc != MVO_HIP_OK) return rc;
+      }
+      for (std::size_t i = 0; i < feature0.size(); i++, n++) {  // FeatureOperations::normFeatures, both sides
+        const double x0 = feature0[i][0], y0 = feature0[i][1], z0 = feature0[i][2];
+        const double s0 = 1.0 / std::sqrt(x0 * x0 + y0 * y0 + z0 * z0);
+        m0[3 * n] = x0 * s0;
+        m0[3 * n + 1] = y0 * s0;
+        m0[3 * n + 2] = z0 * s0;
+        const double x1 = feature1[i][0], y1 = feature1[i][1], z1 = feature1[i][2];
+        const double s1 = 1.0 / std::sqrt(x1 * x1 + y1 * y1 + z1 * z1);
+        m1[3 * n] = x1 * s1;
+        m1[3 * n + 1] = y1 * s1;
+        m1[3 * n + 2] = z1 * s1;
+      }
+      offsets[++p] = n;
+    }
+  }
+  return MVO_HIP_OK;
+}
+
 // Drop-in body of IterativeRefinement::refine.  Returns the library status (the reference
 // returns void and only logs on Ceres FAILURE; results are written back regardless,
-// IterativeRefinement.cpp:235-246).
+// IterativeRefinement.cpp:235-246).  staged = true (default): the gather loop writes into the handle's
+// pinned staging block and mvo_hip_refine_staged uploads from there; false: std::vectors + mvo_hip_refine
+// (pageable memory: the HIP runtime copies the rays once more before they cross PCIe).
 template <class RayT, class RefinementFrameT, class FrameT>
 inline int refine(mvo_hip_handle handle, std::vector<RefinementFrameT> &refinementData,
                   unsigned int numberToRefine, unsigned int numberToNote, int maxNumthreads,
                   int maxNumIterations, double functionTolerance, double gradientTolerance,
                   double parameterTolerance, bool useLossFunction, double lowestLength, double highestLength,
-                  const FrameT &nowFrame, mvo_hip_summary *summary = 0) {
+                  const FrameT &nowFrame, mvo_hip_summary *summary = 0, bool staged = true) {
   assert(refinementData.size() == numberToNote);  // IterativeRefinement.cpp:28-30
   assert(numberToNote > numberToRefine);
   assert(numberToRefine > 0);
@@ -89,9 +132,6 @@ inline int refine(mvo_hip_handle handle, std::vector<RefinementFrameT> &refineme
     for (int c = 0; c < 3; c++) frames[i].vec[c] = refinementData[i].vec[c];
     frames[i].scale = refinementData[i].scale;
   }
-
-  GatheredObservations g;
-  gather<RayT>(nowFrame, numberToRefine, numberToNote, g);
 
   mvo_hip_options opt;
   opt.max_num_iterations = maxNumIterations;
@@ -106,15 +146,22 @@ inline int refine(mvo_hip_handle handle, std::vector<RefinementFrameT> &refineme
   opt.assembly_mode = MVO_HIP_ASSEMBLY_AUTO;
   opt.reserved = 0;
 
-  mvo_hip_observations obs;
-  obs.n_pairs = static_cast<uint32_t>(g.pair_offsets.size() - 1);
-  obs.reserved = 0;
-  obs.pair_offsets = g.pair_offsets.data();
-  obs.m0 = g.m0.data();
-  obs.m1 = g.m1.data();
-
-  const int status =
-      mvo_hip_refine(handle, frames.data(), numberToRefine, numberToNote, &opt, &obs, summary);
+  int status;
+  if (staged) {
+    status = gatherStaged<RayT>(handle, nowFrame, numberToRefine, numberToNote);
+    if (status == MVO_HIP_OK)
+      status = mvo_hip_refine_staged(handle, frames.data(), numberToRefine, numberToNote, &opt, summary);
+  } else {
+    GatheredObservations g;
+    gather<RayT>(nowFrame, numberToRefine, numberToNote, g);
+    mvo_hip_observations obs;
+    obs.n_pairs = static_cast<uint32_t>(g.pair_offsets.size() - 1);
+    obs.reserved = 0;
+    obs.pair_offsets = g.pair_offsets.data();
+    obs.m0 = g.m0.data();
+    obs.m1 = g.m1.data();
+    status = mvo_hip_refine(handle, frames.data(), numberToRefine, numberToNote, &opt, &obs, summary);
+  }
   if (status != MVO_HIP_OK) return status;
 
   for (unsigned int i = 0; i < numberToRefine; i++) {  // IterativeRefinement.cpp:240-246

@@ -3,7 +3,9 @@
 // gathering order can be tested without OpenCV/ROS.
 //
 //   adapter_check gather <tracks.bin> <csr.bin>     CPU only: dumps the CSR buffers the adapter builds
-//   adapter_check refine <tracks.bin> <out.bin>     GPU: runs refine() through libmvo_hip
+//   adapter_check refine <tracks.bin> <out.bin>     GPU: runs refine() through libmvo_hip (gather into the handle's
+//                                                   pinned staging block + mvo_hip_refine_staged)
+//   adapter_check refine_pageable <..> <out.bin>    GPU: the same through std::vectors + mvo_hip_refine
 //   adapter_check tracks <tracks.bin> <out.bin>     GPU: keyframes mirrored into the device-resident
 //                                                   track table (TrackMirror), refine from there; the
 //                                                   device-gathered CSR buffers follow the results
@@ -92,7 +94,7 @@ bool rd(FILE *f, void *p, std::size_t n) { return std::fread(p, 1, n, f) == n; }
 
 int main(int argc, char **argv) {
   if (argc != 4) {
-    std::fprintf(stderr, "usage: adapter_check gather|refine|tracks|latency <tracks.bin> <out.bin>\n");
+    std::fprintf(stderr, "usage: adapter_check gather|refine|refine_pageable|tracks|latency <tracks.bin> <out.bin>\n");
     return 2;
   }
   const std::string mode = argv[1];
@@ -140,15 +142,16 @@ int main(int argc, char **argv) {
     if (rc != MVO_HIP_OK) return 10 + rc;
     const std::vector<RefinementFrame> data0 = data;
     mvo_hip_summary s;
-    std::vector<double> t_all, t_call;
-    for (int it = 0; it < 320 && rc == MVO_HIP_OK; it++) {
-      data = data0;
-      const std::chrono::steady_clock::time_point a = std::chrono::steady_clock::now();
-      rc = mvo_hip_adapter::refine<Vec3>(h, data, M, N, 4, hdr[2], tol[0], tol[1], tol[2], hdr[3] != 0, tol[3], tol[4],
-                                         frames[0], &s);
-      const std::chrono::steady_clock::time_point b = std::chrono::steady_clock::now();
-      if (it >= 20) t_all.push_back(std::chrono::duration<double, std::micro>(b - a).count());
-    }
+    std::vector<double> t_all, t_call, t_pageable;
+    for (int staged = 1; staged >= 0; staged--)
+      for (int it = 0; it < 320 && rc == MVO_HIP_OK; it++) {
+        data = data0;
+        const std::chrono::steady_clock::time_point a = std::chrono::steady_clock::now();
+        rc = mvo_hip_adapter::refine<Vec3>(h, data, M, N, 4, hdr[2], tol[0], tol[1], tol[2], hdr[3] != 0, tol[3], tol[4],
+                                           frames[0], &s, staged != 0);
+        const std::chrono::steady_clock::time_point b = std::chrono::steady_clock::now();
+        if (it >= 20) (staged ? t_all : t_pageable).push_back(std::chrono::duration<double, std::micro>(b - a).count());
+      }
     mvo_hip_adapter::GatheredObservations g;
     mvo_hip_adapter::gather<Vec3>(frames[0], M, N, g);
     mvo_hip_observations obs;
@@ -207,8 +210,9 @@ int main(int argc, char **argv) {
     std::sort(t_all.begin(), t_all.end());
     std::sort(t_call.begin(), t_call.end());
     std::sort(t_mirror.begin(), t_mirror.end());
-    std::fprintf(o, "adapter refine (gather + mvo_hip_refine): median %.1f us, p90 %.1f us; mvo_hip_refine alone: median %.1f us, p90 %.1f us; TrackMirror::refine (device-resident tracks): median %.1f us, p90 %.1f us; %d iterations, %u residual blocks\n",
-                 t_all[t_all.size() / 2], t_all[t_all.size() * 9 / 10], t_call[t_call.size() / 2],
+    std::sort(t_pageable.begin(), t_pageable.end());
+    std::fprintf(o, "adapter refine (gather into pinned staging + mvo_hip_refine_staged): median %.1f us, p90 %.1f us; the same through std::vectors + mvo_hip_refine: median %.1f us; mvo_hip_refine alone (blocks already gathered, pageable): median %.1f us, p90 %.1f us; TrackMirror::refine (device-resident tracks): median %.1f us, p90 %.1f us; %d iterations, %u residual blocks\n",
+                 t_all[t_all.size() / 2], t_all[t_all.size() * 9 / 10], t_pageable[t_pageable.size() / 2], t_call[t_call.size() / 2],
                  t_call[t_call.size() * 9 / 10], t_mirror[t_mirror.size() / 2], t_mirror[t_mirror.size() * 9 / 10],
                  s.iterations, static_cast<unsigned int>(g.m0.size() / 3));
   } else if (mode == "tracks") {
@@ -267,7 +271,7 @@ int main(int argc, char **argv) {
     mvo_hip_summary s;
     std::memset(&s, 0, sizeof s);
     rc = mvo_hip_adapter::refine<Vec3>(h, data, M, N, 4, hdr[2], tol[0], tol[1], tol[2], hdr[3] != 0, tol[3],
-                                       tol[4], frames[0], &s);
+                                       tol[4], frames[0], &s, mode != "refine_pageable");
     mvo_hip_destroy(h);
     if (rc != MVO_HIP_OK) {
       std::fprintf(stderr, "refine: %s\n", mvo_hip_status_string(rc));

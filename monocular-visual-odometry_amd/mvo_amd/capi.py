@@ -37,7 +37,7 @@ EXPORTED_SYMBOLS = [
     "mvo_hip_num_pairs", "mvo_hip_status_string", "mvo_hip_version", "mvo_hip_partial_begin",
     "mvo_hip_partial_pass", "mvo_hip_partial_advance", "mvo_hip_partial_sums", "mvo_hip_partial_sums_count", "mvo_hip_debug_poison_lds",
     "mvo_hip_debug_check_guards", "mvo_hip_refine_noalloc", "mvo_hip_eval_at", "mvo_hip_debug_set_point",
-    "mvo_hip_debug_pair_sums", "mvo_hip_comm_unique_id", "mvo_hip_comm_init", "mvo_hip_comm_destroy", "mvo_hip_solve_partitioned",
+    "mvo_hip_debug_pair_sums", "mvo_hip_staging", "mvo_hip_refine_staged", "mvo_hip_comm_unique_id", "mvo_hip_comm_init", "mvo_hip_comm_destroy", "mvo_hip_solve_partitioned",
 ]
 
 
@@ -132,6 +132,11 @@ def load():
                                      C.POINTER(Observations), C.POINTER(Summary)]
         L.mvo_hip_refine_batch.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32,
                                            C.POINTER(Options), C.POINTER(Observations), C.POINTER(Summary)]
+        L.mvo_hip_staging.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.POINTER(C.POINTER(C.c_uint64)),
+                                      C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.POINTER(C.c_double)),
+                                      C.POINTER(C.c_uint64)]
+        L.mvo_hip_refine_staged.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(Options),
+                                            C.POINTER(Summary)]
         L.mvo_hip_upload.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32,
                                      C.POINTER(Options), C.POINTER(Observations)]
         L.mvo_hip_solve.argtypes = [C.c_void_p]
@@ -250,6 +255,34 @@ class Solver:
                                       C.byref(summ))
         if rc != OK:
             raise MvoHipError(rc, "mvo_hip_refine")
+        return frames, summ
+
+    # -- the same through the handle's pinned staging block (mvo_hip_staging / mvo_hip_refine_staged) --
+    def stage(self, window):
+        """What the adapter's gather loop does: write pair offsets and unit rays into the handle's pinned
+        staging memory (asked for in two steps here, to exercise the grow-and-keep path)."""
+        n, P = int(window.pair_offsets[-1]), len(window.pair_offsets) - 1
+        po, p0, p1 = C.POINTER(C.c_uint64)(), C.POINTER(C.c_double)(), C.POINTER(C.c_double)()
+        cap = C.c_uint64(0)
+        half = n // 2
+        for want, lo, hi in ((half, 0, half), (n, half, n)):
+            rc = self._lib.mvo_hip_staging(self._h, P, want, C.byref(po), C.byref(p0), C.byref(p1), C.byref(cap))
+            if rc != OK:
+                raise MvoHipError(rc, "mvo_hip_staging")
+            assert cap.value >= want
+            if hi > lo:
+                np.ctypeslib.as_array(p0, shape=(3 * cap.value,))[3 * lo:3 * hi] = window.m0[lo:hi].reshape(-1)
+                np.ctypeslib.as_array(p1, shape=(3 * cap.value,))[3 * lo:3 * hi] = window.m1[lo:hi].reshape(-1)
+        np.ctypeslib.as_array(po, shape=(P + 1,))[:] = window.pair_offsets
+
+    def refine_staged(self, window, options=None):
+        """-> (frames_out[N,13], Summary) from what stage() put into the staging block."""
+        opt = options or make_options()
+        frames = np.ascontiguousarray(window.frames, dtype=np.float64).copy()
+        summ = Summary()
+        rc = self._lib.mvo_hip_refine_staged(self._h, frames.ctypes.data, window.M, window.N, C.byref(opt), C.byref(summ))
+        if rc != OK:
+            raise MvoHipError(rc, "mvo_hip_refine_staged")
         return frames, summ
 
     def refine_batch(self, windows, options=None):

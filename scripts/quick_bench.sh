@@ -8,7 +8,7 @@ for WL in config2 config5 config3 config4 config4r; do
   python - <<PY
 import json
 b=json.loads(open("gpurun_out/qb_$WL.json").read().strip().splitlines()[-1])
-print("$WL", "ms/step", b["ms_per_step"], "value", b["value"], "device_ms", b["device_ms_per_step"], "pcie_refine_ms", b.get("refine_ms_pcie_inclusive"))
+print("$WL", "ms/step", b["ms_per_step"], "value", b["value"], "device_ms", b["device_ms_per_step"], "pcie_refine_ms", b.get("refine_ms_pcie_inclusive"), "pageable", b.get("refine_ms_pcie_inclusive_pageable"))
 PY
 done
 python scripts/latency_defaults.py 2>/dev/null | tail -4

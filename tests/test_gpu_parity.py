@@ -260,6 +260,28 @@ def test_error_behaviour(solver):
     assert s.termination in (0, 1)
 
 
+def test_staged_refine_equals_refine(solver):
+    """mvo_hip_refine_staged (rays written by the caller into the handle's pinned staging block, which grows
+    and keeps its contents in between) returns exactly what mvo_hip_refine returns on the same blocks."""
+    with capi.Solver(0) as s2:
+        lib = capi.load()
+        fr = np.zeros((3, 13))
+        opt = capi.make_options()
+        assert lib.mvo_hip_refine_staged(s2._h, fr.ctypes.data, 2, 3, C.byref(opt), None) == capi.ERR_STATE  # nothing staged
+        for w, kw in ((scene.reference_defaults_window(), {}), (scene.config1(), dict(use_loss_function=True, **FIXED10)),
+                      (scene.config2(), FIXED10), (scene.make_window(6, 3, 120, seed=11), FIXED10)):
+            o = capi.make_options(**kw)
+            s2.stage(w)
+            fa, sa = s2.refine_staged(w, o)
+            fb, sb = solver.refine(w, o)
+            assert np.array_equal(fa, fb)
+            assert (sa.termination, sa.iterations, sa.final_cost) == (sb.termination, sb.iterations, sb.final_cost)
+        # offsets that do not fit what was staged are refused
+        s2.stage(scene.make_window(6, 3, 120, seed=11))
+        assert lib.mvo_hip_refine_staged(s2._h, np.zeros((200, 13)).ctypes.data, 5, 200, C.byref(opt), None) in (
+            capi.ERR_INVALID_ARGUMENT, capi.ERR_UNSUPPORTED)
+
+
 def test_download_before_upload_is_an_error():
     with capi.Solver(0) as s2:
         assert capi.load().mvo_hip_solve(s2._h) == capi.ERR_STATE

@@ -70,6 +70,26 @@ def test_adapter_refine_matches_oracle(tmp_path, oracle, c, use_loss, fix):
         assert (term, iters) == (so.termination, so.iterations)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_loss", [False, True])
+def test_staged_and_pageable_adapter_paths_agree_bit_for_bit(tmp_path, use_loss):
+    """refine() gathers into the handle's pinned staging block (mvo_hip_staging / mvo_hip_refine_staged) by
+    default; with staged = false it fills std::vectors and calls mvo_hip_refine.  Same blocks, same order,
+    same kernels: the refined baselines and the summary must be byte-identical.  The second window is large
+    enough that the staging block has to grow in the middle of the gather loop."""
+    _need_exe()
+    for c in (CASES[1], dict(N=30, M=5, L=1500, seed=1002, span=("sliding", 20))):
+        w = _window(c)
+        tracks = str(tmp_path / "tracks.bin")
+        scene.write_track_file(w, tracks, use_loss_function=use_loss, **FIXED10)
+        outs = []
+        for mode in ("refine", "refine_pageable"):
+            out = str(tmp_path / f"out_{mode}.bin")
+            subprocess.check_call([EXE, mode, tracks, out])
+            outs.append(open(out, "rb").read())
+        assert outs[0] == outs[1] and len(outs[0]) == 32 * w.N + 40
+
+
 def _read_csr(raw, base):
     n_pairs, n_blocks = struct.unpack_from("<2Q", raw, base)
     offs = np.frombuffer(raw, dtype="<u8", count=n_pairs + 1, offset=base + 16)
