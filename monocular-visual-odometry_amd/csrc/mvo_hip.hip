@@ -236,12 +236,14 @@ struct mvo_hip_context {
   mvo_hip_timing timing{};
   // batched windows without a loss: the fold of chunk c + 1 (HBM-bound) runs on `stream` while the LM
   // loops of the windows chunk c completed (issue-bound) run on `stream_lm`
-  hipStream_t stream_lm[2] = {nullptr, nullptr};  // alternating: consecutive chunks' LM loops may overlap too
-  hipEvent_t ev_chunk[kMaxOverlapChunks + 2] = {};
+  hipStream_t stream_lm[3] = {nullptr, nullptr, nullptr};  // consecutive chunks' LM loops overlap too (4 hardware queues with `stream`)
+  hipEvent_t ev_chunk[kMaxOverlapChunks + 3] = {};
   bool overlap_ready = false;
   int n_chunks = 0;                                      // 0: no overlap for this upload
   uint32_t chunk_block_end[kMaxOverlapChunks] = {};      // fold workgroups [.., end)
   uint32_t chunk_win_end[kMaxOverlapChunks] = {};        // windows whose tiles all lie in workgroups < end
+  int chunk_kind[kMaxOverlapChunks] = {};                // 0: by shape (k_lm<64> / k_lm<256>); 4: k_lm4; 64 / 256: that kernel
+  bool pipelined = false;                                // the plan below is the staggered one (batch_pipeline_plan)
   std::vector<uint32_t> v_win_last_wave;
   // observation-partitioned solve: this rank's RCCL communicator (mvo_hip_comm_init); collectives are
   // queued on `stream` between the observation pass and the LM step
@@ -432,7 +434,20 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
   const bool want_overlap = !h->pass_mode && !h->inline_eval && W >= 256 && P <= 256 && !lm4_eligible(h) &&
                             n_obs >= (uint64_t)kMinChunk * 256 * waves_per_cu * overlap_chunks &&
                             !std::getenv("MVO_HIP_NO_OVERLAP");
-  const uint64_t max_waves = 256ull * waves_per_cu * (want_overlap ? overlap_chunks : 1);
+  // Batches that k_lm4 takes (thousands of windows of <= 64 pairs): the fold runs in four launches and the
+  // LM loops of the windows already folded start beside it -- STAGGERED by kernel: the bulk on k_lm4 (four
+  // windows per wavefront, ~160 us per launch whatever its size), the windows folded too late for that on
+  // k_lm<64> (~120 us), the last two times 256 on k_lm<256> (~65 us, one window per CU), so that what is
+  // left after the fold's end is the shortest LM latency instead of the longest (do_solve).
+  // MEASURED SLOWER than fold-then-k_lm4 (config 3: 0.75-0.82 ms against 0.67-0.70, profiles/r3/NOTES.md): the
+  // LM wavefronts beside the fold take its issue slots and the 16 x finer tiling costs it bandwidth (5.1 ->
+  // 4.2-4.7 TB/s), more than the 90 us of k_lm4 latency the stagger hides.  Kept as an experiment switch
+  // (MVO_HIP_PIPELINE), off by default, with its test.
+  const bool want_pipeline = !h->pass_mode && !h->inline_eval && lm4_eligible(h) && W >= 2048 && P <= 64 &&
+                             !(opt->assembly_mode & (MVO_HIP_ASSEMBLY_ONE_PER_WAVE | MVO_HIP_ASSEMBLY_FOUR_PER_WAVE)) &&
+                             n_obs >= 16000000ull && std::getenv("MVO_HIP_PIPELINE") != nullptr;
+  // every launch of a chunked fold has to fill the chip by itself; the staggered plan's last launches cover 1/16 of the windows
+  const uint64_t max_waves = 256ull * waves_per_cu * (want_pipeline ? 16 : want_overlap ? overlap_chunks : 1);
   uint64_t want_waves = (n_obs + kMinChunk - 1) / kMinChunk;
   if (want_waves > max_waves) want_waves = max_waves;
   if (want_waves == 0) want_waves = 1;
@@ -529,7 +544,28 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
   // overlap plan (no loss, many windows, LM loop in its own launch): equal ranges of fold workgroups;
   // a window may start its LM loop once the last workgroup holding one of its tiles is done
   h->n_chunks = 0;
-  {
+  h->pipelined = false;
+  if (want_pipeline) {
+    // fold time per window at ~5 TB/s (48 B per residual block), in microseconds
+    const double us_per_win = 48.0 * (double)n_obs / (double)W / 5.1e6;
+    uint32_t tail = 256;                                         // k_lm<256>: one window per CU
+    uint32_t mid = (uint32_t)std::lround(45.0 / us_per_win);     // what the fold passes in the ~45 us k_lm<64> is ahead of k_lm4
+    if (const char* e = std::getenv("MVO_HIP_PIPELINE_MID")) mid = (uint32_t)std::atoi(e);
+    if (mid < 128) mid = 128;
+    if (mid > 768) mid = 768;
+    const uint32_t ends[4] = {W - 2 * tail - mid, W - 2 * tail, W - tail, W};
+    const int kinds[4] = {4, 64, 256, 256};
+    for (int c = 0; c < 4; ++c) {
+      h->chunk_win_end[c] = ends[c];
+      h->chunk_kind[c] = kinds[c];
+      // fold workgroups up to the last one that holds a tile of these windows
+      h->chunk_block_end[c] = c == 3 ? (h->n_waves + FOLD_WAVES - 1) / FOLD_WAVES : win_last_wave[ends[c] - 1] / FOLD_WAVES + 1;
+    }
+    // (a workgroup that straddles a chunk boundary belongs to the earlier fold launch: windows of the later
+    // chunk that have tiles in it simply find them done)
+    h->n_chunks = 4;
+    h->pipelined = true;
+  } else {
     const uint32_t blocks = (h->n_waves + FOLD_WAVES - 1) / FOLD_WAVES;
     if (want_overlap && blocks >= 256u * (uint32_t)overlap_chunks) {
       h->n_chunks = overlap_chunks;
@@ -625,7 +661,9 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
       if (h->h_ctl) (void)hipHostFree(h->h_ctl);
       h->h_ctl = nullptr;
       h->h_ctl_cap = 0;
-      HIP_TRY(hipHostMalloc((void**)&h->h_ctl, mirror_bytes + mirror_bytes / 4, hipHostMallocDefault));
+      // coherent (fine-grained) whatever HIP_HOST_COHERENT says: the host polls the marks k_lm writes here
+      // while the kernel may still be running (do_solve); non-coherent memory would only show them at its end
+      HIP_TRY(hipHostMalloc((void**)&h->h_ctl, mirror_bytes + mirror_bytes / 4, hipHostMallocCoherent));
       h->h_ctl_cap = mirror_bytes + mirror_bytes / 4;
     }
     h->h_done = reinterpret_cast<int32_t*>(h->h_ctl);
@@ -1090,7 +1128,7 @@ int do_solve(mvo_hip_context* h) {
       h->overlap_ready = true;
     }
     uint32_t b0 = 0, win0 = 0;
-    bool used[2] = {false, false};
+    bool used[3] = {false, false, false};
     for (int c = 0; c < h->n_chunks; ++c) {
       const uint32_t b1 = h->chunk_block_end[c], win1 = h->chunk_win_end[c];
       HIP_TRY(timed_begin());
@@ -1098,19 +1136,27 @@ int do_solve(mvo_hip_context* h) {
       HIP_TRY(timed_end());
       ++asm_launches;
       if (win1 > win0) {
-        hipStream_t q = h->stream_lm[c & 1];
-        used[c & 1] = true;
-        HIP_TRY(hipEventRecord(h->ev_chunk[c], s));
-        HIP_TRY(hipStreamWaitEvent(q, h->ev_chunk[c], 0));
-        if (lm4_eligible(h)) HIP_TRY(launch_lm4_range(h, prm, win0, win1, q, false));
-        else HIP_TRY(h->P <= 64 ? launch_lm_range<64>(h, prm, win0, win1, q) : launch_lm_range<MVO_LM_NT_LARGE>(h, prm, win0, win1, q));
+        // the staggered plan's last chunk runs behind the fold on the fold's own stream; the others beside it
+        const bool last_inline = h->pipelined && c + 1 == h->n_chunks;
+        const int qi = h->pipelined ? c % 3 : c & 1;
+        hipStream_t q = last_inline ? s : h->stream_lm[qi];
+        if (!last_inline) {
+          used[qi] = true;
+          HIP_TRY(hipEventRecord(h->ev_chunk[c], s));
+          HIP_TRY(hipStreamWaitEvent(q, h->ev_chunk[c], 0));
+        }
+        int kind = h->pipelined ? h->chunk_kind[c] : (lm4_eligible(h) ? 4 : (h->P <= 64 ? 64 : 256));
+        if (kind == 4 && h->trace_cap != 0) kind = 64;  // k_lm4 records no trace (asked for after the upload)
+        if (kind == 4) HIP_TRY(launch_lm4_range(h, prm, win0, win1, q, false));
+        else if (kind == 64) HIP_TRY(launch_lm_range<64>(h, prm, win0, win1, q));
+        else HIP_TRY(launch_lm_range<MVO_LM_NT_LARGE>(h, prm, win0, win1, q));
         ++lm_launches;
       }
       b0 = b1;
       win0 = win1;
     }
     h->lm_started = true;
-    for (int q = 0; q < 2; ++q)
+    for (int q = 0; q < 3; ++q)
       if (used[q]) {
         HIP_TRY(hipEventRecord(h->ev_chunk[kMaxOverlapChunks + q], h->stream_lm[q]));
         HIP_TRY(hipStreamWaitEvent(s, h->ev_chunk[kMaxOverlapChunks + q], 0));
@@ -1857,6 +1903,9 @@ __global__ __launch_bounds__(256) void k_noalloc_prep(unsigned char* sc, const d
     int clamped;
     x[3] = d_reverse_scale(f[12], max_len, min_len, clamped);  // IR.cpp:102
     if (clamped) atomicOr(&clamp_s, 1 << (2 * tid + (clamped - 1)));
+    // the frames are device memory: what mvo_hip_refine's validate() refuses on the host (an infinite or
+    // NaN length, on which the reference's clamp recursion never ends) is reported as BAD_INPUT here
+    if (!isfinite(f[12]) || !isfinite(x[3])) atomicOr(&bad_s, 1);
   }
   __syncthreads();
   if (tid == 0) {
@@ -1914,8 +1963,19 @@ int mvo_hip_refine_noalloc(int device_ordinal, void* stream, mvo_hip_frame* fram
   if (N > MVO_HIP_MAX_FRAMES) return MVO_HIP_ERR_UNSUPPORTED;  // beyond the scratch array's pair tables
   if (n_blocks > MVO_HIP_NOALLOC_MAX_BLOCKS) return MVO_HIP_ERR_UNSUPPORTED;
   if (n_blocks > 0 && (!m0_device || !m1_device)) return MVO_HIP_ERR_INVALID_ARGUMENT;
-  if (options->max_num_iterations < 0 || !(options->highest_length > options->lowest_length))
+  if (options->max_num_iterations < 0 || !(options->highest_length > options->lowest_length) ||
+      !std::isfinite(options->highest_length) || !std::isfinite(options->lowest_length))
     return MVO_HIP_ERR_INVALID_ARGUMENT;
+  {
+    // as validate() for mvo_hip_refine: reverseScale's clamp (IR.cpp:350-363) must land strictly inside
+    // (lowest, highest) -- the reference would recurse forever otherwise
+    const double eps = std::numeric_limits<double>::epsilon();
+    const double lo = options->lowest_length + (options->lowest_length * eps) + eps;
+    const double hi = options->highest_length - (options->highest_length * eps + eps);
+    if (!(lo > options->lowest_length && lo < options->highest_length && hi < options->highest_length &&
+          hi > options->lowest_length))
+      return MVO_HIP_ERR_INVALID_ARGUMENT;
+  }
   if (hipSetDevice(device_ordinal) != hipSuccess) return MVO_HIP_ERR_DEVICE;
   NoallocDevice* dev = nullptr;
   if (noalloc_setup(device_ordinal, &dev) != hipSuccess) return MVO_HIP_ERR_DEVICE;

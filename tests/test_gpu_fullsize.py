@@ -228,6 +228,20 @@ def test_config3_all_4096_windows_in_one_batch(solver, oracle):
     assert solver.timing()["lm_launches"] == 4
     fb, sb = solver.refine_batch(ws, capi.make_options(**FIXED10))
     assert solver.timing()["lm_launches"] == 1  # four windows per wavefront (k_lm4): one fold, one LM launch
+    # the experiment switch MVO_HIP_PIPELINE (read at upload): fold in four launches, k_lm4 on the bulk beside it,
+    # k_lm<64> on the windows folded too late for that, k_lm<256> on the last 2 x 256 -- slower, but
+    # it must give the same results
+    import os
+    os.environ["MVO_HIP_PIPELINE"] = "1"
+    try:
+        fp, sp = solver.refine_batch(ws, capi.make_options(**FIXED10))
+    finally:
+        del os.environ["MVO_HIP_PIPELINE"]
+    tm = solver.timing()
+    assert tm["lm_launches"] == 4 and tm["assembly_launches"] == 4
+    dp = np.abs(np.asarray(fp) - np.asarray(fb)).reshape(4096, -1).max(axis=1)
+    assert np.median(dp) < 1e-12 and dp.max() < 1e-6
+    assert np.mean([a.iterations == b.iterations for a, b in zip(sp, sb)]) > 0.98
     # zero tolerances: a window whose cost stops changing in the last bits ends a step earlier or later
     # depending on the summation order (tile sizes differ between the two paths)
     same = np.array([a.iterations == b.iterations for a, b in zip(s1, sb)])
@@ -236,7 +250,7 @@ def test_config3_all_4096_windows_in_one_batch(solver, oracle):
     assert np.median(d) < 1e-12 and d.max() < 1e-6  # ten iterations amplify the last bits of the sums in a few windows
     assert all(s.termination in (0, 1) and 6 <= s.iterations <= 10 for s in sb)
     assert sum(s.iterations == 10 for s in sb) > 2048
-    for i in (0, 1, 1023, 1024, 2047, 2048, 3071, 3072, 4000, 4095):
+    for i in (0, 1, 1023, 2048, 3071, 3128, 3129, 3583, 3584, 3839, 3840, 4095):  # incl. both sides of the pipeline's chunk boundaries
         fo, so, _ = oracle.refine(ws[i], oracle.make_options(**FIXED10))
         assert np.abs(refined(fb[i], 5) - refined(fo, 5)).max() < 1e-6, i
         assert abs(sb[i].final_cost - so.final_cost) <= 1e-8 * so.initial_cost, i

@@ -95,3 +95,33 @@ def test_noalloc_rejects_sizes_and_inconsistent_offsets(solver):
     s = capi.Summary.from_buffer_copy(summ.cpu().numpy().tobytes())
     assert (s.termination, s.reason) == (2, 9)
     assert np.array_equal(frames.cpu().numpy(), w.frames)
+
+
+def test_noalloc_refuses_what_refine_refuses(solver):
+    """The checks validate() applies for mvo_hip_refine: non-finite or degenerate length bounds are refused on
+    the host; an infinite or NaN initial length (device memory: the host cannot look) ends as
+    FAILURE / BAD_INPUT with the frames untouched instead of NaN results."""
+    import torch
+
+    w = scene.make_window(6, 3, 120, seed=11)
+    dev = torch.device("cuda", 0)
+    p = torch.zeros(64, dtype=torch.float64, device=dev).data_ptr()
+    for kw in (dict(highest_length=float("inf")), dict(lowest_length=float("nan")),
+               dict(lowest_length=4.0, highest_length=np.nextafter(4.0, 5.0))):
+        assert capi.refine_noalloc(0, None, p, 3, 6, capi.make_options(**kw), p, p, p, 10, None) == capi.ERR_INVALID_ARGUMENT
+    for bad in (float("inf"), float("nan")):
+        fr = np.ascontiguousarray(w.frames).copy()
+        fr[1, 12] = bad
+        frames = torch.from_numpy(fr).to(dev)
+        offs = torch.from_numpy(w.pair_offsets.astype(np.uint64).view(np.int64)).to(dev)
+        m0 = torch.from_numpy(np.ascontiguousarray(w.m0)).to(dev)
+        m1 = torch.from_numpy(np.ascontiguousarray(w.m1)).to(dev)
+        summ = torch.zeros(C.sizeof(capi.Summary), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        rc = capi.refine_noalloc(0, None, frames.data_ptr(), w.M, w.N, capi.make_options(**FIXED10), offs.data_ptr(),
+                                 m0.data_ptr(), m1.data_ptr(), w.n_residual_blocks, summ.data_ptr())
+        assert rc == capi.OK
+        torch.cuda.synchronize()
+        s = capi.Summary.from_buffer_copy(summ.cpu().numpy().tobytes())
+        assert (s.termination, s.reason) == (2, 9)
+        assert np.array_equal(frames.cpu().numpy(), fr, equal_nan=True)
