@@ -169,8 +169,13 @@ struct LmShared {
   double G[MVO_MAXM][9];                        // G[k][3*row + col]: columns (s_k jl0, s_k jl1, s'_k v_k)
   double cls[MVO_MAXM * MCX][10];               // class (a, j = min(b, M)): T(6) q(3) cost(1)   (k_lm<256>)
   double kk[MVO_MAXM][10];                      // the pair (k, k) alone: direction columns only (see below)
-  double C1[MVO_MAXM * MCX][10];                // prefix of the classes over a: C1[k][j] = sum_{a<=k} cls[a][j]
-  double D[MVO_MAXM * MCX][10];                 // ... and suffix over j: D[k][j] = sum_{j'>=j} C1[k][j']
+  // prefix of the classes over a, C1[k][j] = sum_{a<=k} cls[a][j], and its suffix over j, D[k][j] = sum_{j'>=j}
+  // C1[k][j'].  k_lm<256>: every helper wavefront forms its OWN copy right behind barrier B1 (the same 70
+  // instructions, the same bits) and multiplies its share of the system out of it, while wavefront 0 decides
+  // on the point -- no wavefront waits for another one's tables (one barrier and 1.1 k cycles per evaluation
+  // less than with wavefront 0 forming them for everybody).  k_lm<64>: copy 0.
+  double C1[3][MVO_MAXM * MCX][10];
+  double D[3][MVO_MAXM * MCX][10];
   double Hz[MVO_MAXC * MVO_MAXC], gz[MVO_MAXC]; // second system buffer (st.H is the first) and the gradient at z
   double gmn_z;                                 // k_lm<256>: gradient max norm at z (helper wavefront)
   int32_t go, phase, hsel, pad_;
@@ -356,6 +361,94 @@ __device__ __forceinline__ double frames_diff_max(int lane, int M, int fix, cons
   return row0_max(lane < M ? acc : 0.0);
 }
 
+// what the product stage reads / writes (lm_block_rows, lm_gradient_entry): one copy of the tables
+struct LmTables {
+  double (*G)[9];
+  double (*kk)[10];
+  double (*C1)[10];
+  double (*D)[10];
+  double* gz;
+};
+__device__ __forceinline__ LmTables lm_tables(LmShared& sh, int copy) {
+  LmTables t;
+  t.G = sh.G; t.kk = sh.kk; t.C1 = sh.C1[copy]; t.D = sh.D[copy]; t.gz = sh.gz;
+  return t;
+}
+
+// Stages (2) and (3) of an evaluation by ONE wavefront.
+// (2) classes in pair order and their prefix over a:  C1[k][j] = sum_{a <= k} cls[a][j].  Class (a, j),
+//     j = min(b, M): j < M is the single pair b = j, j = M collects the pairs b = M .. N-2 (those with a
+//     fixed-frame offset).  Lane (j, v) walks a; classes that do not exist (a > j, a >= M, j > M) count as
+//     zero, so every entry of C1 is defined.
+// (3) suffix over j:  D[k][j] = sum_{j' >= j} C1[k][j'], lane (k, v).  W_kl = D[k][l] for l > k.
+// FROM_PAIRS (k_lm<64> evaluating its own pairs): the classes are read from the per-pair rows in pairbuf.
+template <bool FROM_PAIRS>
+__device__ __forceinline__ void lm_prefix_suffix(const double (*cls)[10], const double* pairbuf, double (*C1)[10],
+                                                 double (*D)[10], int M, int N, int lane) {
+  const int jA = lane / 10, vA = lane - 10 * jA;
+  const int kB = lane < MVO_MAXM * 10 ? jA : 0, vB = vA;
+  if (lane < MCX * 10) {
+    double x[MVO_MAXM];
+    if (!FROM_PAIRS) {
+#pragma unroll
+      for (int a = 0; a < MVO_MAXM; ++a) x[a] = cls[a * MCX + jA][vA];  // reads issue back to back
+    } else {
+      // pairs of class (a, j), a <= j: one for j < M, the N - 1 - M pairs b >= M for j = M; the
+      // five frames' loads of one step are independent (clamped rows for the classes that do not exist)
+      const int cnt = (jA < M) ? 1 : (jA == M ? N - 1 - M : 0);
+      int row[MVO_MAXM];
+#pragma unroll
+      for (int a = 0; a < MVO_MAXM; ++a) {
+        x[a] = 0.0;
+        row[a] = (a < M && a <= jA && jA <= M) ? pair_index(N, a, jA) : -1;
+      }
+      for (int i = 0; i < cnt; ++i) {
+#pragma unroll
+        for (int a = 0; a < MVO_MAXM; ++a) {
+          const double t = pairbuf[(row[a] >= 0 ? row[a] + i : 0) * 10 + vA];
+          x[a] += row[a] >= 0 ? t : 0.0;
+        }
+      }
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int a = 0; a < MVO_MAXM; ++a) {
+      acc += (a < M && a <= jA && jA <= M) ? x[a] : 0.0;
+      C1[a * MCX + jA][vA] = acc;
+    }
+  }
+  wave0_sync();  // (this wavefront's own LDS writes, read back below)
+  if (lane < MVO_MAXM * 10) {
+    double x[MCX];
+#pragma unroll
+    for (int j = 0; j < MCX; ++j) x[j] = C1[kB * MCX + j][vB];
+    double acc = 0.0;
+#pragma unroll
+    for (int j = MCX - 1; j >= 0; --j) {
+      acc += x[j];
+      D[kB * MCX + j][vB] = acc;
+    }
+  }
+  wave0_sync();
+}
+
+// k_lm<256>, wavefront 0: the cost at z = the total of all classes' cost entries, in the order the tables
+// would give it (D[M-1][0][9]: per j the prefix over a, then the suffix from j = M down to 0) -- the verdict
+// on z needs nothing else, so wavefront 0 does not wait for any table.
+__device__ __forceinline__ double lm_cost_total(const double (*cls)[10], int M, int lane) {
+  const int j = lane < MCX ? lane : 0;
+  double x[MVO_MAXM];
+#pragma unroll
+  for (int a = 0; a < MVO_MAXM; ++a) x[a] = cls[a * MCX + j][9];
+  double col = 0.0;
+#pragma unroll
+  for (int a = 0; a < MVO_MAXM; ++a) col += (a < M && a <= j && j <= M) ? x[a] : 0.0;
+  double acc = 0.0;
+#pragma unroll
+  for (int jj = MCX - 1; jj >= 0; --jj) acc += bcast_lane(col, jj);
+  return acc;
+}
+
 // The current ceres::IterationSummary and the verdict on the evaluation just completed, handed from
 // lm_decide to lm_step.
 struct LmDecision {
@@ -377,7 +470,7 @@ __device__ __forceinline__ void lm_trace_row(TraceRec* __restrict__ trace, const
 
 // Wave-0 control logic: Ceres 1.14 TrustRegionMinimizer::Minimize restated around the evaluation
 // that was just completed at z (= x0 in PH_EVAL_X0, the candidate in PH_EVAL_CAND).  Two halves:
-//   lm_decide  needs the COST at z only (sh.D): tolerances, step quality, accept / reject, radius.  In
+//   lm_decide  needs the COST at z only: tolerances, step quality, accept / reject, radius.  In
 //              k_lm<256> it runs while two other wavefronts multiply out the blocks of the system at z.
 //   lm_step    needs the system: x <- z, gradient norm, termination tests, the damped solve, the next
 //              candidate.  Returns 1 when a new candidate awaits evaluation (published in sh.zvec/zt).
@@ -386,7 +479,7 @@ __device__ __forceinline__ void lm_trace_row(TraceRec* __restrict__ trace, const
 // Written for a short instruction stream (one wavefront issues an instruction per ~4.4 cycles whatever
 // the dependences): one exit, the per-iteration record only as scalars, square roots only where a
 // tolerance or the trace asks for them.
-__device__ __forceinline__ void lm_decide(LmRegs& r, LmShared& sh, const SolveParams& prm, int M, int lane,
+__device__ __forceinline__ void lm_decide(LmRegs& r, double cost_raw, const SolveParams& prm, int M, int lane,
                                           TraceRec* __restrict__ trace, LmDecision& d MVO_STAMP_PARAM) {
   const int fix = prm.fix_length;
 #ifdef MVO_LM_STAMPS
@@ -401,7 +494,7 @@ __device__ __forceinline__ void lm_decide(LmRegs& r, LmShared& sh, const SolvePa
   // Ceres 1.14 rejects non-finite residuals (ResidualBlock::Evaluate / IsEvaluationValid): at the
   // initial point the minimizer fails before any step; a candidate that "failed to evaluate" gets
   // cost = max and is rejected.  A NaN/Inf residual makes the summed cost non-finite.
-  const double cost_raw = sh.D[(MVO_MAXM - 1) * MCX][9];  // all classes: prefix over every a, suffix from j = 0
+  // cost_raw = all classes: prefix over every a, suffix from j = 0 (D[M-1][0][9], or lm_cost_total)
   const double cost_z = (d.first || isfinite(cost_raw)) ? cost_raw : DBL_MAX;
   d.cost_z = cost_z;
   d.take_z = d.first;
@@ -721,9 +814,9 @@ __device__ __forceinline__ void lm_gradient_entry(SH& sh, bool on, int k4, int i
 
 // k_lm<256>, a helper wavefront: the gradient at z and its max norm || z - Plus(z, -g) ||_inf, the
 // same arithmetic lm_step performs in k_lm<64> (frames_plus with sign = -1, frames_diff_max).
-__device__ __forceinline__ void lm_gradient_and_norm(LmShared& sh, int M, int fix, int lane) {
+__device__ __forceinline__ void lm_gradient_and_norm(LmShared& sh, LmTables& tb, int M, int fix, int lane) {
   const int e = lane < 3 * M ? lane : 0;
-  lm_gradient_entry(sh, lane < 3 * M, e / 3, e % 3);
+  lm_gradient_entry(tb, lane < 3 * M, e / 3, e % 3);
   wave0_sync();  // this wavefront's own LDS writes, read back below
   const int k = lane < M ? lane : 0;
   const double xv[3] = {sh.zvec[k][0], sh.zvec[k][1], sh.zvec[k][2]};
@@ -971,6 +1064,17 @@ __device__ __forceinline__ void half_reduce10(const double (&v)[10], int lane, d
   x4 += dpp_mov_f64<0x141>(x4);
 }
 
+// k_lm<256>, helper wavefront cw (0..2) between barriers B1 and B1c: its own copy of the prefix / suffix
+// tables, then its share of the system at z -- the diagonal blocks, the gradient and its norm, the other blocks.
+__device__ __forceinline__ void lm_helper_products(LmShared& sh, const BlockRole& br, int cw, int M, int N, int fix,
+                                                   int lane) {
+  LmTables tb = lm_tables(sh, cw);
+  lm_prefix_suffix<false>(sh.cls, nullptr, tb.C1, tb.D, M, N, lane);
+  if (cw == 0) lm_block_rows<1>(tb, br, lane, sh.hsel ? sh.st.H : sh.Hz);
+  else if (cw == 1) lm_gradient_and_norm(sh, tb, M, fix, lane);
+  else lm_block_rows<2>(tb, br, lane, sh.hsel ? sh.st.H : sh.Hz);
+}
+
 // k_lm<256>, wavefronts 1..3: the loop of a class wavefront.  Two layouts, chosen per window:
 //   N - 1 - M <= 32 (HALF): wavefront w evaluates the pairs (a, b), a = 2 (w - 1) + (lane >> 5),
 //                   b = M + (lane & 31): one pair per lane, one evaluation, one reduction per half;
@@ -978,7 +1082,7 @@ __device__ __forceinline__ void half_reduce10(const double (&v)[10], int lane, d
 // Either way the class totals end up in sh.cls[a][M].  Then, while wavefront 0 decides on the point
 // (lm_decide), wavefronts 1 and 3 multiply out the diagonal / the other blocks of the system and
 // wavefront 2 the gradient and its norm.  A class wavefront executes exactly the workgroup barriers wavefront 0 executes (marked
-// B0 / B1 / B1b / B1c / B2 on both sides).
+// B0 / B1 / B1c / B2 on both sides).
 template <int NT>
 __device__ __forceinline__ void lm_class_wave(LmShared& sh, const SolveParams& prm, int cw, int lane, int M, int N, int P,
                                               bool& need_pass, int unit_slots, const PairDev* __restrict__ wp,
@@ -1025,10 +1129,7 @@ __device__ __forceinline__ void lm_class_wave(LmShared& sh, const SolveParams& p
       }
     }
     __syncthreads();  // B1
-    __syncthreads();  // B1b
-    if (cw == 0) lm_block_rows<1>(sh, br, lane, sh.hsel ? sh.st.H : sh.Hz);
-    else if (cw == 1) lm_gradient_and_norm(sh, M, prm.fix_length, lane);
-    else lm_block_rows<2>(sh, br, lane, sh.hsel ? sh.st.H : sh.Hz);
+    lm_helper_products(sh, br, cw, M, N, prm.fix_length, lane);
     __syncthreads();  // B1c
     __syncthreads();  // B2
     if (sh.go) need_pass = true;
@@ -1040,10 +1141,7 @@ __device__ __forceinline__ void lm_class_wave(LmShared& sh, const SolveParams& p
     // multiply out the system.  Same barriers as below.
     const BlockRole br = block_role(M, lane);
     __syncthreads();  // B1
-    __syncthreads();  // B1b
-    if (cw == 0) lm_block_rows<1>(sh, br, lane, sh.hsel ? sh.st.H : sh.Hz);
-    else if (cw == 1) lm_gradient_and_norm(sh, M, prm.fix_length, lane);
-    else lm_block_rows<2>(sh, br, lane, sh.hsel ? sh.st.H : sh.Hz);
+    lm_helper_products(sh, br, cw, M, N, prm.fix_length, lane);
     __syncthreads();  // B1c
     __syncthreads();  // B2
     if (sh.go) need_pass = true;
@@ -1149,10 +1247,7 @@ __device__ __forceinline__ void lm_class_wave(LmShared& sh, const SolveParams& p
         }
     }
     __syncthreads();  // B1: class totals are in LDS
-    __syncthreads();  // B1b: wavefront 0 has formed C1 and D
-    if (cw == 0) lm_block_rows<1>(sh, br, lane, sh.hsel ? sh.st.H : sh.Hz);
-    else if (cw == 1) lm_gradient_and_norm(sh, M, prm.fix_length, lane);
-    else lm_block_rows<2>(sh, br, lane, sh.hsel ? sh.st.H : sh.Hz);
+    lm_helper_products(sh, br, cw, M, N, prm.fix_length, lane);
     __syncthreads();  // B1c: the system at z is in LDS
     __syncthreads();  // B2: wavefront 0 has taken its step and published the next point
     if (!sh.go) break;
@@ -1287,8 +1382,6 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
   bool have_in = false;
   // lane roles of the three assembly stages (fixed): (j, v) of the prefix stage, (k, v) of the suffix
   // stage, block row (k, l, i) / gradient entry (k, i) of the product stage
-  const int jA = lane / 10, vA = lane - 10 * jA;
-  const int kB = lane < MVO_MAXM * 10 ? jA : 0, vB = vA;
   const BlockRole br = block_role(M, lane);  // block rows of the upper triangle; then 3M gradient entries
 
   while (!need_pass && (!LARGE || wave0)) {
@@ -1349,69 +1442,24 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
     else wave0_sync();
     MVO_STAMP(1);
     {
-      // (2) classes in pair order and their prefix over a:  C1[k][j] = sum_{a <= k} cls[a][j].
-      // Class (a, j), j = min(b, M): j < M is the single pair b = j, j = M collects the pairs
-      // b = M .. N-2 (those with a fixed-frame offset).  Lane (j, v) walks a; classes that do not
-      // exist (a > j, a >= M, j > M) count as zero, so every entry of C1 is defined.
-      if (lane < MCX * 10) {
-        double x[MVO_MAXM];
-        if (LARGE || prm.cls_ready) {
-#pragma unroll
-          for (int a = 0; a < MVO_MAXM; ++a) x[a] = sh.cls[a * MCX + jA][vA];  // reads issue back to back
-        } else {
-          // pairs of class (a, j), a <= j: one for j < M, the N - 1 - M pairs b >= M for j = M; the
-          // five frames' loads of one step are independent (clamped rows for the classes that do not exist)
-          const int cnt = (jA < M) ? 1 : (jA == M ? N - 1 - M : 0);
-          int row[MVO_MAXM];
-#pragma unroll
-          for (int a = 0; a < MVO_MAXM; ++a) {
-            x[a] = 0.0;
-            row[a] = (a < M && a <= jA && jA <= M) ? pair_index(N, a, jA) : -1;
-          }
-          for (int i = 0; i < cnt; ++i) {
-#pragma unroll
-            for (int a = 0; a < MVO_MAXM; ++a) {
-              const double t = pairbuf[(row[a] >= 0 ? row[a] + i : 0) * 10 + vA];
-              x[a] += row[a] >= 0 ? t : 0.0;
-            }
-          }
-        }
-        double acc = 0.0;
-#pragma unroll
-        for (int a = 0; a < MVO_MAXM; ++a) {
-          acc += (a < M && a <= jA && jA <= M) ? x[a] : 0.0;
-          sh.C1[a * MCX + jA][vA] = acc;
-        }
-      }
-      wave0_sync();
-      MVO_STAMP(2);
-      // (3) suffix over j:  D[k][j] = sum_{j' >= j} C1[k][j'], lane (k, v).  W_kl = D[k][l] for l > k.
-      if (lane < MVO_MAXM * 10) {
-        double x[MCX];
-#pragma unroll
-        for (int j = 0; j < MCX; ++j) x[j] = sh.C1[kB * MCX + j][vB];
-        double acc = 0.0;
-#pragma unroll
-        for (int j = MCX - 1; j >= 0; --j) {
-          acc += x[j];
-          sh.D[kB * MCX + j][vB] = acc;
-        }
-      }
-      wave0_sync();
-      MVO_STAMP(3);
-      // (4) the blocks of the system at z and the verdict on z.  k_lm<256>: two helper wavefronts multiply
-      // out the blocks and the gradient (lm_class_wave) while this one decides -- the verdict needs the
-      // cost only; k_lm<64>: one after the other.
+      // (2)-(4): prefix / suffix tables, the blocks of the system at z, and the verdict on z.  k_lm<256>: the
+      // helper wavefronts form the tables (each its own copy) and multiply out blocks and gradient
+      // (lm_helper_products) while this one decides -- the verdict needs the cost only, which it adds up
+      // itself; k_lm<64>: one after the other.
       LmDecision dec;
       if (LARGE) {
-        __syncthreads();  // B1b: C1 and D are complete
-        lm_decide(r, sh, prm, M, lane, (w == 0) ? trace : nullptr, dec MVO_STAMP_ARG);
+        const double cost_raw = lm_cost_total(sh.cls, M, lane);
+        lm_decide(r, cost_raw, prm, M, lane, (w == 0) ? trace : nullptr, dec MVO_STAMP_ARG);
         __syncthreads();  // B1c: the system at z and its gradient norm are complete
       } else {
-        lm_block_rows<0>(sh, br, lane, hsel ? sh.st.H : sh.Hz);
-        lm_gradient_entry(sh, lane >= br.nB4 && lane < br.nB4 + 3 * M, br.k4, br.i4);
+        LmTables tb = lm_tables(sh, 0);
+        if (prm.cls_ready) lm_prefix_suffix<false>(sh.cls, nullptr, tb.C1, tb.D, M, N, lane);
+        else lm_prefix_suffix<true>(sh.cls, pairbuf, tb.C1, tb.D, M, N, lane);
+        MVO_STAMP(3);
+        lm_block_rows<0>(tb, br, lane, hsel ? sh.st.H : sh.Hz);
+        lm_gradient_entry(tb, lane >= br.nB4 && lane < br.nB4 + 3 * M, br.k4, br.i4);
         wave0_sync();
-        lm_decide(r, sh, prm, M, lane, (w == 0) ? trace : nullptr, dec MVO_STAMP_ARG);
+        lm_decide(r, tb.D[(MVO_MAXM - 1) * MCX][9], prm, M, lane, (w == 0) ? trace : nullptr, dec MVO_STAMP_ARG);
       }
       MVO_STAMP(4);
       // ---------------- damping, next candidate ----------------
