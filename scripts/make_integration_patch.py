@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Writes integration/mvo_use_hip.patch: the three reference-side edits of INTEGRATION.md as a unified
+"""Writes integration/mvo_use_hip.patch: the four reference-side edits of INTEGRATION.md as a unified
 diff against the reference tree (run where /root/reference exists; the patch only ADDS lines, so the
 only reference text it carries is two lines of context around each insertion).
   python scripts/make_integration_patch.py            # regenerate
@@ -86,19 +86,42 @@ CPP_BODY = '''
 '''
 
 
+FRAME_HPP = '''#ifdef MVO_USE_HIP
+  /**
+   * What mvo_hip_adapter::TrackMirror reads of a keyframe (IterativeRefinementHip.hpp): the projected
+   * positions and the predecessor indices of the features [from, size()), under the frame's lock.
+   */
+  void getFeatureTable(std::size_t from, std::vector<cv::Vec3d> &rays, std::vector<int> &preFeature) const {
+    rays.clear();
+    preFeature.clear();
+    this->lock();
+    for (std::size_t i = from; i < this->_features.size(); i++) {
+      rays.push_back(this->_features[i]._positionProjected);
+      preFeature.push_back(this->_features[i]._preFeature);
+    }
+    this->unlock();
+  }
+#endif
+
+'''
+
+
 def insert_after(lines, needle, text, occurrence=0):
     idx = [i for i, l in enumerate(lines) if needle in l][occurrence]
     return lines[: idx + 1] + text.splitlines(keepends=True) + lines[idx + 1:]
 
 
-def insert_before(lines, needle, text):
-    idx = [i for i, l in enumerate(lines) if needle in l][0]
+def insert_before(lines, needle, text, back=0):
+    idx = [i for i, l in enumerate(lines) if needle in l][0] - back
     return lines[:idx] + text.splitlines(keepends=True) + lines[idx:]
 
 
 def edited(rel, lines):
     if rel.endswith("CMakeLists.txt"):
         return insert_after(lines, "add_dependencies(mvo_node mvo_gencfg)", CMAKE)
+    if rel.endswith("Frame.hpp"):
+        # in front of the doc comment of the member getCorrespondingFeatures(past, ...)
+        return insert_before(lines, " * Retrieves corresponding Features between this Frame and the n to the past Frame.", FRAME_HPP, back=1)
     if rel.endswith("IterativeRefinement.hpp"):
         lines = insert_after(lines, '#include "../operations/VisualisationUtils.hpp"', HPP_INCLUDE)
         lines = insert_before(lines, "IterativeRefinement() = default;", HPP_BEFORE_CTOR)
@@ -107,7 +130,8 @@ def edited(rel, lines):
     return insert_after(lines, "assert(numberToRefine > 0);", CPP_BODY)
 
 
-FILES = ["mvo/CMakeLists.txt", "mvo/src/algorithms/IterativeRefinement.hpp", "mvo/src/algorithms/IterativeRefinement.cpp"]
+FILES = ["mvo/CMakeLists.txt", "mvo/src/algorithms/IterativeRefinement.hpp", "mvo/src/algorithms/IterativeRefinement.cpp",
+         "mvo/src/sliding_window/Frame.hpp"]
 
 
 def build():
@@ -134,6 +158,7 @@ def check():
             subprocess.check_call(["git", "apply", PATCH], cwd=tmp)
             body = open(os.path.join(tmp, FILES[2])).read()
             assert "mvo_hip_adapter::refine<cv::Vec3d>" in body and body.count("#ifdef MVO_USE_HIP") == 2
+            assert "void getFeatureTable(std::size_t from" in open(os.path.join(tmp, FILES[3])).read()
         return r.returncode, r.stderr
 
 
