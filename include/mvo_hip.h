@@ -239,13 +239,18 @@ int mvo_hip_partial_sums(mvo_hip_handle h, void *device_buffer, uint64_t n_doubl
  * LM step entirely on the handle's stream -- no host round trip per pass; results as after
  * mvo_hip_solve, identical on every rank (mvo_hip_download).  Every rank must make the same calls in
  * the same order.  Fail-stop: a rank whose HIP or RCCL call fails returns an error while the others wait
- * in their next collective -- tear the job down, as after any failed collective.  librccl.so.1 is opened on the first of these calls (MVO_HIP_ERR_UNSUPPORTED when it
+ * in their next collective -- tear the job down, as after any failed collective: mvo_hip_comm_abort
+ * (ncclCommAbort, no wait for the stream; callable from another thread than the one stuck in the solve)
+ * ends this rank's pending collectives and releases the communicator, and mvo_hip_comm_destroy does the
+ * same by itself on a handle whose own collective call failed.  After an abort the handle holds no
+ * result (mvo_hip_download: MVO_HIP_ERR_STATE) and may be given a new communicator.  librccl.so.1 is opened on the first of these calls (MVO_HIP_ERR_UNSUPPORTED when it
  * cannot be found), so single-GPU users never load it.  mvo_hip_comm_destroy (or mvo_hip_destroy)
  * releases the communicator. */
 #define MVO_HIP_COMM_ID_BYTES 128
 int mvo_hip_comm_unique_id(void *id_out);
 int mvo_hip_comm_init(mvo_hip_handle h, const void *unique_id, int rank, int world);
 int mvo_hip_comm_destroy(mvo_hip_handle h);
+int mvo_hip_comm_abort(mvo_hip_handle h);
 int mvo_hip_solve_partitioned(mvo_hip_handle h);
 
 /* Debug/parity entry point: the raw residual r_i and the raw local Jacobian row of every

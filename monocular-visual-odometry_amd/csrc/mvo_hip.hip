@@ -225,6 +225,7 @@ struct mvo_hip_context {
   bool pass_mode = false;
   bool inline_eval = false;  // k_lm runs the observation passes itself (small or many windows)
   bool tickets_clean = false;  // d_pticket is all zero (it is after every completed launch)
+  bool comm_broken = false;      // an ncclAllReduce call failed on this communicator
   bool pairsum_foreign = false;  // d_pairsum holds all-reduced sums (partitioned no-loss solve): rows of pairs that are empty HERE are not zero
   std::vector<mvo_hip_frame> h_frames;  // copy of the uploaded frames (write-back base)
   std::vector<PairDev> h_pairs;
@@ -1003,6 +1004,7 @@ int do_solve_partitioned(mvo_hip_context* h) {
     const ncclResult_t r = rc.AllReduce(buf, buf, partial_count(h), ncclDouble, ncclSum, h->comm, s);
     if (r != ncclSuccess) {
       h->last_rccl_error = r;
+      h->comm_broken = true;  // the peers are waiting in this collective: mvo_hip_comm_destroy aborts instead of draining
       return MVO_HIP_ERR_DEVICE;
     }
     return MVO_HIP_OK;
@@ -1686,12 +1688,29 @@ int mvo_hip_comm_init(mvo_hip_handle h, const void* unique_id, int rank, int wor
 int mvo_hip_comm_destroy(mvo_hip_handle h) {
   if (!h) return MVO_HIP_ERR_INVALID_ARGUMENT;
   if (!h->comm) return MVO_HIP_OK;
+  if (h->comm_broken) return mvo_hip_comm_abort(h);  // a collective failed: draining the stream could wait for ever
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   const ncclResult_t r = mvo_rccl().CommDestroy(h->comm);
   h->comm = nullptr;
   h->comm_world = 1;
   h->comm_rank = 0;
+  return r == ncclSuccess ? MVO_HIP_OK : MVO_HIP_ERR_DEVICE;
+}
+
+int mvo_hip_comm_abort(mvo_hip_handle h) {
+  if (!h) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  if (!h->comm) return MVO_HIP_OK;
+  // no stream synchronisation: this is the way out for a rank whose peers have failed, i.e. whose stream
+  // holds a collective that will never complete (ncclCommAbort ends it)
+  const MvoRccl& rc = mvo_rccl();
+  const ncclResult_t r = rc.CommAbort ? rc.CommAbort(h->comm) : rc.CommDestroy(h->comm);
+  h->comm = nullptr;
+  h->comm_world = 1;
+  h->comm_rank = 0;
+  h->comm_broken = false;
+  h->solved = false;       // whatever the aborted solve left behind is not a result
+  h->done_ready = false;
   return r == ncclSuccess ? MVO_HIP_OK : MVO_HIP_ERR_DEVICE;
 }
 

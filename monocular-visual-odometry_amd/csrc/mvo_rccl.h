@@ -6,7 +6,7 @@
 // loading it, so it is opened on the first mvo_hip_comm_* call (dlopen "librccl.so.1": the same
 // search and SONAME rules as a DT_NEEDED entry -- in a process that already holds an RCCL, e.g.
 // PyTorch's, that copy and its HIP runtime are the ones used, as for libamdhip64).  Types come from
-// <rccl/rccl.h>; only the five entry points below are resolved.
+// <rccl/rccl.h>; only the entry points below are resolved.
 #pragma once
 
 #include <dlfcn.h>
@@ -18,6 +18,7 @@ struct MvoRccl {
   decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
   decltype(&ncclCommInitRank) CommInitRank = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclCommAbort) CommAbort = nullptr;  // optional: mvo_hip_comm_abort falls back on CommDestroy
   decltype(&ncclAllReduce) AllReduce = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
   bool ok = false;
@@ -33,6 +34,7 @@ inline const MvoRccl& mvo_rccl() {
     r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
     r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+    r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(dlsym(lib, "ncclCommAbort"));
     r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(lib, "ncclAllReduce"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
     r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce && r.GetErrorString;

@@ -37,7 +37,7 @@ EXPORTED_SYMBOLS = [
     "mvo_hip_num_pairs", "mvo_hip_status_string", "mvo_hip_version", "mvo_hip_partial_begin",
     "mvo_hip_partial_pass", "mvo_hip_partial_advance", "mvo_hip_partial_sums", "mvo_hip_partial_sums_count", "mvo_hip_debug_poison_lds",
     "mvo_hip_debug_check_guards", "mvo_hip_refine_noalloc", "mvo_hip_eval_at", "mvo_hip_debug_set_point",
-    "mvo_hip_debug_pair_sums", "mvo_hip_staging", "mvo_hip_refine_staged", "mvo_hip_comm_unique_id", "mvo_hip_comm_init", "mvo_hip_comm_destroy", "mvo_hip_solve_partitioned",
+    "mvo_hip_debug_pair_sums", "mvo_hip_staging", "mvo_hip_refine_staged", "mvo_hip_comm_unique_id", "mvo_hip_comm_init", "mvo_hip_comm_destroy", "mvo_hip_comm_abort", "mvo_hip_solve_partitioned",
 ]
 
 
@@ -148,6 +148,7 @@ def load():
         L.mvo_hip_comm_unique_id.argtypes = [C.c_void_p]
         L.mvo_hip_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.mvo_hip_comm_destroy.argtypes = [C.c_void_p]
+        L.mvo_hip_comm_abort.argtypes = [C.c_void_p]
         L.mvo_hip_solve_partitioned.argtypes = [C.c_void_p]
         L.mvo_hip_debug_set_point.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         L.mvo_hip_pair_moments.argtypes = [C.c_void_p, C.c_void_p]
@@ -373,6 +374,12 @@ class Solver:
         rc = self._lib.mvo_hip_comm_destroy(self._h)
         if rc != OK:
             raise MvoHipError(rc, "mvo_hip_comm_destroy")
+
+    def comm_abort(self):
+        """ncclCommAbort: the way out after a failed collective (no wait for the stream)."""
+        rc = self._lib.mvo_hip_comm_abort(self._h)
+        if rc != OK:
+            raise MvoHipError(rc, "mvo_hip_comm_abort")
 
     def solve_partitioned_rccl(self):
         rc = self._lib.mvo_hip_solve_partitioned(self._h)

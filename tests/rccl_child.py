@@ -44,4 +44,12 @@ with capi.Solver(0, profiling=False) as s:
     s.upload([scene.make_window(6, 3, 120, seed=11)], capi.make_options(**FIXED10))
     s.solve_partitioned_rccl()
     out["reinit_iterations"] = int(s.download()[1][0].iterations)
+    # the fail-stop exit: abort instead of destroy; the handle then holds neither communicator nor result
+    s.comm_abort()
+    s.comm_abort()                          # idempotent
+    L = capi.load()
+    out["after_abort"] = [int(L.mvo_hip_solve_partitioned(s._h)), int(L.mvo_hip_download(s._h, None, None))]
+    s.comm_init(capi.comm_unique_id(), 0, 1)
+    s.solve_partitioned_rccl()
+    out["after_abort_iterations"] = int(s.download()[1][0].iterations)
 print("RESULT " + json.dumps(out))

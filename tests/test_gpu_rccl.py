@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 from _util import FIXED10, refined
-from mvo_amd import scene
+from mvo_amd import capi, scene
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -33,6 +33,8 @@ def test_world_of_one_rccl_solve_through_the_c_abi_without_torch(oracle):
         assert o["iterations"] == o["iterations_single"]
         assert np.allclose(o["final_cost"], o["final_cost_single"], rtol=1e-9, atol=0)
     assert out["reinit_iterations"] == 10
+    assert out["after_abort"] == [capi.ERR_STATE, capi.ERR_STATE]  # mvo_hip_comm_abort: no communicator, no result
+    assert out["after_abort_iterations"] == 10
     # and against the oracle
     w = scene.make_window(30, 5, 800, seed=41, span=("sliding", 18))
     fo, so, _ = oracle.refine(w, oracle.make_options(**FIXED10))
