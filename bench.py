@@ -616,6 +616,10 @@ def main():
     ap.add_argument("--weak", action="store_true", help="N > 1: every rank its own copy of the workload")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-large", action="store_true", help="skip the config-4-size roofline leg")
+    ap.add_argument("--no-pcie", action="store_true",
+                    help="skip the host-buffer (PCIe-inclusive) legs: their fold launches -- cold behind a copy, or reading "
+                         "pinned host memory in place -- carry the same kernel name as the timed region's and would be "
+                         "averaged into it by a kernel trace (scripts/profile.sh)")
     args = ap.parse_args()
     global BK_DEVICE
 
@@ -785,7 +789,7 @@ def main():
         "roofline": roof,
     }
 
-    if rank == 0 and not partitioned and len(ws) == 1:
+    if rank == 0 and not partitioned and len(ws) == 1 and not args.no_pcie:
         # the call the reference would actually make: HOST buffers in and out (upload over PCIe + solve +
         # download) -- never part of `value`.  Two forms: the gather loop wrote the rays into the handle's
         # pinned staging block (mvo_hip_staging + mvo_hip_refine_staged: what the shipped adapter does), or

@@ -6,7 +6,7 @@ OUT=$R/gpurun_out/ks_$WL
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -- \
-  python3 "$R/bench.py" --workload $WL --steps $ST --warmup 3 --no-cpu --no-large > "$OUT/bench.json" 2> "$OUT/err.log" || { tail -5 "$OUT/err.log"; exit 1; }
+  python3 "$R/bench.py" --workload $WL --steps $ST --warmup 3 --no-cpu --no-large --no-pcie > "$OUT/bench.json" 2> "$OUT/err.log" || { tail -5 "$OUT/err.log"; exit 1; }
 F=$(find "$OUT" -name "*kernel_stats.csv" | head -1)
 python3 - "$F" <<'PY'
 import csv, sys

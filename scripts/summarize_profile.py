@@ -11,11 +11,12 @@ from mvo_amd.srchash import source_hash  # noqa: E402
 
 out = sys.argv[1]
 print(f"# rocprofv3 summary ({os.path.basename(out)})\n")
-print("Each trace is ONE workload (`--no-large` on config 2 / 5; config 4 / 4r traced on their own).\n"
-      "`avg_launch_us` in the bench lines below was measured with HIP events UNDER the profiler, which\n"
-      "adds ~10 us to every event interval (config 2: 18 us by events vs 5.7 us in the trace); outside\n"
-      "the profiler the same interval reads 7.4 us (events cost ~2 us around a 5.5-us kernel) and the\n"
-      "config-4-size launches agree within 3 % (88-94 us by events vs 91.5 us here).\n")
+print("Each trace is ONE workload, the bench's timed region and its warm-up only (`--no-large --no-pcie` on config 2 / 5:\n"
+      "the host-buffer legs launch the same fold kernel cold behind a copy, 12-14 us, or reading pinned host memory\n"
+      "in place, 111 us, and would be averaged into the kernel's line; config 3 / 4 / 4r traced on their own).\n"
+      "`avg_launch_us` in the bench lines below was measured with HIP events UNDER the profiler, which adds ~10 us\n"
+      "to every event interval; outside the profiler the config-2 interval reads 9.8 us (events cost ~2.4 us around\n"
+      "a 7.4-us kernel) and the config-4-size launches agree with the trace within 1 %: `profiles/*/bench_*_unprofiled.json`.\n")
 for d in sorted(glob.glob(os.path.join(out, "kt_*"))):
     if not os.path.isdir(d):
         continue
