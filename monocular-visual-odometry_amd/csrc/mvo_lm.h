@@ -300,28 +300,11 @@ __device__ __forceinline__ void gj_setup(double (&a)[MVO_MAXC], const double (&h
   }
 }
 
-// acc += row_bcast<J>(acc) * nf as ONE instruction: v_fmac_f64 with a DPP source operand (row_newbcast is the
-// DPP control the fp64 ALU accepts on gfx90a and later).  The compiler keeps the broadcast as a v_mov_b64_dpp of
-// its own in front of a v_fma_f64 -- 120 extra instructions per elimination on a wavefront whose instruction
-// count is its run time.  Same product, same addend, one rounding: bit for bit the two-instruction form.
-// A DPP read needs two wait states behind a VALU write of the register it reads, and the compiler does not see
-// into the asm: GUARD puts them in front (s_nop 1) wherever the elimination's order does not already separate
-// the two by two instructions (see gj_eliminate).  volatile: the statements keep their order among themselves.
-template <int J, bool GUARD>
-__device__ __forceinline__ void fmac_row_bcast(double& acc, double nf) {
-  if constexpr (GUARD)
-    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf"
-                 : "+v"(acc) : "v"(nf), "n"(J));
-  else
-    asm volatile("v_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf"
-                 : "+v"(acc) : "v"(nf), "n"(J));
-}
-
 template <int J, int K>
-__device__ __forceinline__ void gj_row_update(double (&a)[MVO_MAXC], double nf) {
+__device__ __forceinline__ void gj_row_update(double (&a)[MVO_MAXC], double f) {
   if constexpr (K < MVO_MAXC) {
-    fmac_row_bcast<J, false>(a[K], nf);
-    gj_row_update<J, K + 1>(a, nf);
+    a[K] -= f * row_bcast<J>(a[K]);
+    gj_row_update<J, K + 1>(a, f);
   }
 }
 
@@ -349,19 +332,16 @@ __device__ __forceinline__ void gj_eliminate(double (&a)[MVO_MAXC], double& rhs,
     int lane_here = lane;
     asm volatile("" : "+v"(lane_here));
     const bool me = lane_here == J;
-    const double nf = me ? 0.0 : a[J] * -rinv;  // minus the row's multiplier
+    const double f = me ? 0.0 : a[J] * rinv;
     myrinv = me ? rinv : myrinv;
     double piv_next = 1.0, rinv_next = 1.0;
-    // Wait states: a[K] (K >= J + 2) was last written by step J - 1's update of the same column, and at
-    // least the two statements for rhs and a[J + 1] lie between; a[J + 1] and rhs may have been written by
-    // the statement just before (the last steps), so those two carry the guard.
     if constexpr (J + 1 < MVO_MAXC) {
-      fmac_row_bcast<J, true>(a[J + 1], nf);
+      a[J + 1] -= f * row_bcast<J>(a[J + 1]);
       piv_next = bcast_lane(a[J + 1] + ddl, J + 1);
       rinv_next = fast_rcp(piv_next);
-      gj_row_update<J, J + 2>(a, nf);
+      gj_row_update<J, J + 2>(a, f);
     }
-    fmac_row_bcast<J, true>(rhs, nf);
+    rhs -= f * row_bcast<J>(rhs);
     gj_eliminate<J + 1>(a, rhs, myrinv, phimax, lane, ddl, piv_next, rinv_next, n);
   }
 }

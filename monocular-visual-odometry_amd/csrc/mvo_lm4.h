@@ -108,16 +108,16 @@ __device__ __forceinline__ void gj_eliminate4(double (&a)[MVO_MAXC], double& rhs
     int l_here = l;
     asm volatile("" : "+v"(l_here));
     const bool me = l_here == J;
-    const double nf = me ? 0.0 : a[J] * -rinv;  // minus the row's multiplier (fmac_row_bcast, mvo_lm.h)
+    const double f = me ? 0.0 : a[J] * rinv;
     myrinv = me ? rinv : myrinv;
     double piv_next = 1.0, rinv_next = 1.0;
     if constexpr (J + 1 < MVO_MAXC) {
-      fmac_row_bcast<J, true>(a[J + 1], nf);
+      a[J + 1] -= f * row_bcast<J>(a[J + 1]);
       piv_next = row_bcast<J + 1>(a[J + 1] + ddl);
       rinv_next = fast_rcp(piv_next);
-      gj_row_update<J, J + 2>(a, nf);
+      gj_row_update<J, J + 2>(a, f);
     }
-    fmac_row_bcast<J, true>(rhs, nf);
+    rhs -= f * row_bcast<J>(rhs);
     gj_eliminate4<J + 1>(a, rhs, myrinv, phimax, l, ddl, piv_next, rinv_next);
   }
 }
