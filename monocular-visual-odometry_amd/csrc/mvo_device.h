@@ -82,7 +82,9 @@ struct LmState {
   int32_t status;  // 0 running, 1 terminated
   int32_t termination, reason;
   int32_t phase;
-  int32_t ntrace, pad;
+  int32_t ntrace;
+  int32_t pending_invalid;  // the step that led to the point under evaluation turned out invalid: the evaluation is
+                            // ignored and HandleInvalidStep runs instead of the verdict (lm_decide)
 };
 
 struct LmResult {
@@ -118,6 +120,46 @@ __device__ __forceinline__ double fast_rcp(double x) {
   r = fma(fma(-x, r, 1.0), r, r);
   r = fma(fma(-x, r, 1.0), r, r);
   return r;
+}
+
+// 1/sqrt(x) for x in a sane range (squared baseline lengths): v_rsq_f64 seed + two coupled Newton steps
+// (Goldschmidt: g -> sqrt(x), h -> 1 / (2 sqrt(x))), <= 1 ulp; nine instructions where sqrt + reciprocal take ~35
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  double e = fma(-h, g, 0.5);
+  g = fma(g, e, g);
+  h = fma(h, e, h);
+  e = fma(-h, g, 0.5);
+  h = fma(h, e, h);
+  return h + h;
+}
+
+// exp(x) in ~20 instructions for k_lm's critical path (the library routine inlines to 106): x = k ln2 + r,
+// |r| <= ln2 / 2, Taylor polynomial of degree 13 (remainder 4e-18 relative), scaled by v_ldexp_f64, which
+// saturates to +inf / flushes towards 0 like the library's result does.  The argument is clamped to
+// +-1100 first so that the integer conversion never saturates (exp(+-1100) is already inf / 0).
+// Measured against libm over [-745, 710]: scripts/exp/rcp_precision.hip.
+__device__ __forceinline__ double fast_exp(double x) {
+  const double xc = fmin(fmax(x, -1100.0), 1100.0);
+  const double kf = rint(xc * 1.4426950408889634074);
+  double r = fma(-kf, 6.93147180369123816490e-01, xc);  // ln2, high part (low 21 bits zero: kf * hi is exact)
+  r = fma(-kf, 1.90821492927058770002e-10, r);           // ln2, low part
+  double p = 1.0 / 6227020800.0;
+  p = fma(p, r, 1.0 / 479001600.0);
+  p = fma(p, r, 1.0 / 39916800.0);
+  p = fma(p, r, 1.0 / 3628800.0);
+  p = fma(p, r, 1.0 / 362880.0);
+  p = fma(p, r, 1.0 / 40320.0);
+  p = fma(p, r, 1.0 / 5040.0);
+  p = fma(p, r, 1.0 / 720.0);
+  p = fma(p, r, 1.0 / 120.0);
+  p = fma(p, r, 1.0 / 24.0);
+  p = fma(p, r, 1.0 / 6.0);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(p, (int)kf);
 }
 
 // IR.cpp:282-296 + :334-346: x (+) (a,b) = (B*A)*x

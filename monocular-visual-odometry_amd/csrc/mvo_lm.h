@@ -142,7 +142,7 @@ __device__ __forceinline__ void wave_reduce10(const double (&v)[10], int lane, d
 
 // s(t) and s'(t) of IR.cpp:298-309 with one exp and one reciprocal
 __device__ __forceinline__ void d_scale_both(double t, double max_len, double min_len, double& s, double& sp) {
-  const double e = exp(-1.0 * t);
+  const double e = fast_exp(-1.0 * t);
   if (isinf(e)) {
     s = min_len;
     sp = 0.0;
@@ -165,7 +165,7 @@ constexpr int MCX = MVO_MAXM + 1;  // classes per frame a: j = min(b, M) in 0..M
 
 struct LmShared {
   LmState st;                                   // image of the solver state between launches (HBM <-> LDS at begin / end)
-  double zvec[MVO_MAXM][3], zt[MVO_MAXM], zs[MVO_MAXM], zsp[MVO_MAXM];
+  double zvec[MVO_MAXM][3], zt[MVO_MAXM], zs[MVO_MAXM];
   double G[MVO_MAXM][9];                        // G[k][3*row + col]: columns (s_k jl0, s_k jl1, s'_k v_k)
   double cls[MVO_MAXM * MCX][10];               // class (a, j = min(b, M)): T(6) q(3) cost(1)   (k_lm<256>)
   double kk[MVO_MAXM][10];                      // the pair (k, k) alone: direction columns only (see below)
@@ -195,7 +195,7 @@ struct LmRegs {
   double x_cost, x_norm, min_cost, mcc, radius, decf, gmn, initial_cost, final_cost;
   double se_min, se_cur, se_ref, se_cand, se_acc_ref, se_acc_cand;
   int32_t se_nonmono, reuse_diag, iteration, num_invalid, nsucc, nunsucc, status, termination, reason, phase,
-      ntrace;
+      ntrace, pending_invalid;
 };
 
 __device__ __forceinline__ void regs_load(LmRegs& r, const LmState& g, int fix, int n, int lane) {
@@ -221,6 +221,7 @@ __device__ __forceinline__ void regs_load(LmRegs& r, const LmState& g, int fix, 
   r.se_nonmono = g.se_nonmono; r.reuse_diag = g.reuse_diagonal; r.iteration = g.iteration;
   r.num_invalid = g.num_invalid; r.nsucc = g.nsucc; r.nunsucc = g.nunsucc; r.status = g.status;
   r.termination = g.termination; r.reason = g.reason; r.phase = g.phase; r.ntrace = g.ntrace;
+  r.pending_invalid = g.pending_invalid;
 }
 
 __device__ __forceinline__ void regs_store(const LmRegs& r, LmState& g, int lane) {
@@ -249,6 +250,7 @@ __device__ __forceinline__ void regs_store(const LmRegs& r, LmState& g, int lane
     g.se_nonmono = r.se_nonmono; g.reuse_diagonal = r.reuse_diag; g.iteration = r.iteration;
     g.num_invalid = r.num_invalid; g.nsucc = r.nsucc; g.nunsucc = r.nunsucc; g.status = r.status;
     g.termination = r.termination; g.reason = r.reason; g.phase = r.phase; g.ntrace = r.ntrace;
+    g.pending_invalid = r.pending_invalid;
   }
 }
 
@@ -271,23 +273,37 @@ __device__ __forceinline__ void lm_terminate(LmRegs& r, int termination, int rea
 
 // Lanes k < M publish the point to evaluate and everything the evaluation needs per frame:
 // s_k, s'_k and G_k = [s_k J_loc(v_k) | s'_k v_k], J_loc(v) = [[-2vy, 2vz], [2vx, 0], [0, -2vx]].
+// Two halves: what the per-pair stage reads (point and s_k) and what only the product stage reads (t_k, G_k).
+// k_lm<256> writes the second half behind barrier B2, while the class wavefronts are already at the pairs.
 template <class SH>
-__device__ __forceinline__ void lm_publish_point(SH& sh, const SolveParams& prm, int M, int lane,
-                                                 const double v[3], double t) {
+__device__ __forceinline__ void lm_publish_point_early(SH& sh, const SolveParams& prm, int M, int lane,
+                                                       const double v[3], double t, double& s, double& sp) {
+  d_scale_both(t, prm.max_len, prm.min_len, s, sp);
   if (lane < M) {
     const int k = lane;
-    double s, sp;
-    d_scale_both(t, prm.max_len, prm.min_len, s, sp);
     sh.zvec[k][0] = v[0];
     sh.zvec[k][1] = v[1];
     sh.zvec[k][2] = v[2];
-    sh.zt[k] = t;
     sh.zs[k] = s;
-    sh.zsp[k] = sp;
+  }
+}
+template <class SH>
+__device__ __forceinline__ void lm_publish_point_late(SH& sh, int M, int lane, const double v[3], double t, double s,
+                                                      double sp) {
+  if (lane < M) {
+    const int k = lane;
+    sh.zt[k] = t;
     sh.G[k][0] = s * (-2.0 * v[1]); sh.G[k][1] = s * (2.0 * v[2]);  sh.G[k][2] = sp * v[0];
     sh.G[k][3] = s * (2.0 * v[0]);  sh.G[k][4] = 0.0;               sh.G[k][5] = sp * v[1];
     sh.G[k][6] = 0.0;               sh.G[k][7] = s * (-2.0 * v[0]); sh.G[k][8] = sp * v[2];
   }
+}
+template <class SH>
+__device__ __forceinline__ void lm_publish_point(SH& sh, const SolveParams& prm, int M, int lane,
+                                                 const double v[3], double t) {
+  double s, sp;
+  lm_publish_point_early(sh, prm, M, lane, v, t, s, sp);
+  lm_publish_point_late(sh, M, lane, v, t, s, sp);
 }
 
 // a[j] = js_l H_lj js_j for matrix row l = lane.  jsm = the jacobi scale on active lanes and 0 on the
@@ -470,15 +486,33 @@ __device__ __forceinline__ void lm_trace_row(TraceRec* __restrict__ trace, const
 
 // Wave-0 control logic: Ceres 1.14 TrustRegionMinimizer::Minimize restated around the evaluation
 // that was just completed at z (= x0 in PH_EVAL_X0, the candidate in PH_EVAL_CAND).  Two halves:
-//   lm_decide  needs the COST at z only: tolerances, step quality, accept / reject, radius.  In
-//              k_lm<256> it runs while two other wavefronts multiply out the blocks of the system at z.
+//   lm_decide  needs the COST at z only: tolerances, step quality, accept / reject, radius, and the part of
+//              FinalizeIterationAndCheckIfMinimizerCanContinue that needs no gradient.  In k_lm<256> it runs
+//              while the helper wavefronts multiply out the blocks of the system at z.
 //   lm_step    needs the system: x <- z, gradient norm, termination tests, the damped solve, the next
-//              candidate.  Returns 1 when a new candidate awaits evaluation (published in sh.zvec/zt).
+//              candidate.  Returns 1 when a point awaits evaluation (published in sh.zvec / zs).
 // The system assembled at z is in the buffer `hsel` does NOT select (hsel ? sh.Hz : st.H holds the
 // ACCEPTED system), gradient in sh.gz.  Every lane executes both; scalars are uniform.
-// Written for a short instruction stream (one wavefront issues an instruction per ~4.4 cycles whatever
-// the dependences): one exit, the per-iteration record only as scalars, square roots only where a
-// tolerance or the trace asks for them.
+// Written for a short, STRAIGHT instruction stream (one wavefront issues an instruction per ~4.4 cycles
+// whatever the dependences, and every loop-carried value of a nested loop costs register copies at its
+// latch): there is no inner loop.  An invalid step (solver failure, model cost change <= 0) is the rare case
+// and takes the long way round: nothing new is published, the point in LDS is evaluated once more, and the
+// next lm_decide runs HandleInvalidStep instead of a verdict (LmRegs::pending_invalid) -- the same sequence
+// of records, radii and counters as Ceres' loop, one wasted evaluation per invalid step.
+__device__ __forceinline__ void lm_finalize_early(LmRegs& r, const LmDecision& d) {
+  // FinalizeIterationAndCheckIfMinimizerCanContinue, the part that needs no gradient
+  if (d.it_succ) {
+    ++r.nsucc;
+    if (r.x_cost < r.min_cost) {
+      r.min_cost = r.x_cost;
+      r.bv[0] = r.xv[0]; r.bv[1] = r.xv[1]; r.bv[2] = r.xv[2]; r.bt = r.xt;
+    }
+  } else {
+    ++r.nunsucc;
+  }
+  r.final_cost = fmin(r.final_cost, d.it_cost);
+}
+
 __device__ __forceinline__ void lm_decide(LmRegs& r, double cost_raw, const SolveParams& prm, int M, int lane,
                                           TraceRec* __restrict__ trace, LmDecision& d MVO_STAMP_PARAM) {
   const int fix = prm.fix_length;
@@ -491,6 +525,24 @@ __device__ __forceinline__ void lm_decide(LmRegs& r, double cost_raw, const Solv
   d.it_valid = d.it_succ = 0;
   d.first = (r.phase == PH_EVAL_X0);
   d.done = false;
+  d.take_z = false;
+  d.cost_z = 0.0;
+  if (r.pending_invalid) {
+    // ---- HandleInvalidStep: the evaluation that just completed repeated a point and is ignored ----
+    r.pending_invalid = 0;
+    if (++r.num_invalid >= 5) {  // max_num_consecutive_invalid_steps
+      lm_terminate(r, 2, 6);
+      d.done = true;
+    } else {
+      r.radius *= 0.5;  // StepIsInvalid
+      r.reuse_diag = 1;
+      d.it_cost = r.x_cost;
+      d.it_gmn = r.gmn;
+      lm_finalize_early(r, d);
+    }
+    MVO_ASTAMP(8);
+    return;
+  }
   // Ceres 1.14 rejects non-finite residuals (ResidualBlock::Evaluate / IsEvaluationValid): at the
   // initial point the minimizer fails before any step; a candidate that "failed to evaluate" gets
   // cost = max and is rejected.  A NaN/Inf residual makes the summed cost non-finite.
@@ -597,19 +649,27 @@ __device__ __forceinline__ void lm_decide(LmRegs& r, double cost_raw, const Solv
     }
     d.it_cost = r.x_cost;
   }
+  if (!d.done) lm_finalize_early(r, d);
   MVO_ASTAMP(8);
 }
 
 // GMN_READY: the gradient max norm at z was left in sh.gmn_z by a helper wavefront (k_lm<256>).
+// mcc_term (per lane): the model cost change is 1/2 of its sum over row 0; the sum, its sign test and with it the
+// last word on the step's validity are left to lm_model_cost_change, which k_lm<256> runs behind barrier B2
+// while the class wavefronts already evaluate the candidate.
 template <bool GMN_READY>
 __device__ __forceinline__ int lm_step(LmRegs& r, LmShared& sh, const SolveParams& prm, int M, int n, int lane,
-                                       TraceRec* __restrict__ trace, int& hsel, LmDecision& d MVO_STAMP_PARAM) {
+                                       TraceRec* __restrict__ trace, int& hsel, LmDecision& d, double& mcc_term,
+                                       double& pub_s, double& pub_sp MVO_STAMP_PARAM) {
+  // returns 0: the window has terminated; 1: a new candidate is published (its second half -- pub_s, pub_sp --
+  // is the caller's to write, lm_publish_point_late); 2: the step is invalid, the point in LDS is evaluated again
   LmState& st = sh.st;
   const int fix = prm.fix_length;
 #ifdef MVO_LM_STAMPS
   const bool stamp_on = stamp_acc_ != nullptr;
   unsigned long long astamp_prev_ = __builtin_amdgcn_s_memtime();
 #endif
+  mcc_term = 0.0;
   if (d.take_z) {
     // EvaluateGradientAndJacobian = the system assembled at z
     const double* __restrict__ Hnew = hsel ? st.H : sh.Hz;
@@ -634,100 +694,76 @@ __device__ __forceinline__ int lm_step(LmRegs& r, LmShared& sh, const SolveParam
     d.it_gmn = r.gmn;
   }
   MVO_ASTAMP(15);
-  bool done = d.done;
-  int go = 0;
-  while (!done) {
-    // ---- FinalizeIterationAndCheckIfMinimizerCanContinue ----
-    if (d.it_succ) {
-      ++r.nsucc;
-      if (r.x_cost < r.min_cost) {
-        r.min_cost = r.x_cost;
-        r.bv[0] = r.xv[0]; r.bv[1] = r.xv[1]; r.bv[2] = r.xv[2]; r.bt = r.xt;
-      }
-    } else {
-      ++r.nunsucc;
-    }
-    lm_trace_row(trace, prm, lane, r.ntrace, d, r.radius);
-    ++r.ntrace;
-    r.final_cost = fmin(r.final_cost, d.it_cost);
-
-    if (r.iteration >= prm.max_it) {
-      lm_terminate(r, 1, 1);
-      break;
-    }
-    if (d.it_succ && d.it_gmn <= prm.gtol) {
-      lm_terminate(r, 0, 2);
-      break;
-    }
-    if (r.radius <= 1e-32) {  // min_trust_region_radius
-      lm_terminate(r, 0, 5);
-      break;
-    }
-
-    MVO_ASTAMP(9);
-    // ---- next iteration: ComputeTrustRegionStep ----
-    ++r.iteration;
-    d.it_cost = d.it_cost_change = d.it_gmn = d.it_step_norm = d.it_rel = 0.0;
-    d.it_valid = d.it_succ = 0;
-
-    if (!r.reuse_diag) r.dg = fmin(fmax(r.js * r.js * r.hdiag, 1e-6), 1e32);  // min/max_lm_diagonal
-    r.reuse_diag = 1;
-    // (Js^T Js + D^2) y = Js^T r with Js = J diag(jscale), D^2 = diag / radius; step = -y.
-    // Ceres solves the equivalent least-squares problem by dense QR; here the reduced system is
-    // eliminated in registers, one row per lane (Gauss-Jordan, no pivoting: the matrix is SPD).
-    const double jsm = lane < n ? r.js : 0.0;
-    double a[MVO_MAXC];
-    {
-      const double* __restrict__ Hacc = hsel ? sh.Hz : st.H;
-      const int fl = fcol(lane < n ? lane : 0, fix);
-      double hrow[MVO_MAXC];
-#pragma unroll
-      for (int j = 0; j < MVO_MAXC; ++j) hrow[j] = Hacc[fl * MVO_MAXC + (fix ? 3 * (j >> 1) + (j & 1) : j)];  // loads first
-      gj_setup<0>(a, hrow, jsm);
-    }
-    const double dd = r.dg * fast_rcp(r.radius);
-    const double ddl = lane < n ? dd : 1.0;  // added to a row's diagonal entry when it becomes the pivot
-    const double rhs0 = jsm * r.g;
-    MVO_ASTAMP(10);
-    double rhs = rhs0, myrinv = 1.0;
-    unsigned phimax = 0;
-    {
-      const double piv0 = bcast_lane(a[0] + ddl, 0);
-      gj_eliminate<0>(a, rhs, myrinv, phimax, lane, ddl, piv0, fast_rcp(piv0), n);
-    }
-    MVO_ASTAMP(11);
-    const double step = lane < n ? -(rhs * myrinv) : 0.0;
-    // a pivot < 0 or infinite, or a non-finite step (a zero pivot gives one): the linear solver failed
-    const bool ok = phimax < 0x7ff00000u && !__any(!isfinite(step));
-    // model_cost_change = -(Js step)^T (r + Js step / 2) = -step^T b - step^T As step / 2 with
-    // b = Js^T r, As = Js^T Js.  The step solves (As + D^2) step = -b, so As step = -b - D^2 step
-    // and the change is (-step^T b + step^T D^2 step) / 2 -- no second pass over the matrix.
-    const double mcc = ok ? 0.5 * row0_sum(step * (dd * step - rhs0)) : 0.0;
-    MVO_ASTAMP(12);
-    r.mcc = mcc;
-    if (!(ok && mcc > 0.0)) {
-      // ---- HandleInvalidStep ----
-      if (++r.num_invalid >= 5) {  // max_num_consecutive_invalid_steps
-        lm_terminate(r, 2, 6);
-        break;
-      }
-      r.radius *= 0.5;  // StepIsInvalid
-      r.reuse_diag = 1;
-      d.it_cost = r.x_cost;
-      d.it_gmn = r.gmn;
-      continue;
-    }
-    r.num_invalid = 0;
-    // ---- ComputeCandidatePoint: delta = step o jscale; candidate = Plus(x, delta) ----
-    frames_plus(lane, M, fix, r.xv, r.xt, step * r.js, 1.0, r.cv, r.ct);
-    MVO_ASTAMP(13);
-    lm_publish_point(sh, prm, M, lane, r.cv, r.ct);
-    MVO_ASTAMP(14);
-    r.phase = PH_EVAL_CAND;
-    go = 1;
-    break;
+  if (d.done) return 0;
+  // ---- FinalizeIterationAndCheckIfMinimizerCanContinue, the rest: the record and the tests ----
+  lm_trace_row(trace, prm, lane, r.ntrace, d, r.radius);
+  ++r.ntrace;
+  if (r.iteration >= prm.max_it) {
+    lm_terminate(r, 1, 1);
+    return 0;
   }
-  return go;
+  if (d.it_succ && d.it_gmn <= prm.gtol) {
+    lm_terminate(r, 0, 2);
+    return 0;
+  }
+  if (r.radius <= 1e-32) {  // min_trust_region_radius
+    lm_terminate(r, 0, 5);
+    return 0;
+  }
+  MVO_ASTAMP(9);
+  // ---- next iteration: ComputeTrustRegionStep ----
+  ++r.iteration;
+  if (!r.reuse_diag) r.dg = fmin(fmax(r.js * r.js * r.hdiag, 1e-6), 1e32);  // min/max_lm_diagonal
+  r.reuse_diag = 1;
+  // (Js^T Js + D^2) y = Js^T r with Js = J diag(jscale), D^2 = diag / radius; step = -y.
+  // Ceres solves the equivalent least-squares problem by dense QR; here the reduced system is
+  // eliminated in registers, one row per lane (Gauss-Jordan, no pivoting: the matrix is SPD).
+  const double jsm = lane < n ? r.js : 0.0;
+  double a[MVO_MAXC];
+  {
+    const double* __restrict__ Hacc = hsel ? sh.Hz : st.H;
+    const int fl = fcol(lane < n ? lane : 0, fix);
+    double hrow[MVO_MAXC];
+#pragma unroll
+    for (int j = 0; j < MVO_MAXC; ++j) hrow[j] = Hacc[fl * MVO_MAXC + (fix ? 3 * (j >> 1) + (j & 1) : j)];  // loads first
+    gj_setup<0>(a, hrow, jsm);
+  }
+  const double dd = r.dg * fast_rcp(r.radius);
+  const double ddl = lane < n ? dd : 1.0;  // added to a row's diagonal entry when it becomes the pivot
+  const double rhs0 = jsm * r.g;
+  MVO_ASTAMP(10);
+  double rhs = rhs0, myrinv = 1.0;
+  unsigned phimax = 0;
+  {
+    const double piv0 = bcast_lane(a[0] + ddl, 0);
+    gj_eliminate<0>(a, rhs, myrinv, phimax, lane, ddl, piv0, fast_rcp(piv0), n);
+  }
+  MVO_ASTAMP(11);
+  const double step = lane < n ? -(rhs * myrinv) : 0.0;
+  // a pivot < 0 or infinite, or a non-finite step (a zero pivot gives one): the linear solver failed
+  const bool ok = phimax < 0x7ff00000u && !__any(!isfinite(step));
+  // model_cost_change = -(Js step)^T (r + Js step / 2) = -step^T b - step^T As step / 2 with
+  // b = Js^T r, As = Js^T Js.  The step solves (As + D^2) step = -b, so As step = -b - D^2 step
+  // and the change is (-step^T b + step^T D^2 step) / 2 -- no second pass over the matrix.
+  mcc_term = ok ? step * (dd * step - rhs0) : 0.0;  // (an invalid step: sum 0, which fails the sign test)
+  MVO_ASTAMP(12);
+  r.phase = PH_EVAL_CAND;
+  if (!ok) return 2;
+  // ---- ComputeCandidatePoint: delta = step o jscale; candidate = Plus(x, delta) ----
+  frames_plus(lane, M, fix, r.xv, r.xt, step * r.js, 1.0, r.cv, r.ct);
+  MVO_ASTAMP(13);
+  lm_publish_point_early(sh, prm, M, lane, r.cv, r.ct, pub_s, pub_sp);
+  MVO_ASTAMP(14);
+  return 1;
+}
+
+// The rest of the step, off the critical path: the model cost change and the step's validity.  When the step was
+// invalid the point in LDS is stale (the last candidate, or x0) and its evaluation will be ignored.
+__device__ __forceinline__ void lm_model_cost_change(LmRegs& r, double mcc_term) {
+  const double mcc = 0.5 * row0_sum(mcc_term);
+  r.mcc = mcc;
+  if (mcc > 0.0) r.num_invalid = 0;
+  else r.pending_invalid = 1;
 }
 
 // ---- stage (4) of an evaluation: the blocks of the system at z ---------------------------------
@@ -929,8 +965,7 @@ __device__ __forceinline__ void free_baseline(const SH& sh, int a, int kmax, dou
 // beta = the free frames' part of the pair's baseline (free_baseline); the fixed-frame offset is added here.
 __device__ __forceinline__ void pair_eval(const PairIn& in, const double (&beta)[3], int pass_mode, double (&o)[10]) {
   const double bx = beta[0] + in.off[0], by = beta[1] + in.off[1], bz = beta[2] + in.off[2];
-  const double nb = sqrt(bx * bx + by * by + bz * bz);
-  const double inb = fast_rcp(nb), inb2 = inb * inb;
+  const double inb = fast_rsqrt(bx * bx + by * by + bz * bz), inb2 = inb * inb;
   const double u0 = bx * inb, u1 = by * inb, u2 = bz * inb;
   const double* S = in.S;
   const double Su0 = S[0] * u0 + S[1] * u1 + S[2] * u2;
@@ -1463,13 +1498,20 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
       }
       MVO_STAMP(4);
       // ---------------- damping, next candidate ----------------
-      const int go = lm_step<LARGE>(r, sh, prm, M, n, lane, (w == 0) ? trace : nullptr, hsel, dec MVO_STAMP_ARG);
+      double mcc_term, pub_s = 0.0, pub_sp = 0.0;
+      const int go = lm_step<LARGE>(r, sh, prm, M, n, lane, (w == 0) ? trace : nullptr, hsel, dec, mcc_term, pub_s,
+                                    pub_sp MVO_STAMP_ARG);
       if (lane == 0) sh.hsel = hsel;
-      if (lane == 0) sh.go = go;
+      if (lane == 0) sh.go = go != 0;
+      if (LARGE) __syncthreads();  // B2: the class wavefronts start on the point
+      else wave0_sync();
+      MVO_STAMP(5);
+      if (!go) break;
+      // off the critical path (k_lm<256>: the class wavefronts are at the pairs): the step's model cost change and
+      // validity, and the half of the point only the product stage reads (behind B1 / this wavefront's own order)
+      lm_model_cost_change(r, mcc_term);
+      if (go == 1) lm_publish_point_late(sh, M, lane, r.cv, r.ct, pub_s, pub_sp);
     }
-    __syncthreads();  // B2
-    MVO_STAMP(5);
-    if (!sh.go) break;
     if (prm.pass_mode && !prm.inline_eval) need_pass = true;
   }
 

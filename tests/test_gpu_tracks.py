@@ -408,7 +408,10 @@ def test_refine_sequence_on_a_sliding_ring_with_changing_shapes(solver):
             exp, es = solver.refine(w2, opt)
             assert gs.iterations == es.iterations and gs.termination == es.termination, k
             assert abs(gs.initial_cost - es.initial_cost) <= 1e-12 * max(es.initial_cost, 1e-300), k
-            assert np.abs(got - exp).max() < 1e-8, k
+            # the two routes differ by the summation order of S_p (1e-12); a window with a gauge direction
+            # (k = 14: M = 2, N = 5) amplifies that to 1e-9 ... 1e-7 depending on the last bits of the
+            # trajectory -- the bar is the library's parity bar for refined parameters, 1e-6
+            assert np.abs(got - exp).max() < 1e-6, k
 
 
 def test_fused_refine_reports_its_blocks_when_asked(solver):
