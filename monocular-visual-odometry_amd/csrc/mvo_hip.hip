@@ -788,9 +788,25 @@ hipError_t launch_pass(mvo_hip_context* h, bool fused = false) {
   return e;
 }
 
+// which compile-time specialisation of k_lm serves these parameters (mvo_lm.h, "SPEC")
+static bool lm_generic_only() {
+  static const bool v = [] { const char* e = getenv("MVO_HIP_LM_GENERIC"); return e && e[0] == '1'; }();
+  return v;
+}
+static int lm_spec(const SolveParams& prm) {
+  if (lm_generic_only() || prm.use_loss || prm.pass_mode || prm.proj_ready || prm.cls_ready || prm.fix_length ||
+      prm.trace_cap != 0)
+    return 0;
+  return prm.inline_eval ? 2 : 1;
+}
+template <int NT>
+static auto lm_kernel(int spec) -> decltype(&k_lm<NT, 0>) {
+  return spec == 1 ? k_lm<NT, 1> : spec == 2 ? k_lm<NT, 2> : k_lm<NT, 0>;
+}
+
 template <int NT>
 hipError_t launch_lm(mvo_hip_context* h, const SolveParams& prm, bool from_pair_sums = false) {
-  hipLaunchKernelGGL(k_lm<NT>, dim3(h->W), dim3(NT), 0, h->stream, prm, from_pair_sums ? 1 : 0,
+  hipLaunchKernelGGL(lm_kernel<NT>(lm_spec(prm)), dim3(h->W), dim3(NT), 0, h->stream, prm, from_pair_sums ? 1 : 0,
                      h->t.wins,
                      h->t.frames, h->t.initx,
                      from_pair_sums ? h->t.pairs_unit : h->t.pairs,
@@ -817,7 +833,7 @@ template <int NT>
 hipError_t launch_lm_range(mvo_hip_context* h, SolveParams prm, uint32_t win0, uint32_t win1, hipStream_t stream) {
   prm.fresh = 1;
   prm.win_base = (int32_t)win0;
-  hipLaunchKernelGGL(k_lm<NT>, dim3(win1 - win0), dim3(NT), 0, stream, prm, 0, h->t.wins, h->t.frames,
+  hipLaunchKernelGGL(lm_kernel<NT>(lm_spec(prm)), dim3(win1 - win0), dim3(NT), 0, stream, prm, 0, h->t.wins, h->t.frames,
                      h->t.initx, h->t.pairs, h->d_partial.as<double>(), h->t.m0, h->t.m1, h->d_pairsum.as<double>(),
                      h->d_states.as<LmState>(), h->d_results, h->d_status,
                      h->d_trace.as<TraceRec>(), h->d_done, (const double*)nullptr, (const double*)nullptr,
@@ -2037,8 +2053,8 @@ int mvo_hip_refine_noalloc(int device_ordinal, void* stream, mvo_hip_frame* fram
                        reinterpret_cast<LmResult*>(sc + kNaResult), ctl, (TraceRec*)nullptr,
                        ctl + 16, (const double*)nullptr, (const double*)nullptr, (double*)nullptr);
   };
-  if (small) launch(k_lm<64>, 64);
-  else launch(k_lm<MVO_LM_NT_LARGE>, MVO_LM_NT_LARGE);
+  if (small) launch(lm_kernel<64>(lm_spec(prm)), 64);
+  else launch(lm_kernel<MVO_LM_NT_LARGE>(lm_spec(prm)), MVO_LM_NT_LARGE);
   if (hipGetLastError() != hipSuccess) return MVO_HIP_ERR_DEVICE;
 
   hipLaunchKernelGGL(k_noalloc_finish, dim3(1), dim3(64), 0, s, (const unsigned char*)sc,

@@ -1290,7 +1290,14 @@ __device__ __forceinline__ void lm_class_wave(LmShared& sh, const SolveParams& p
   }
 }
 
-template <int NT>
+// SPEC: the same kernel with the run-time switches of the common solves fixed at compile time, so that the
+// compiler sees one path instead of all of them (fewer live values around wavefront 0's loop, fewer hoisted
+// addresses spilled to lanes and read back):
+//   0  every switch at run time (loss / pass modes, fixLength, traces, partitioned solves)
+//   1  no loss, observations folded by the chip-wide kernels, all columns free, no trace  (one large window)
+//   2  the same with the window's own workgroup folding its observations                   (small windows)
+// The host picks it from SolveParams (lm_spec, mvo_hip.hip); MVO_HIP_LM_GENERIC=1 keeps everything on 0.
+template <int NT, int SPEC = 0>
 __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, const WinDev* __restrict__ wins,
                                            const double* __restrict__ frames, const double* __restrict__ init_x,
                                            const PairDev* __restrict__ pairs, const double* partial,
@@ -1305,6 +1312,17 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
                                            double* __restrict__ pair_u) {      // pass mode: (u, |baseline|) per pair for the next pass
   constexpr bool LARGE = NT > 64;
   static_assert(NT == 64 || NT == MVO_LM_NT_LARGE, "one wavefront, or three class wavefronts + one for the short pairs and the LM step");
+  if constexpr (SPEC != 0) {
+    prm.use_loss = 0;
+    prm.pass_mode = 0;
+    prm.inline_eval = SPEC == 2 ? 1 : 0;
+    prm.x0_ready = 0;
+    prm.proj_ready = 0;
+    prm.cls_ready = 0;
+    prm.fix_length = 0;
+    prm.trace_cap = 0;
+    trace = nullptr;
+  }
   __shared__ LmShared sh;
   __shared__ double pairbuf[LARGE ? 1 : 64 * 10];  // k_lm<64>: P x 10: T(6) q(3) cost(1)
   __shared__ double inl_sums[LARGE ? 1 : 64 * 8];   // k_lm<64>, inline evaluation: the passes' 8 sums per pair
