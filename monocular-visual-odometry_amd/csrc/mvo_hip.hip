@@ -797,11 +797,13 @@ static int lm_spec(const SolveParams& prm) {
   if (lm_generic_only() || prm.use_loss || prm.pass_mode || prm.proj_ready || prm.cls_ready || prm.fix_length ||
       prm.trace_cap != 0)
     return 0;
-  return prm.inline_eval ? 2 : 1;
+  const int base = prm.inline_eval ? 2 : 1;
+  return (prm.N - 1 - prm.M <= 32) ? base + 2 : base;
 }
 template <int NT>
 static auto lm_kernel(int spec) -> decltype(&k_lm<NT, 0>) {
-  return spec == 1 ? k_lm<NT, 1> : spec == 2 ? k_lm<NT, 2> : k_lm<NT, 0>;
+  if (NT == 64 && spec >= 3) spec -= 2;  // one wavefront: no class wavefronts to specialise
+  return spec == 1 ? k_lm<NT, 1> : spec == 2 ? k_lm<NT, 2> : spec == 3 ? k_lm<NT, 3> : spec == 4 ? k_lm<NT, 4> : k_lm<NT, 0>;
 }
 
 template <int NT>

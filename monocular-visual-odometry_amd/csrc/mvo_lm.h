@@ -179,6 +179,12 @@ struct LmShared {
   double Hz[MVO_MAXC * MVO_MAXC], gz[MVO_MAXC]; // second system buffer (st.H is the first) and the gradient at z
   double gmn_z;                                 // k_lm<256>: gradient max norm at z (helper wavefront)
   int32_t go, phase, hsel, pad_;
+  // k_lm<256> with the step split off (LmSolver below): verdict -> solver before barrier B1c, step -> control before B2
+  double ctl_radius;
+  int32_t ctl_take, ctl_done, ctl_first, ctl_reuse;
+  double mcc_term[MVO_MAXC + 1];                // per row: the model cost change is half their sum
+  double zsp[MVO_MAXM];                         // s'(t_k) of the published point (the control wavefront forms G from it)
+  int32_t step_ok, pad2_;
 };
 
 static_assert(offsetof(LmShared, kk) == offsetof(LmShared, cls) + sizeof(double) * MVO_MAXM * MCX * 10,
@@ -1099,6 +1105,19 @@ __device__ __forceinline__ void half_reduce10(const double (&v)[10], int lane, d
   x4 += dpp_mov_f64<0x141>(x4);
 }
 
+// k_lm<256>: a pair (a, j < M) is a class of its own; the pair (k, k) is kept a second time (see lm_block_rows)
+__device__ __forceinline__ void lm_store_short_pair(LmShared& sh, bool on, int a, int j, const double (&o)[10]) {
+  if (on) {
+    double* __restrict__ dst = sh.cls[a * MCX + j];
+#pragma unroll
+    for (int v = 0; v < 10; ++v) dst[v] = o[v];
+    if (a == j) {
+#pragma unroll
+      for (int v = 0; v < 10; ++v) sh.kk[a][v] = o[v];
+    }
+  }
+}
+
 // k_lm<256>, helper wavefront cw (0..2) between barriers B1 and B1c: its own copy of the prefix / suffix
 // tables, then its share of the system at z -- the diagonal blocks, the gradient and its norm, the other blocks.
 __device__ __forceinline__ void lm_helper_products(LmShared& sh, const BlockRole& br, int cw, int M, int N, int fix,
@@ -1110,6 +1129,114 @@ __device__ __forceinline__ void lm_helper_products(LmShared& sh, const BlockRole
   else lm_block_rows<2>(tb, br, lane, sh.hsel ? sh.st.H : sh.Hz);
 }
 
+// ---- k_lm<256, SPEC != 0>: the numeric half of the LM step on a wavefront of its own -------------------------
+// Wavefront 0 keeps Ceres' control logic (verdict, step evaluator, tolerances, counters, the best point, the
+// records); class wavefront 2 -- idle between barriers B1c and B2 like the other two -- keeps the numbers of the
+// step: gradient, jacobi scaling, LM diagonal, the accepted point and the candidate, one matrix row per lane.
+// Between B1c and B2 it takes the system over if the verdict says so, eliminates, forms the candidate and publishes
+// it, while wavefront 0 finishes the iteration's bookkeeping (gradient tolerance, record, counters) beside it.
+// What wavefront 0's instruction stream carried around the elimination before -- some forty scalars of state held
+// in vector registers, their copies at every join of the control flow, spills to the accumulation registers -- is
+// off this path: 5.5 k -> 3.x k cycles from B1c to B2 at config 2.  The step is computed before the control
+// wavefront knows whether the minimiser goes on (speculation: when it terminates, the candidate is dropped).
+// Hand-over through LDS: verdict (take z / first / done / reuse the diagonal / radius) before B1c; per-row terms of
+// the model cost change, solver success and the candidate (zvec, zt, zs, zsp) before B2.
+struct LmSolver {
+  double g, js, dg, hdiag;     // lane l < n: column l
+  double xv[3], xt, cv[3], ct;  // lane k < M: accepted point / candidate of frame k
+  int hsel;
+};
+
+__device__ __forceinline__ void lm_solver_init(LmSolver& q, const LmShared& sh, int lane) {
+  const int k = lane < MVO_MAXM ? lane : 0;
+  q.g = q.js = q.dg = q.hdiag = 0.0;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) q.xv[j] = q.cv[j] = sh.st.x_vec[k][j];
+  q.xt = q.ct = sh.st.x_t[k];
+  q.hsel = 0;
+}
+
+__device__ __forceinline__ void lm_solver_step(LmSolver& q, LmShared& sh, const SolveParams& prm, int M, int n,
+                                               int lane) {
+  if (sh.ctl_done) return;  // (uniform) the window has terminated: wavefront 0 clears sh.go
+  const int take = sh.ctl_take, first = sh.ctl_first, reuse = sh.ctl_reuse;
+  const double radius = sh.ctl_radius;
+  const int fix = prm.fix_length;
+  LmState& st = sh.st;
+  if (take) {
+    // x <- z; EvaluateGradientAndJacobian = the system assembled at z
+    const double* __restrict__ Hnew = q.hsel ? st.H : sh.Hz;
+    const int fl = fcol(lane < n ? lane : 0, fix);
+    q.hsel ^= 1;
+    q.g = lane < n ? sh.gz[fl] : 0.0;
+    q.hdiag = lane < n ? Hnew[fl * MVO_MAXC + fl] : 0.0;
+    q.xv[0] = q.cv[0]; q.xv[1] = q.cv[1]; q.xv[2] = q.cv[2]; q.xt = q.ct;
+    if (first) q.js = 1.0 / (1.0 + sqrt(fmax(q.hdiag, 0.0)));  // jacobi_scaling (see lm_step)
+  }
+  if (!reuse) q.dg = fmin(fmax(q.js * q.js * q.hdiag, 1e-6), 1e32);  // min/max_lm_diagonal
+  const double jsm = lane < n ? q.js : 0.0;
+  double a[MVO_MAXC];
+  {
+    const double* __restrict__ Hacc = q.hsel ? sh.Hz : st.H;
+    const int fl = fcol(lane < n ? lane : 0, fix);
+    double hrow[MVO_MAXC];
+#pragma unroll
+    for (int j = 0; j < MVO_MAXC; ++j) hrow[j] = Hacc[fl * MVO_MAXC + (fix ? 3 * (j >> 1) + (j & 1) : j)];
+    gj_setup<0>(a, hrow, jsm);
+  }
+  const double dd = q.dg * fast_rcp(radius);
+  const double ddl = lane < n ? dd : 1.0;
+  const double rhs0 = jsm * q.g;
+  double rhs = rhs0, myrinv = 1.0;
+  unsigned phimax = 0;
+  {
+    const double piv0 = bcast_lane(a[0] + ddl, 0);
+    gj_eliminate<0>(a, rhs, myrinv, phimax, lane, ddl, piv0, fast_rcp(piv0), n);
+  }
+  const double step = lane < n ? -(rhs * myrinv) : 0.0;
+  const bool ok = phimax < 0x7ff00000u && !__any(!isfinite(step));
+  if (lane <= MVO_MAXC) sh.mcc_term[lane] = ok ? step * (dd * step - rhs0) : 0.0;  // (see lm_step)
+  if (lane == 0) sh.step_ok = ok ? 1 : 0;
+  if (!ok) return;
+  frames_plus(lane, M, fix, q.xv, q.xt, step * q.js, 1.0, q.cv, q.ct);
+  double s_, sp_;
+  lm_publish_point_early(sh, prm, M, lane, q.cv, q.ct, s_, sp_);
+  if (lane < M) {
+    sh.zt[lane] = q.ct;
+    sh.zsp[lane] = sp_;
+  }
+}
+
+// ... and what is left for wavefront 0 between B1c and B2: the rest of FinalizeIterationAndCheckIfMinimizerCanContinue.
+// Returns 1 when the minimiser goes on (the solver wavefront's step counts), 0 when the window has terminated.
+__device__ __forceinline__ int lm_control_finish(LmRegs& r, LmShared& sh, const SolveParams& prm, int lane,
+                                                 TraceRec* __restrict__ trace, int& hsel, LmDecision& d) {
+  if (d.take_z) {
+    hsel ^= 1;
+    r.gmn = sh.gmn_z;
+    d.it_gmn = r.gmn;
+  }
+  if (d.done) return 0;
+  lm_trace_row(trace, prm, lane, r.ntrace, d, r.radius);
+  ++r.ntrace;
+  if (r.iteration >= prm.max_it) {
+    lm_terminate(r, 1, 1);
+    return 0;
+  }
+  if (d.it_succ && d.it_gmn <= prm.gtol) {
+    lm_terminate(r, 0, 2);
+    return 0;
+  }
+  if (r.radius <= 1e-32) {  // min_trust_region_radius
+    lm_terminate(r, 0, 5);
+    return 0;
+  }
+  ++r.iteration;
+  r.reuse_diag = 1;
+  r.phase = PH_EVAL_CAND;
+  return 1;
+}
+
 // k_lm<256>, wavefronts 1..3: the loop of a class wavefront.  Two layouts, chosen per window:
 //   N - 1 - M <= 32 (HALF): wavefront w evaluates the pairs (a, b), a = 2 (w - 1) + (lane >> 5),
 //                   b = M + (lane & 31): one pair per lane, one evaluation, one reduction per half;
@@ -1118,7 +1245,7 @@ __device__ __forceinline__ void lm_helper_products(LmShared& sh, const BlockRole
 // (lm_decide), wavefronts 1 and 3 multiply out the diagonal / the other blocks of the system and
 // wavefront 2 the gradient and its norm.  A class wavefront executes exactly the workgroup barriers wavefront 0 executes (marked
 // B0 / B1 / B1c / B2 on both sides).
-template <int NT>
+template <int NT, bool SPLIT, bool HALF_ONLY, bool SHORT_HERE>
 __device__ __forceinline__ void lm_class_wave(LmShared& sh, const SolveParams& prm, int cw, int lane, int M, int N, int P,
                                               bool& need_pass, int unit_slots, const PairDev* __restrict__ wp,
                                               const double* partial, uint32_t pair_off, const double* __restrict__ fr,
@@ -1185,7 +1312,7 @@ __device__ __forceinline__ void lm_class_wave(LmShared& sh, const SolveParams& p
   constexpr int ROUNDS = 4;  // class (a, M) has at most MVO_HIP_MAX_FRAMES - 1 - M <= 256 pairs
   constexpr int NA = 2;      // frames per class wavefront: cw and cw + 3
   const int n_pairs_a = N - 1 > M ? N - 1 - M : 0;
-  const bool half = n_pairs_a <= 32;           // wave-uniform
+  const bool half = HALF_ONLY || n_pairs_a <= 32;  // wave-uniform (HALF_ONLY: the host checked, lm_spec)
   const int n_rounds = (n_pairs_a + 63) >> 6;  // wave-uniform
   const bool two = cw + 3 < M;                 // wave-uniform: a second frame to serve
   int my_p[NA][ROUNDS];
@@ -1203,9 +1330,22 @@ __device__ __forceinline__ void lm_class_wave(LmShared& sh, const SolveParams& p
     my_ok[0][0] = a_h < M && b_h <= N - 2;
     my_p[0][0] = my_ok[0][0] ? pair_index(N, a_h, b_h) : 0;
   }
+  // SHORT_HERE (HALF layout only): the <= 15 pairs (a, b < M), each a class of its own, ride along in the upper
+  // half of class wavefront 2, whose frame there (a = 5) never exists -- wavefront 0 has nothing to evaluate and
+  // spends the time behind barrier B2 on the rest of its bookkeeping.
+  const bool short_wave = SHORT_HERE && cw == 2;  // wave-uniform
+  const int nshort = (M * (M + 1)) / 2;
+  const bool is_short = short_wave && lane >= 32 && lane - 32 < nshort;
+  int s_a = 0, s_j = 0;
+  upper_block(M, is_short ? lane - 32 : 0, s_a, s_j);  // (a, b) with a <= b < M, row-major
+  if (is_short) my_p[0][0] = pair_index(N, s_a, s_j);  // (my_ok stays false: not part of the half's class total)
   const BlockRole br = block_role(M, lane);
   PairIn in[NA][ROUNDS];
   bool have_in = false;
+  LmSolver slv;
+  const bool solver_wave = SPLIT && cw == 2;  // wave-uniform
+  const int n_cols = prm.fix_length ? 2 * M : 3 * M;
+  if (solver_wave) lm_solver_init(slv, sh, lane);
   while (!need_pass) {
     if (prm.inline_eval && prm.pass_mode) {
       if (prm.use_loss) inline_pass<2, NT>(sh, wp, P, M, fr, m0, m1, my_sums);
@@ -1228,8 +1368,9 @@ __device__ __forceinline__ void lm_class_wave(LmShared& sh, const SolveParams& p
     }
     if (half) {
       double beta[3], o[10];
-      free_baseline(sh, a_h < M ? a_h : 0, M - 1, beta);
+      free_baseline(sh, is_short ? s_a : (a_h < M ? a_h : 0), is_short ? s_j : M - 1, beta);
       pair_eval(in[0][0], beta, prm.pass_mode, o);
+      if (short_wave) lm_store_short_pair(sh, is_short, s_a, s_j, o);
 #pragma unroll
       for (int v = 0; v < 10; ++v) o[v] = my_ok[0][0] ? o[v] : 0.0;
       double y, x4;
@@ -1284,7 +1425,8 @@ __device__ __forceinline__ void lm_class_wave(LmShared& sh, const SolveParams& p
     __syncthreads();  // B1: class totals are in LDS
     lm_helper_products(sh, br, cw, M, N, prm.fix_length, lane);
     __syncthreads();  // B1c: the system at z is in LDS
-    __syncthreads();  // B2: wavefront 0 has taken its step and published the next point
+    if (solver_wave) lm_solver_step(slv, sh, prm, M, n_cols, lane);
+    __syncthreads();  // B2: the step is taken and the next point published
     if (!sh.go) break;
     if (prm.pass_mode && !prm.inline_eval) need_pass = true;
   }
@@ -1296,6 +1438,8 @@ __device__ __forceinline__ void lm_class_wave(LmShared& sh, const SolveParams& p
 //   0  every switch at run time (loss / pass modes, fixLength, traces, partitioned solves)
 //   1  no loss, observations folded by the chip-wide kernels, all columns free, no trace  (one large window)
 //   2  the same with the window's own workgroup folding its observations                   (small windows)
+//   3, 4  = 1, 2 for windows with at most 32 pairs (a, b >= M) per refined frame (N - 1 - M <= 32): k_lm<256> hands
+//      the numeric half of the LM step to a class wavefront (LmSolver); k_lm<64> is the same kernel as 1, 2
 // The host picks it from SolveParams (lm_spec, mvo_hip.hip); MVO_HIP_LM_GENERIC=1 keeps everything on 0.
 template <int NT, int SPEC = 0>
 __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, const WinDev* __restrict__ wins,
@@ -1315,7 +1459,7 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
   if constexpr (SPEC != 0) {
     prm.use_loss = 0;
     prm.pass_mode = 0;
-    prm.inline_eval = SPEC == 2 ? 1 : 0;
+    prm.inline_eval = (SPEC == 2 || SPEC == 4) ? 1 : 0;
     prm.x0_ready = 0;
     prm.proj_ready = 0;
     prm.cls_ready = 0;
@@ -1421,7 +1565,10 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
   // k_lm<64>:  lane p evaluates pair p.
   // k_lm<256>: wavefronts 1..3 take the pairs (a, b >= M) (lm_class_wave); wavefront 0's lane i the
   //            i-th pair with b < M (a = 0: b = 0..M-1, a = 1: b = 1..M-1, ...), then the LM step.
-  if (LARGE && !wave0) lm_class_wave<NT>(sh, prm, wv - 1, lane, M, N, P, need_pass, unit_slots, wp, partial, win.pair_off, fr, m0, m1, my_sums, proj);
+  // SPEC 3 / 4: at most 32 pairs (a, b >= M) per frame -- the class wavefronts hold one pair per lane (HALF layout)
+  // and class wavefront 2 has the registers to take the numeric half of the step (LmSolver)
+  constexpr bool SPLIT = LARGE && SPEC >= 3;
+  if (LARGE && !wave0) lm_class_wave<NT, SPLIT, SPLIT, SPLIT>(sh, prm, wv - 1, lane, M, N, P, need_pass, unit_slots, wp, partial, win.pair_off, fr, m0, m1, my_sums, proj);
   int my_p0 = lane < P ? lane : 0;
   bool my_ok0 = lane < P;
   int my_a = 0, my_j = 0;  // k_lm<256>: the short pair's (a, b)
@@ -1463,6 +1610,8 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
           dst[2 * (lane + 64 * q)] = t[q].x;
           dst[2 * (lane + 64 * q) + 1] = t[q].y;
         }
+    } else if (SPLIT) {
+      // class wavefront 2 evaluates the short pairs as well (lm_class_wave, SHORT_HERE): nothing for this wavefront
     } else {
       double o[10], beta[3];
       int pa, pb;
@@ -1503,6 +1652,13 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
       if (LARGE) {
         const double cost_raw = lm_cost_total(sh.cls, M, lane);
         lm_decide(r, cost_raw, prm, M, lane, (w == 0) ? trace : nullptr, dec MVO_STAMP_ARG);
+        if (SPLIT && lane == 0) {  // the verdict, for the solver wavefront
+          sh.ctl_radius = r.radius;
+          sh.ctl_take = dec.take_z ? 1 : 0;
+          sh.ctl_done = dec.done ? 1 : 0;
+          sh.ctl_first = dec.first ? 1 : 0;
+          sh.ctl_reuse = r.reuse_diag;
+        }
         __syncthreads();  // B1c: the system at z and its gradient norm are complete
       } else {
         LmTables tb = lm_tables(sh, 0);
@@ -1516,9 +1672,11 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
       }
       MVO_STAMP(4);
       // ---------------- damping, next candidate ----------------
-      double mcc_term, pub_s = 0.0, pub_sp = 0.0;
-      const int go = lm_step<LARGE>(r, sh, prm, M, n, lane, (w == 0) ? trace : nullptr, hsel, dec, mcc_term, pub_s,
-                                    pub_sp MVO_STAMP_ARG);
+      double mcc_term = 0.0, pub_s = 0.0, pub_sp = 0.0;
+      int go;
+      if (SPLIT) go = lm_control_finish(r, sh, prm, lane, (w == 0) ? trace : nullptr, hsel, dec);
+      else go = lm_step<LARGE>(r, sh, prm, M, n, lane, (w == 0) ? trace : nullptr, hsel, dec, mcc_term, pub_s,
+                               pub_sp MVO_STAMP_ARG);
       if (lane == 0) sh.hsel = hsel;
       if (lane == 0) sh.go = go != 0;
       if (LARGE) __syncthreads();  // B2: the class wavefronts start on the point
@@ -1527,9 +1685,21 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
       if (!go) break;
       // off the critical path (k_lm<256>: the class wavefronts are at the pairs): the step's model cost change and
       // validity, and the half of the point only the product stage reads (behind B1 / this wavefront's own order)
+      if (SPLIT) {
+        mcc_term = lane < n ? sh.mcc_term[lane] : 0.0;
+        go = sh.step_ok ? 1 : 2;
+        if (go == 1) {  // the candidate the solver wavefront published
+          const int k = lane < M ? lane : 0;
+          r.cv[0] = sh.zvec[k][0]; r.cv[1] = sh.zvec[k][1]; r.cv[2] = sh.zvec[k][2];
+          r.ct = sh.zt[k];
+          pub_s = sh.zs[k];
+          pub_sp = sh.zsp[k];
+        }
+      }
       lm_model_cost_change(r, mcc_term);
       if (go == 1) lm_publish_point_late(sh, M, lane, r.cv, r.ct, pub_s, pub_sp);
     }
+    MVO_STAMP(2);
     if (prm.pass_mode && !prm.inline_eval) need_pass = true;
   }
 

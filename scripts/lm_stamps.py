@@ -7,7 +7,7 @@ from mvo_amd import capi, scene
 capi.LIB_PATH = os.path.join(ROOT, "monocular-visual-odometry_amd", "libmvo_hip_stamps.so")
 lib = capi.load()
 lib.mvo_hip_debug_stamps.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
-names = ["iterations", "per-pair", "class sums", "W/y", "blocks", "lm_advance", "prologue", "epilogue", "adv:decide", "adv:finalize", "adv:setup", "adv:eliminate", "adv:mcc", "adv:plus", "adv:publish", "adv:take_z"]
+names = ["iterations", "per-pair", "w0 behind B2", "W/y", "blocks", "lm_advance", "prologue", "epilogue", "adv:decide", "adv:finalize", "adv:setup", "adv:eliminate", "adv:mcc", "adv:plus", "adv:publish", "adv:take_z"]
 fixed = dict(max_num_iterations=10, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
 for label, ws in (("defaults N=3 M=2", [scene.reference_defaults_window()]), ("config1", [scene.config1()]),
                   ("config2", [scene.config2()]), ("config4", [scene.config4()]), ("config1 x 64", [scene.config3_window(i) for i in range(64)])):
@@ -19,7 +19,7 @@ for label, ws in (("defaults N=3 M=2", [scene.reference_defaults_window()]), ("c
         s.solve()
         lib.mvo_hip_debug_stamps(buf, 0)
         n = max(1, buf[0])
-        print(label, "evaluations", buf[0], " cycles/eval:", {names[i]: buf[i] // n for i in range(1, 6)}, "total", sum(buf[1:6]) // n)
+        print(label, "evaluations", buf[0], " cycles/eval:", {names[i]: buf[i] // n for i in range(1, 6)}, "total", sum(buf[1:6]) // n, " per LAUNCH: prologue", buf[6], "epilogue", buf[7])
         print("    inside lm_advance:", {names[i]: buf[i] // n for i in range(8, 16)})
 
 # the robust path: one evaluation per k_lm launch -- prologue / epilogue cycles per LAUNCH beside the evaluation's
