@@ -340,11 +340,11 @@ __device__ __forceinline__ void gj_row_update(double (&a)[MVO_MAXC], double f) {
 // remaining columns, whose independent updates then fill that latency.
 // n (wave-uniform): the active rows; the steps from n on would run on identity padding (the reference's
 // shipped window refines two frames: 6 of 15) and are skipped by one scalar branch.
-template <int J>
+template <int J, bool FULL = false>
 __device__ __forceinline__ void gj_eliminate(double (&a)[MVO_MAXC], double& rhs, double& myrinv, unsigned& phimax,
                                              int lane, double ddl, double piv, double rinv, int n) {
   if constexpr (J < MVO_MAXC) {
-    if (J >= n) return;
+    if (!FULL && J >= n) return;  // FULL: the caller checked n == MVO_MAXC (five refined frames, all columns free)
     // largest high word of the pivots, as unsigned: a negative pivot (sign bit), an infinite one or a NaN
     // (exponent 0x7ff) all end up >= 0x7ff00000 -- one scalar max per step
     const unsigned hi = (unsigned)__double2hiint(piv);
@@ -364,7 +364,7 @@ __device__ __forceinline__ void gj_eliminate(double (&a)[MVO_MAXC], double& rhs,
       gj_row_update<J, J + 2>(a, f);
     }
     rhs -= f * row_bcast<J>(rhs);
-    gj_eliminate<J + 1>(a, rhs, myrinv, phimax, lane, ddl, piv_next, rinv_next, n);
+    gj_eliminate<J + 1, FULL>(a, rhs, myrinv, phimax, lane, ddl, piv_next, rinv_next, n);
   }
 }
 
@@ -955,15 +955,16 @@ __device__ __forceinline__ void free_baseline(const SH& sh, int a, int kmax, dou
     zv[k][1] = sh.zvec[k][1];
     zv[k][2] = sh.zvec[k][2];
   }
-  beta[0] = beta[1] = beta[2] = 0.0;
+  // frames outside a .. kmax take part with s = 0: their terms are exact zeros, added in front of or behind the
+  // sum without changing a bit of it (one select per frame instead of two per frame and component)
 #pragma unroll
-  for (int k = 0; k < MVO_MAXM; ++k) {
-    const bool first = k == a, on = k > a && k <= kmax;
+  for (int k = 0; k < MVO_MAXM; ++k) zs[k] = (k >= a && k <= kmax) ? zs[k] : 0.0;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const double t = zs[k] * zv[k][j];
-      beta[j] = first ? t : (on ? beta[j] + t : beta[j]);
-    }
+  for (int j = 0; j < 3; ++j) {
+    double acc = zs[0] * zv[0][j];
+#pragma unroll
+    for (int k = 1; k < MVO_MAXM; ++k) acc += zs[k] * zv[k][j];
+    beta[j] = acc;
   }
 }
 
@@ -1191,7 +1192,8 @@ __device__ __forceinline__ void lm_solver_step(LmSolver& q, LmShared& sh, const 
   unsigned phimax = 0;
   {
     const double piv0 = bcast_lane(a[0] + ddl, 0);
-    gj_eliminate<0>(a, rhs, myrinv, phimax, lane, ddl, piv0, fast_rcp(piv0), n);
+    if (n == MVO_MAXC) gj_eliminate<0, true>(a, rhs, myrinv, phimax, lane, ddl, piv0, fast_rcp(piv0), n);
+    else gj_eliminate<0>(a, rhs, myrinv, phimax, lane, ddl, piv0, fast_rcp(piv0), n);
   }
   const double step = lane < n ? -(rhs * myrinv) : 0.0;
   const bool ok = phimax < 0x7ff00000u && !__any(!isfinite(step));
@@ -1508,6 +1510,11 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
   // are identity rows) -- so the second buffer starts from zero like the first.
   for (int i = tid; i < MVO_MAXC * MVO_MAXC; i += NT) sh.Hz[i] = 0.0;
   if (tid == 0) sh.hsel = 0;
+  // frames k >= M are never published; free_baseline multiplies them by s = 0, so they must hold numbers
+  if (tid < MVO_MAXM) {
+    sh.zs[tid] = 0.0;
+    sh.zvec[tid][0] = sh.zvec[tid][1] = sh.zvec[tid][2] = 0.0;
+  }
   if (prm.pass_mode && !prm.inline_eval)  // (uniform) this launch ends by publishing every pair's unit baseline
     for (int b = tid; b < N && b < FOFF_FRAMES; b += NT) {
       const double* __restrict__ f = fr + MVO_FRAME_DOUBLES * b;

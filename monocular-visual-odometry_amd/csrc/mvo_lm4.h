@@ -457,6 +457,14 @@ __global__ __launch_bounds__(64) void k_lm4(SolveParams prm, int win_end, int un
     (&sh.win[q].H[0][0])[e] = 0.0;
   }
   if (lane < LM4_WINDOWS) sh.win[lane].cost = 0.0;
+  // frames k >= M are never published; free_baseline multiplies them by s = 0, so they must hold numbers
+  if (lane < LM4_WINDOWS * MVO_MAXM) {
+    Lm4Win& wz = sh.win[lane / MVO_MAXM];
+    const int k = lane % MVO_MAXM;
+    wz.zs[k] = 0.0;
+    wz.zvec[k][0] = wz.zvec[k][1] = wz.zvec[k][2] = 0.0;
+  }
+  wave0_sync();
   if (row_exists && l == 0) win_status[w_row] = 0;
 
   Lm4Regs r;
