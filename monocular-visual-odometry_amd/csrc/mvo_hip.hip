@@ -794,16 +794,17 @@ static bool lm_generic_only() {
   return v;
 }
 static int lm_spec(const SolveParams& prm) {
-  if (lm_generic_only() || prm.use_loss || prm.pass_mode || prm.proj_ready || prm.cls_ready || prm.fix_length ||
-      prm.trace_cap != 0)
-    return 0;
+  if (lm_generic_only() || prm.cls_ready || prm.fix_length || prm.trace_cap != 0) return 0;
+  if (prm.pass_mode && !prm.inline_eval && prm.proj_ready && prm.x0_ready) return 5;
+  if (prm.use_loss || prm.pass_mode || prm.proj_ready) return 0;
   const int base = prm.inline_eval ? 2 : 1;
   return (prm.N - 1 - prm.M <= 32) ? base + 2 : base;
 }
 template <int NT>
 static auto lm_kernel(int spec) -> decltype(&k_lm<NT, 0>) {
-  if (NT == 64 && spec >= 3) spec -= 2;  // one wavefront: no class wavefronts to specialise
-  return spec == 1 ? k_lm<NT, 1> : spec == 2 ? k_lm<NT, 2> : spec == 3 ? k_lm<NT, 3> : spec == 4 ? k_lm<NT, 4> : k_lm<NT, 0>;
+  if (NT == 64 && (spec == 3 || spec == 4)) spec -= 2;  // one wavefront: no class wavefronts to specialise
+  return spec == 1 ? k_lm<NT, 1> : spec == 2 ? k_lm<NT, 2> : spec == 3 ? k_lm<NT, 3> : spec == 4 ? k_lm<NT, 4> :
+         spec == 5 ? k_lm<NT, 5> : k_lm<NT, 0>;
 }
 
 template <int NT>

@@ -1442,6 +1442,8 @@ __device__ __forceinline__ void lm_class_wave(LmShared& sh, const SolveParams& p
 //   2  the same with the window's own workgroup folding its observations                   (small windows)
 //   3, 4  = 1, 2 for windows with at most 32 pairs (a, b >= M) per refined frame (N - 1 - M <= 32): k_lm<256> hands
 //      the numeric half of the LM step to a class wavefront (LmSolver); k_lm<64> is the same kernel as 1, 2
+//   5  the robust path's relaunch: one evaluation per launch from the pairs the pass's tails projected (pass_mode,
+//      x0_ready, proj_ready; with or without the loss), all columns free, no trace
 // The host picks it from SolveParams (lm_spec, mvo_hip.hip); MVO_HIP_LM_GENERIC=1 keeps everything on 0.
 template <int NT, int SPEC = 0>
 __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, const WinDev* __restrict__ wins,
@@ -1459,15 +1461,22 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
   constexpr bool LARGE = NT > 64;
   static_assert(NT == 64 || NT == MVO_LM_NT_LARGE, "one wavefront, or three class wavefronts + one for the short pairs and the LM step");
   if constexpr (SPEC != 0) {
-    prm.use_loss = 0;
-    prm.pass_mode = 0;
-    prm.inline_eval = (SPEC == 2 || SPEC == 4) ? 1 : 0;
-    prm.x0_ready = 0;
-    prm.proj_ready = 0;
     prm.cls_ready = 0;
     prm.fix_length = 0;
     prm.trace_cap = 0;
     trace = nullptr;
+    if constexpr (SPEC == 5) {
+      prm.pass_mode = 1;
+      prm.inline_eval = 0;
+      prm.x0_ready = 1;
+      prm.proj_ready = 1;
+    } else {
+      prm.use_loss = 0;
+      prm.pass_mode = 0;
+      prm.inline_eval = (SPEC == 2 || SPEC == 4) ? 1 : 0;
+      prm.x0_ready = 0;
+      prm.proj_ready = 0;
+    }
   }
   __shared__ LmShared sh;
   __shared__ double pairbuf[LARGE ? 1 : 64 * 10];  // k_lm<64>: P x 10: T(6) q(3) cost(1)
@@ -1574,7 +1583,7 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
   //            i-th pair with b < M (a = 0: b = 0..M-1, a = 1: b = 1..M-1, ...), then the LM step.
   // SPEC 3 / 4: at most 32 pairs (a, b >= M) per frame -- the class wavefronts hold one pair per lane (HALF layout)
   // and class wavefront 2 has the registers to take the numeric half of the step (LmSolver)
-  constexpr bool SPLIT = LARGE && SPEC >= 3;
+  constexpr bool SPLIT = LARGE && (SPEC == 3 || SPEC == 4);
   if (LARGE && !wave0) lm_class_wave<NT, SPLIT, SPLIT, SPLIT>(sh, prm, wv - 1, lane, M, N, P, need_pass, unit_slots, wp, partial, win.pair_off, fr, m0, m1, my_sums, proj);
   int my_p0 = lane < P ? lane : 0;
   bool my_ok0 = lane < P;
