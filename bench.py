@@ -714,14 +714,17 @@ def main():
     # default (mvo_hip_set_profiling is off unless asked for)
     every = 4
     n_prof = 0
+    prof_on = None
     for i in range(args.steps):
         timed = i % every == 0
-        solver.set_profiling(timed)
+        if timed != prof_on:
+            solver.set_profiling(timed)
+            prof_on = timed
         run_solve()
         frames, summ = solver.download(copy=False)  # refined frames + summaries are on the host
-        tm = solver.timing()
-        host_s += tm["solve_seconds"]
-        if timed:
+        if timed:  # the timing record is read on the event-timed steps only (a ctypes call and a dict per step otherwise)
+            tm = solver.timing()
+            host_s += tm["solve_seconds"]
             n_prof += 1
             asm_s += tm["assembly_seconds"]
             asm_n += tm["assembly_launches"]
@@ -782,7 +785,7 @@ def main():
         "residual_jacobian_obs_per_sec": round(job_blocks * (its_per_step / n_windows) * args.steps / elapsed, 1),
         "windows_per_sec": round(job_windows * args.steps / elapsed, 3),
         "device_ms_per_step": round(dev_s / n_prof * 1e3, 5),
-        "host_solve_ms_per_step": round(host_s / args.steps * 1e3, 5),
+        "host_solve_ms_per_step": round(host_s / n_prof * 1e3, 5),  # mvo_hip_solve on the event-timed steps
         "fold_kernel_us": round(first_s / n_prof * 1e6, 3),
         "steps_with_hip_events": n_prof,
         "upload_seconds_pcie_inclusive": round(upload_s, 6),
