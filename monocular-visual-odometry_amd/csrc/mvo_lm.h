@@ -1765,17 +1765,23 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
     }
   }
   // the solver state leaves the registers: LDS image, then HBM (pass mode re-enters with it)
+  constexpr bool ONE_LAUNCH = SPEC >= 1 && SPEC <= 4;  // the solve ends in this launch: nobody reads the state again
   if (wave0) {
     regs_store(r, sh.st, lane);
     if (lane == 0) sh.phase = hsel;
   }
-  __syncthreads();
-  if (sh.phase) {  // bring the accepted system home before the state leaves LDS
-    for (int i = tid; i < MVO_MAXC * MVO_MAXC; i += NT) sh.st.H[i] = sh.Hz[i];
+  if (ONE_LAUNCH) {
+    if (!wave0) return;
+    wave0_sync();  // wavefront 0 reads back its own image below
+  } else {
     __syncthreads();
+    if (sh.phase) {  // bring the accepted system home before the state leaves LDS
+      for (int i = tid; i < MVO_MAXC * MVO_MAXC; i += NT) sh.st.H[i] = sh.Hz[i];
+      __syncthreads();
+    }
+    for (int i = tid; i < (int)(sizeof(LmState) / 8); i += NT)
+      reinterpret_cast<double*>(gst)[i] = reinterpret_cast<const double*>(&sh.st)[i];
   }
-  for (int i = tid; i < (int)(sizeof(LmState) / 8); i += NT)
-    reinterpret_cast<double*>(gst)[i] = reinterpret_cast<const double*>(&sh.st)[i];
 #ifdef MVO_LM_STAMPS
   if (w == 0 && tid == 0) stamp_lds_[7] += __builtin_amdgcn_s_memtime() - stamp_prev_;  // slot 7: last stamp -> state out
   __syncthreads();
