@@ -188,6 +188,7 @@ struct mvo_hip_context {
   int env_overlap_chunks = 0;  // 0: the default (kOverlapChunks)
   bool env_no_host_results = false, env_no_poll = false;
   bool env_no_tails = false;  // MVO_HIP_NO_TAILS: per-pair sums by k_reduce_slots launches instead of the passes' ticket tails
+  bool env_lm_generic = false;  // MVO_HIP_LM_GENERIC: k_lm<NT, 0> for every solve (no compile-time specialisation)
   // d_ctl = [window status: W int32, padded][done counter: 4 int32][results: W LmResult];
   // the last two are mirrored in pinned host memory by one copy
   int32_t* d_status = nullptr;
@@ -788,13 +789,10 @@ hipError_t launch_pass(mvo_hip_context* h, bool fused = false) {
   return e;
 }
 
-// which compile-time specialisation of k_lm serves these parameters (mvo_lm.h, "SPEC")
-static bool lm_generic_only() {
-  static const bool v = [] { const char* e = getenv("MVO_HIP_LM_GENERIC"); return e && e[0] == '1'; }();
-  return v;
-}
-static int lm_spec(const SolveParams& prm) {
-  if (lm_generic_only() || prm.cls_ready || prm.fix_length || prm.trace_cap != 0) return 0;
+// which compile-time specialisation of k_lm serves these parameters (mvo_lm.h, "SPEC"); generic_only:
+// MVO_HIP_LM_GENERIC at mvo_hip_create (tests compare the specialisations against the generic kernel)
+static int lm_spec(const SolveParams& prm, bool generic_only) {
+  if (generic_only || prm.cls_ready || prm.fix_length || prm.trace_cap != 0) return 0;
   if (prm.pass_mode && !prm.inline_eval && prm.proj_ready && prm.x0_ready) return 5;
   if (prm.use_loss || prm.pass_mode || prm.proj_ready) return 0;
   const int base = prm.inline_eval ? 2 : 1;
@@ -809,7 +807,7 @@ static auto lm_kernel(int spec) -> decltype(&k_lm<NT, 0>) {
 
 template <int NT>
 hipError_t launch_lm(mvo_hip_context* h, const SolveParams& prm, bool from_pair_sums = false) {
-  hipLaunchKernelGGL(lm_kernel<NT>(lm_spec(prm)), dim3(h->W), dim3(NT), 0, h->stream, prm, from_pair_sums ? 1 : 0,
+  hipLaunchKernelGGL(lm_kernel<NT>(lm_spec(prm, h->env_lm_generic)), dim3(h->W), dim3(NT), 0, h->stream, prm, from_pair_sums ? 1 : 0,
                      h->t.wins,
                      h->t.frames, h->t.initx,
                      from_pair_sums ? h->t.pairs_unit : h->t.pairs,
@@ -836,7 +834,7 @@ template <int NT>
 hipError_t launch_lm_range(mvo_hip_context* h, SolveParams prm, uint32_t win0, uint32_t win1, hipStream_t stream) {
   prm.fresh = 1;
   prm.win_base = (int32_t)win0;
-  hipLaunchKernelGGL(lm_kernel<NT>(lm_spec(prm)), dim3(win1 - win0), dim3(NT), 0, stream, prm, 0, h->t.wins, h->t.frames,
+  hipLaunchKernelGGL(lm_kernel<NT>(lm_spec(prm, h->env_lm_generic)), dim3(win1 - win0), dim3(NT), 0, stream, prm, 0, h->t.wins, h->t.frames,
                      h->t.initx, h->t.pairs, h->d_partial.as<double>(), h->t.m0, h->t.m1, h->d_pairsum.as<double>(),
                      h->d_states.as<LmState>(), h->d_results, h->d_status,
                      h->d_trace.as<TraceRec>(), h->d_done, (const double*)nullptr, (const double*)nullptr,
@@ -1390,6 +1388,7 @@ int mvo_hip_create(int device_ordinal, uint32_t max_windows, uint32_t max_frames
   h->env_no_host_results = std::getenv("MVO_HIP_NO_HOST_RESULTS") != nullptr;
   h->env_no_poll = std::getenv("MVO_HIP_NO_POLL") != nullptr;
   h->env_no_tails = std::getenv("MVO_HIP_NO_TAILS") != nullptr;
+  h->env_lm_generic = std::getenv("MVO_HIP_LM_GENERIC") != nullptr;
   if (hipSetDevice(device_ordinal) != hipSuccess ||
       hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
       mvo_noalloc_resolve(device_ordinal) != hipSuccess) {  // the library's set-up call: scratch address, once per device
@@ -2056,8 +2055,8 @@ int mvo_hip_refine_noalloc(int device_ordinal, void* stream, mvo_hip_frame* fram
                        reinterpret_cast<LmResult*>(sc + kNaResult), ctl, (TraceRec*)nullptr,
                        ctl + 16, (const double*)nullptr, (const double*)nullptr, (double*)nullptr);
   };
-  if (small) launch(lm_kernel<64>(lm_spec(prm)), 64);
-  else launch(lm_kernel<MVO_LM_NT_LARGE>(lm_spec(prm)), MVO_LM_NT_LARGE);
+  if (small) launch(lm_kernel<64>(lm_spec(prm, false)), 64);
+  else launch(lm_kernel<MVO_LM_NT_LARGE>(lm_spec(prm, false)), MVO_LM_NT_LARGE);
   if (hipGetLastError() != hipSuccess) return MVO_HIP_ERR_DEVICE;
 
   hipLaunchKernelGGL(k_noalloc_finish, dim3(1), dim3(64), 0, s, (const unsigned char*)sc,
