@@ -157,7 +157,9 @@ struct mvo_hip_context {
   hipError_t last_hip_error = hipSuccess;
   // device buffers
   DevBuf d_arena, d_m0, d_m1, d_c, d_partial, d_pair_u, d_states, d_ctl, d_trace, d_res, d_jac, d_pairsum, d_pticket,
-      d_proj,  // pass mode: T(6) q(3) cost(1) per pair, left by the passes' tails (project_pair8)
+      d_proj,  // pass mode: T(6) q(3) cost(1) per pair, left by the passes' tails (project_pair8); twice: the
+               // persistent robust solver (k_lm<256, 6>) alternates between the two halves
+      d_grid,  // its barrier counter and give-up flag (mvo_grid.h)
       d_cls;   // partitioned pass mode: MVO_CLS_DOUBLES class totals per window (k_class_sums), what the ranks all-reduce
   // The tables of one upload (and the rays of a small one) are staged in ONE pinned block and
   // reach the device in ONE copy into d_arena; these point into it (rays: or into d_m0 / d_m1).
@@ -189,6 +191,11 @@ struct mvo_hip_context {
   bool env_no_host_results = false, env_no_poll = false;
   bool env_no_tails = false;  // MVO_HIP_NO_TAILS: per-pair sums by k_reduce_slots launches instead of the passes' ticket tails
   bool env_lm_generic = false;  // MVO_HIP_LM_GENERIC: k_lm<NT, 0> for every solve (no compile-time specialisation)
+  bool env_no_persistent = false;  // MVO_HIP_NO_PERSISTENT: the robust path launch by launch, never k_lm<256, 6>
+  bool env_persistent_test_fail = false;
+  bool persistent_failed = false;  // a persistent launch ended without a result once: not tried again on this handle
+  bool persistent_in_flight = false;
+  int n_cus = 0;
   // d_ctl = [window status: W int32, padded][done counter: 4 int32][results: W LmResult];
   // the last two are mirrored in pinned host memory by one copy
   int32_t* d_status = nullptr;
@@ -641,9 +648,9 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
     for (const PairDev& pd : pairs) empty_pair |= pd.count == 0;
     if (empty_pair) HIP_TRY(hipMemsetAsync(h->d_pairsum.p, 0, sizeof(double) * 8 * pairs.size(), h->stream));
     if (h->pass_mode) {
-      HIP_TRY(h->d_proj.reserve(sizeof(double) * 10 * pairs.size()));
-      // a pair without residual blocks is never projected: zeros from here on
-      if (empty_pair) HIP_TRY(hipMemsetAsync(h->d_proj.p, 0, sizeof(double) * 10 * pairs.size(), h->stream));
+      HIP_TRY(h->d_proj.reserve(sizeof(double) * 10 * pairs.size() * 2));
+      // a pair without residual blocks is never projected: zeros from here on (both halves)
+      if (empty_pair) HIP_TRY(hipMemsetAsync(h->d_proj.p, 0, sizeof(double) * 10 * pairs.size() * 2, h->stream));
     }
     h->pairsum_foreign = false;
   }
@@ -745,7 +752,7 @@ hipError_t launch_fold(mvo_hip_context* h, bool write_c, bool fused = false) {
   int32_t* ticket = tails ? h->d_pticket.as<int32_t>() : nullptr;
   double* pairsum = h->d_pairsum.as<double>();
   const bool pass0 = write_c && fused;
-  const PassOut po{h->t.pair_u0, pass0 ? h->d_proj.as<double>() : nullptr};
+  const PassOut po{h->t.pair_u0, pass0 ? h->d_proj.as<double>() : nullptr, 0};
 #define MVO_FOLD_ARGS(cbuf, celems) \
   h->t.tiles, h->t.wave_tiles, h->n_waves, h->t.frames, h->t.m0, h->t.m1, cbuf, celems, h->d_partial.as<double>(), \
       ticket, h->t.pairs, pairsum, po
@@ -773,7 +780,7 @@ hipError_t launch_pass(mvo_hip_context* h, bool fused = false) {
   if (!blocks) return hipSuccess;
   const bool tails = fused && !h->env_no_tails;
   int32_t* ticket = tails ? h->d_pticket.as<int32_t>() : nullptr;
-  const PassOut po{h->d_pair_u.as<double>(), fused ? h->d_proj.as<double>() : nullptr};
+  const PassOut po{h->d_pair_u.as<double>(), fused ? h->d_proj.as<double>() : nullptr, 0};
   if (h->opt.use_loss_function)
     hipLaunchKernelGGL((k_pass<true>), dim3(blocks), dim3(FOLD_THREADS), pass_lds(h), h->stream,
                        h->t.tiles, h->t.wave_tiles, h->n_waves, h->d_c.as<double>(),
@@ -815,7 +822,55 @@ hipError_t launch_lm(mvo_hip_context* h, const SolveParams& prm, bool from_pair_
                      h->t.m0, h->t.m1, h->d_pairsum.as<double>(),
                      h->d_states.as<LmState>(), h->results_on_host ? h->h_results : h->d_results,
                      h->d_status, h->d_trace.as<TraceRec>(),
-                     h->d_done, h->d_proj.as<double>(), h->d_cls.as<double>(), h->d_pair_u.as<double>());
+                     h->d_done, h->d_proj.as<double>(), h->d_cls.as<double>(), h->d_pair_u.as<double>(), RobustArgs{});
+  return hipGetLastError();
+}
+
+// ---- the robust path of one window as one persistent launch (k_lm<256, 6>, mvo_lm.h) ----
+// MVO_HIP_NO_PERSISTENT (read at mvo_hip_create) keeps the launch-per-evaluation path; so does a handle on which a
+// persistent launch once ended without a result (persistent_failed).
+bool robust_persistent_ok(const mvo_hip_context* h, const SolveParams& prm) {
+  if (h->env_no_persistent || h->persistent_failed || h->env_lm_generic || h->env_no_tails) return false;
+  if (h->W != 1 || !h->pass_mode || h->inline_eval || prm.fix_length || prm.trace_cap != 0 || prm.cls_ready) return false;
+  const uint32_t blocks = (h->n_waves + FOLD_WAVES - 1) / FOLD_WAVES;
+  return blocks >= 1 && blocks <= (uint32_t)kRobustMaxWorkgroups && h->P <= (uint32_t)kRobustMaxPairs &&
+         h->max_block_tiles <= (uint32_t)kRobustMaxTiles && (int)blocks <= h->n_cus;
+}
+hipError_t launch_lm_persistent(mvo_hip_context* h, SolveParams prm) {
+  const uint32_t blocks = (h->n_waves + FOLD_WAVES - 1) / FOLD_WAVES;
+  hipError_t e = h->d_grid.reserve(256);
+  if (e != hipSuccess) return e;
+  e = hipMemsetAsync(h->d_grid.p, 0, 256, h->stream);
+  if (e != hipSuccess) return e;
+  prm.fresh = 1;
+  prm.win_base = 0;
+  prm.x0_ready = 1;
+  prm.proj_ready = 1;
+  RobustArgs ra;
+  ra.tiles = h->t.tiles;
+  ra.wave_tiles = h->t.wave_tiles;
+  ra.cbuf = h->d_c.as<double>();
+  ra.cstride = (size_t)h->c_elems;
+  ra.partial = h->d_partial.as<double>();
+  ra.pair_ticket = h->d_pticket.as<int32_t>();
+  ra.pairs_slots = h->t.pairs;
+  ra.pair_sums = h->d_pairsum.as<double>();
+  ra.proj[0] = h->d_proj.as<double>();
+  ra.proj[1] = h->d_proj.as<double>() + 10 * (size_t)h->W * h->P;
+  ra.gs.count = h->d_grid.as<uint32_t>();
+  ra.gs.error = h->d_grid.as<uint32_t>() + 32;
+  ra.n_waves = h->n_waves;
+  ra.n_wg = blocks;
+  // test aid (MVO_HIP_PERSISTENT_TEST_FAIL, read at mvo_hip_create): a grid size the kernel refuses -- it returns at
+  // once without a result, which is what the host sees when a wait has given up: the fall-back path under test
+  if (h->env_persistent_test_fail) ra.n_wg = blocks + 1;
+  ra.robust = h->opt.use_loss_function ? 1 : 0;
+  hipLaunchKernelGGL((k_lm<MVO_LM_NT_LARGE, 6>), dim3(blocks), dim3(MVO_LM_NT_LARGE), 0, h->stream, prm, 1, h->t.wins,
+                     h->t.frames, h->t.initx, h->t.pairs_unit, h->d_pairsum.as<double>(), h->t.m0, h->t.m1,
+                     h->d_pairsum.as<double>(), h->d_states.as<LmState>(),
+                     h->results_on_host ? h->h_results : h->d_results, h->d_status, h->d_trace.as<TraceRec>(), h->d_done,
+                     h->d_proj.as<double>(), h->d_cls.as<double>(), h->d_pair_u.as<double>(), ra);
+  h->lm_started = true;
   return hipGetLastError();
 }
 
@@ -838,7 +893,7 @@ hipError_t launch_lm_range(mvo_hip_context* h, SolveParams prm, uint32_t win0, u
                      h->t.initx, h->t.pairs, h->d_partial.as<double>(), h->t.m0, h->t.m1, h->d_pairsum.as<double>(),
                      h->d_states.as<LmState>(), h->d_results, h->d_status,
                      h->d_trace.as<TraceRec>(), h->d_done, (const double*)nullptr, (const double*)nullptr,
-                     (double*)nullptr);
+                     (double*)nullptr, RobustArgs{});
   return hipGetLastError();
 }
 
@@ -883,7 +938,7 @@ hipError_t launch_lm_any(mvo_hip_context* h, SolveParams prm, bool from_pair_sum
 // launch-of-its-own form of the passes' tails (MVO_HIP_NO_TAILS)
 hipError_t launch_reduce_slots(mvo_hip_context* h, const double* upairs) {
   const uint32_t n = h->W * h->P;
-  const PassOut po{upairs, upairs ? h->d_proj.as<double>() : nullptr};
+  const PassOut po{upairs, upairs ? h->d_proj.as<double>() : nullptr, 0};
   hipLaunchKernelGGL(k_reduce_slots, dim3((n * 8 + 255) / 256), dim3(256), 0, h->stream,
                      h->t.pairs, n, h->d_partial.as<double>(), h->d_pairsum.as<double>(), po);
   return hipGetLastError();
@@ -1082,6 +1137,18 @@ int do_solve_partitioned(mvo_hip_context* h) {
   return MVO_HIP_OK;
 }
 
+int do_solve(mvo_hip_context* h);
+// A persistent launch that ended without a result (a wait gave up -- some workgroup of the grid was not resident,
+// e.g. another process holds CUs): the stream is idle here; the handle stops trying and the solve is repeated
+// launch by launch.  do_solve treats the half-counted tickets and status words like those of any abandoned solve.
+static int persistent_fallback(mvo_hip_context* h) {
+  h->persistent_failed = true;
+  h->persistent_in_flight = false;
+  h->done_ready = false;
+  h->tickets_clean = false;
+  return do_solve(h);
+}
+
 int do_solve(mvo_hip_context* h) {
   if (!h->uploaded) return MVO_HIP_ERR_STATE;
   const auto t_begin = std::chrono::steady_clock::now();
@@ -1096,6 +1163,7 @@ int do_solve(mvo_hip_context* h) {
   if (h->trace_cap > 0) HIP_TRY(h->d_trace.reserve(sizeof(TraceRec) * (size_t)h->trace_cap));
 
   h->lm_started = false;
+  h->persistent_in_flight = false;
   // No per-solve fills: the first k_lm launch starts from a zero state of its own and clears its
   // window's status word (SolveParams::fresh); the done counter only ever counts up (done_base).
   if (!h->done_ready) {
@@ -1213,11 +1281,18 @@ int do_solve(mvo_hip_context* h) {
     // is no pass at all: the projections are the zeros the upload left.
     pp.x0_ready = 1;
     pp.proj_ready = 1;
-    HIP_TRY(launch_lm_any(h, pp, true));  // evaluates x0 and takes the first step
+    h->persistent_in_flight = fused && robust_persistent_ok(h, pp);
+    if (h->persistent_in_flight) {
+      // one window whose pass grid fits the chip in one round: the whole solve behind the fold is ONE launch, every
+      // workgroup of the pass grid running the LM step itself (k_lm<256, 6>, mvo_lm.h)
+      HIP_TRY(launch_lm_persistent(h, pp));
+    } else {
+      HIP_TRY(launch_lm_any(h, pp, true));  // evaluates x0 and takes the first step
+    }
     ++lm_launches;
     // enqueue the evaluations in chunks without any host round-trip inside a chunk, and look at the done
     // counter between
-    const int total_evals = h->opt.max_num_iterations;
+    const int total_evals = h->persistent_in_flight ? 0 : h->opt.max_num_iterations;
     const int chunk = 12;
     int issued = 0;
     while (issued < total_evals) {
@@ -1264,14 +1339,20 @@ int do_solve(mvo_hip_context* h) {
     if (!seen) HIP_TRY(hipStreamSynchronize(s));
     h->copy_pending = false;
     for (uint32_t w = 0; w < h->W; ++w)
-      if (h->h_results[w].pad != kResultWritten) return MVO_HIP_ERR_DEVICE;  // every window must have terminated
+      if (h->h_results[w].pad != kResultWritten) {
+        if (h->persistent_in_flight) return persistent_fallback(h);
+        return MVO_HIP_ERR_DEVICE;  // every window must have terminated
+      }
     h->h_done[0] = (int32_t)(done_base + h->W);
   } else {
     // done counter and results are adjacent on both sides: one copy
     HIP_TRY(hipMemcpyAsync(h->h_ctl, h->d_done, 16 + sizeof(LmResult) * h->W, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     h->copy_pending = false;
-    if ((uint32_t)h->h_done[0] - done_base != h->W) return MVO_HIP_ERR_DEVICE;  // every window must have terminated
+    if ((uint32_t)h->h_done[0] - done_base != h->W) {
+      if (h->persistent_in_flight) return persistent_fallback(h);
+      return MVO_HIP_ERR_DEVICE;  // every window must have terminated
+    }
   }
   h->done_base = (uint32_t)h->h_done[0];
   h->done_ready = true;
@@ -1389,6 +1470,12 @@ int mvo_hip_create(int device_ordinal, uint32_t max_windows, uint32_t max_frames
   h->env_no_poll = std::getenv("MVO_HIP_NO_POLL") != nullptr;
   h->env_no_tails = std::getenv("MVO_HIP_NO_TAILS") != nullptr;
   h->env_lm_generic = std::getenv("MVO_HIP_LM_GENERIC") != nullptr;
+  h->env_no_persistent = std::getenv("MVO_HIP_NO_PERSISTENT") != nullptr;
+  h->env_persistent_test_fail = std::getenv("MVO_HIP_PERSISTENT_TEST_FAIL") != nullptr;
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess) h->n_cus = cus;
+  }
   if (hipSetDevice(device_ordinal) != hipSuccess ||
       hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
       mvo_noalloc_resolve(device_ordinal) != hipSuccess) {  // the library's set-up call: scratch address, once per device
@@ -1412,7 +1499,7 @@ void mvo_hip_destroy(mvo_hip_handle h) {
   if (h->comm) (void)mvo_rccl().CommDestroy(h->comm);
   h->comm = nullptr;
   DevBuf* bufs[] = {&h->d_arena, &h->d_m0, &h->d_m1, &h->d_c, &h->d_partial, &h->d_pair_u, &h->d_states,
-                    &h->d_ctl, &h->d_trace, &h->d_res, &h->d_jac, &h->d_pairsum, &h->d_pticket, &h->d_proj, &h->d_cls};
+                    &h->d_ctl, &h->d_trace, &h->d_res, &h->d_jac, &h->d_pairsum, &h->d_pticket, &h->d_proj, &h->d_cls, &h->d_grid};
   for (DevBuf* b : bufs) b->release();
   if (h->h_arena) (void)hipHostFree(h->h_arena);
   if (h->h_ctl) (void)hipHostFree(h->h_ctl);
@@ -2053,7 +2140,7 @@ int mvo_hip_refine_noalloc(int device_ordinal, void* stream, mvo_hip_frame* fram
                        reinterpret_cast<const double*>(sc + kNaInitX), pairs, (const double*)sums, m0_device,
                        m1_device, sums, reinterpret_cast<LmState*>(sc + kNaState),
                        reinterpret_cast<LmResult*>(sc + kNaResult), ctl, (TraceRec*)nullptr,
-                       ctl + 16, (const double*)nullptr, (const double*)nullptr, (double*)nullptr);
+                       ctl + 16, (const double*)nullptr, (const double*)nullptr, (double*)nullptr, RobustArgs{});
   };
   if (small) launch(lm_kernel<64>(lm_spec(prm, false)), 64);
   else launch(lm_kernel<MVO_LM_NT_LARGE>(lm_spec(prm, false)), MVO_LM_NT_LARGE);

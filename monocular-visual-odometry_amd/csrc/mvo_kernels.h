@@ -102,6 +102,8 @@ constexpr int MVO_MCX = MVO_MAXM + 1;  // classes per frame a: j = min(b, M) in 
 struct PassOut {
   const double* upairs;  // [W * P][4]: (u, |baseline|) per pair at the point under evaluation
   double* proj;          // [W * P][10]: T(6) q(3) cost(1) per pair (project_pair8); nullptr: sums only
+  int coherent_proj;     // the projections are read by other workgroups of THIS launch (persistent robust solver,
+                         // k_lm<256, 6>): stored device-coherently, like the slots
 };
 
 // Projected moments of one frame pair from its 8 pass sums, by the 8 consecutive lanes that hold them
@@ -148,8 +150,13 @@ __device__ __forceinline__ void pair_project_store(const PassOut& po, uint32_t p
   const double mine = project_pair8(acc, lane, u, up[3], extra);
   const int v = lane & 7;
   double* __restrict__ out = po.proj + 10 * (size_t)p;
-  out[v] = mine;
-  if (v < 2) out[8 + v] = extra;
+  if (po.coherent_proj) {
+    __hip_atomic_store(out + v, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (v < 2) __hip_atomic_store(out + 8 + v, extra, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    out[v] = mine;
+    if (v < 2) out[8 + v] = extra;
+  }
 }
 
 // The workgroup that stores the LAST slot of a frame pair adds that pair's slots up (what k_reduce_slots
@@ -307,6 +314,54 @@ __global__ __launch_bounds__(FOLD_THREADS) void k_fold(const TileDev* __restrict
 // reads c (24 B / block) as 16-byte loads from three SoA planes.
 // partial[slot] = { S (6, weighted), sum rho(r^2) or sum r^2, sum w r^2 }
 // ---------------------------------------------------------------------------------------
+// the tiles of wavefront gw: one evaluation of their residual blocks at the unit baselines in `upairs`; the tile's
+// 8 sums land in red[(tile - bt0) * 8 + value].  Shared by k_pass and the persistent robust solver (k_lm<256, 6>).
+template <bool ROBUST>
+__device__ __forceinline__ void pass_wave_tiles(const TileDev* __restrict__ tiles, const uint32_t* __restrict__ wave_tiles,
+                                                uint32_t gw, uint32_t n_waves, uint32_t bt0,
+                                                const double* __restrict__ cbuf, size_t cstride,
+                                                const int32_t* __restrict__ win_status,  // nullptr: every window is live
+                                                const double* upairs, double* red, int lane) {
+  if (gw >= n_waves) return;
+  const uint32_t t0 = wave_tiles[gw], t1 = wave_tiles[gw + 1];
+  for (uint32_t t = t0; t < t1; ++t) {
+    const TileDev tl = tiles[t];
+    double S[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (win_status == nullptr || win_status[tl.win] == 0) {
+      const double u0 = upairs[4 * (size_t)tl.pair], u1 = upairs[4 * (size_t)tl.pair + 1],
+                   u2 = upairs[4 * (size_t)tl.pair + 2];
+      // 16-byte loads need an even start: step back one element when the tile starts odd
+      const uint32_t head = tl.c_start & 1u;
+      const double* __restrict__ cx = cbuf + (tl.c_start - head);
+      const double* __restrict__ cy = cx + cstride;
+      const double* __restrict__ cz = cy + cstride;
+      const uint32_t len = tl.count + head;
+      double prod = 1.0;     // running product of (1 + 4 r^2) of this lane
+      int32_t prod_exp = 0;  // exponent split off so far
+      for (uint32_t i0 = 2 * lane; i0 < len; i0 += 128 * 64) {
+        const uint32_t i1 = (len - i0) > 128 * 64 ? i0 + 128 * 64 : len;
+#pragma unroll 2
+        for (uint32_t i = i0; i < i1; i += 128) {
+          const double2 x = *reinterpret_cast<const double2*>(cx + i);
+          const double2 y = *reinterpret_cast<const double2*>(cy + i);
+          const double2 z = *reinterpret_cast<const double2*>(cz + i);
+          const bool v0 = i >= head, v1 = (i + 1) < len;  // neighbours' elements and pads are not data
+          pass_accum<ROBUST>(v0 ? x.x : 0.0, v0 ? y.x : 0.0, v0 ? z.x : 0.0, u0, u1, u2, S, prod);
+          pass_accum<ROBUST>(v1 ? x.y : 0.0, v1 ? y.y : 0.0, v1 ? z.y : 0.0, u0, u1, u2, S, prod);
+        }
+        if (ROBUST) {  // <= 128 factors <= 5 since the last split: far from overflow
+          int e;
+          prod = frexp(prod, &e);
+          prod_exp += e;
+        }
+      }
+      if (ROBUST) S[6] = 0.25 * (log(prod) + (double)prod_exp * 0.693147180559945309417232121458);
+    }
+    const double tot = wave_reduce8(S, lane);
+    if ((lane & 7) == 0) red[(t - bt0) * 8 + reduce8_value_of_lane(lane)] = tot;
+  }
+}
+
 template <bool ROBUST>
 __global__ __launch_bounds__(FOLD_THREADS) void k_pass(const TileDev* __restrict__ tiles,
                                                        const uint32_t* __restrict__ wave_tiles, uint32_t n_waves,
@@ -321,46 +376,7 @@ __global__ __launch_bounds__(FOLD_THREADS) void k_pass(const TileDev* __restrict
   const uint32_t bw0 = blockIdx.x * FOLD_WAVES;
   const uint32_t bw1 = bw0 + FOLD_WAVES < n_waves ? bw0 + FOLD_WAVES : n_waves;
   const uint32_t bt0 = wave_tiles[bw0], bt1 = wave_tiles[bw1];
-  const uint32_t gw = bw0 + wv;
-  if (gw < n_waves) {
-    const uint32_t t0 = wave_tiles[gw], t1 = wave_tiles[gw + 1];
-    for (uint32_t t = t0; t < t1; ++t) {
-      const TileDev tl = tiles[t];
-      double S[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (win_status[tl.win] == 0) {
-        const double u0 = po.upairs[4 * (size_t)tl.pair], u1 = po.upairs[4 * (size_t)tl.pair + 1],
-                     u2 = po.upairs[4 * (size_t)tl.pair + 2];
-        // 16-byte loads need an even start: step back one element when the tile starts odd
-        const uint32_t head = tl.c_start & 1u;
-        const double* __restrict__ cx = cbuf + (tl.c_start - head);
-        const double* __restrict__ cy = cx + cstride;
-        const double* __restrict__ cz = cy + cstride;
-        const uint32_t len = tl.count + head;
-        double prod = 1.0;     // running product of (1 + 4 r^2) of this lane
-        int32_t prod_exp = 0;  // exponent split off so far
-        for (uint32_t i0 = 2 * lane; i0 < len; i0 += 128 * 64) {
-          const uint32_t i1 = (len - i0) > 128 * 64 ? i0 + 128 * 64 : len;
-#pragma unroll 2
-          for (uint32_t i = i0; i < i1; i += 128) {
-            const double2 x = *reinterpret_cast<const double2*>(cx + i);
-            const double2 y = *reinterpret_cast<const double2*>(cy + i);
-            const double2 z = *reinterpret_cast<const double2*>(cz + i);
-            const bool v0 = i >= head, v1 = (i + 1) < len;  // neighbours' elements and pads are not data
-            pass_accum<ROBUST>(v0 ? x.x : 0.0, v0 ? y.x : 0.0, v0 ? z.x : 0.0, u0, u1, u2, S, prod);
-            pass_accum<ROBUST>(v1 ? x.y : 0.0, v1 ? y.y : 0.0, v1 ? z.y : 0.0, u0, u1, u2, S, prod);
-          }
-          if (ROBUST) {  // <= 128 factors <= 5 since the last split: far from overflow
-            int e;
-            prod = frexp(prod, &e);
-            prod_exp += e;
-          }
-        }
-        if (ROBUST) S[6] = 0.25 * (log(prod) + (double)prod_exp * 0.693147180559945309417232121458);
-      }
-      const double tot = wave_reduce8(S, lane);
-      if ((lane & 7) == 0) red[(t - bt0) * 8 + reduce8_value_of_lane(lane)] = tot;
-    }
-  }
+  pass_wave_tiles<ROBUST>(tiles, wave_tiles, bw0 + wv, n_waves, bt0, cbuf, cstride, win_status, po.upairs, red, lane);
   block_store_partials(tiles, bt0, bt1, red, partial, pair_ticket != nullptr);
   block_finish_pairs(pair_ticket, tiles, bt0, bt1, pairs, red, partial, pair_sums, po);
 }

@@ -24,6 +24,7 @@
 
 #include "mvo_device.h"
 #include "mvo_kernels.h"
+#include "mvo_grid.h"
 
 #include <stddef.h>
 
@@ -992,7 +993,15 @@ __device__ __forceinline__ void pair_eval(const PairIn& in, const double (&beta)
 }
 
 // the pair's projected moments as the pass's tail left them (project_pair8): ten doubles, 16-byte loads
+// COHERENT: the projections were stored by other workgroups of THIS launch (persistent robust solver): device-scope loads
+template <bool COHERENT = false>
 __device__ __forceinline__ void proj_load(const double* __restrict__ proj, size_t pair, double (&o)[10]) {
+  if (COHERENT) {
+    const double* q = proj + 10 * pair;
+#pragma unroll
+    for (int j = 0; j < 10; ++j) o[j] = __hip_atomic_load(q + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
   const double2* __restrict__ q = reinterpret_cast<const double2*>(proj + 10 * pair);
 #pragma unroll
   for (int j = 0; j < 5; ++j) {
@@ -1247,12 +1256,12 @@ __device__ __forceinline__ int lm_control_finish(LmRegs& r, LmShared& sh, const 
 // (lm_decide), wavefronts 1 and 3 multiply out the diagonal / the other blocks of the system and
 // wavefront 2 the gradient and its norm.  A class wavefront executes exactly the workgroup barriers wavefront 0 executes (marked
 // B0 / B1 / B1c / B2 on both sides).
-template <int NT, bool SPLIT, bool HALF_ONLY, bool SHORT_HERE>
+template <int NT, bool SPLIT, bool HALF_ONLY, bool SHORT_HERE, bool COHERENT_PROJ = false>
 __device__ __forceinline__ void lm_class_wave(LmShared& sh, const SolveParams& prm, int cw, int lane, int M, int N, int P,
                                               bool& need_pass, int unit_slots, const PairDev* __restrict__ wp,
                                               const double* partial, uint32_t pair_off, const double* __restrict__ fr,
                                               const double* __restrict__ m0, const double* __restrict__ m1,
-                                              double* my_sums, const double* __restrict__ proj) {
+                                              double* my_sums, const double* proj) {
   if (prm.proj_ready) {
     // Pass mode with the passes as launches of their own: this launch is ONE evaluation long and the pass's
     // tails left every pair projected (project_pair8, mvo_kernels.h).  Wavefront cw adds up the long classes
@@ -1261,7 +1270,7 @@ __device__ __forceinline__ void lm_class_wave(LmShared& sh, const SolveParams& p
     constexpr int ROUNDS = 4;
     const int n_pairs_a = N - 1 > M ? N - 1 - M : 0;
     const int n_rounds = (n_pairs_a + 63) >> 6;  // wave-uniform
-    const double* __restrict__ pw = proj + 10 * (size_t)pair_off;
+    const double* pw = proj + 10 * (size_t)pair_off;
     double o[2][ROUNDS][10];
     bool ok[2][ROUNDS];
 #pragma unroll
@@ -1271,7 +1280,7 @@ __device__ __forceinline__ void lm_class_wave(LmShared& sh, const SolveParams& p
         const int a = cw + 3 * q, b = M + lane + 64 * rr;
         ok[q][rr] = a < M && b <= N - 2;
         if (rr < n_rounds && (q == 0 || cw + 3 < M))  // wave-uniform: rounds and frames that exist
-          proj_load(pw, (size_t)(ok[q][rr] ? pair_index(N, a, b) : 0), o[q][rr]);
+          proj_load<COHERENT_PROJ>(pw, (size_t)(ok[q][rr] ? pair_index(N, a, b) : 0), o[q][rr]);
       }
     const BlockRole br = block_role(M, lane);
 #pragma unroll
@@ -1434,6 +1443,40 @@ __device__ __forceinline__ void lm_class_wave(LmShared& sh, const SolveParams& p
   }
 }
 
+// ---- k_lm<256, 6>: the robust path of ONE window as ONE persistent launch -----------------------------------------
+// (IterativeRefinement.cpp:85-88 + :231-233: ceres::Solve with a loss function re-weights every residual at every
+// evaluation.)  The launch-per-evaluation path pays, per evaluation, a pass launch, a k_lm relaunch (state in and out
+// of HBM, ~5 of its ~8 us) and two launch boundaries.  Here the grid of the PASS (one workgroup per four wave-chunks of
+// residual blocks, all resident, at most one per CU) stays for the whole solve, and EVERY workgroup runs the LM step
+// itself -- replicated: the same instruction stream on the same numbers, bit for bit the same verdicts and candidates
+// everywhere -- so that the step has nobody to hand its result to.  Per evaluation:
+//   1. every workgroup: class totals from the pairs' projections (device-scope loads), system, verdict, step, candidate
+//      (the SPEC-5 evaluation, state in registers for the whole solve);
+//   2. every workgroup: unit baselines of ALL pairs at the candidate into its LDS (the epilogue's arithmetic);
+//   3. the pass over the workgroup's own tiles, slots stored device-coherently, per-pair tickets, the workgroup that
+//      completes a pair adds its slots up and projects it (block_finish_pairs) into the OTHER projection buffer;
+//   4. grid_sync (mvo_grid.h) -- the only wait, bounded, with a give-up flag.
+// Two projection buffers alternate, so a workgroup that is one evaluation ahead never writes what another still reads;
+// slots and tickets are rewritten only behind the barrier.  Workgroup 0 writes the result.  If a wait gives up the
+// launch ends without a result, the host sees the error word and repeats the solve launch by launch.
+// Eligible (host, robust_persistent_ok): one window, pass workgroups <= kRobustMaxWorkgroups, pairs <=
+// kRobustMaxPairs, tiles per workgroup <= kRobustMaxTiles, the SPEC-5 conditions (all columns free, no trace).
+constexpr int kRobustMaxWorkgroups = 192, kRobustMaxPairs = 512, kRobustMaxTiles = 64;
+struct RobustArgs {
+  const TileDev* tiles;
+  const uint32_t* wave_tiles;
+  const double* cbuf;
+  size_t cstride;
+  double* partial;
+  int32_t* pair_ticket;
+  const PairDev* pairs_slots;  // the pairs with their slot ranges (k_lm's own `pairs` are the unit rows here)
+  double* pair_sums;
+  double* proj[2];             // [0]: what the fold's tails wrote (evaluation 0)
+  GridSync gs;
+  uint32_t n_waves, n_wg;
+  int32_t robust;              // Cauchy(0.5) / plain (assembly_mode = PASSES)
+};
+
 // SPEC: the same kernel with the run-time switches of the common solves fixed at compile time, so that the
 // compiler sees one path instead of all of them (fewer live values around wavefront 0's loop, fewer hoisted
 // addresses spilled to lanes and read back):
@@ -1444,6 +1487,7 @@ __device__ __forceinline__ void lm_class_wave(LmShared& sh, const SolveParams& p
 //      the numeric half of the LM step to a class wavefront (LmSolver); k_lm<64> is the same kernel as 1, 2
 //   5  the robust path's relaunch: one evaluation per launch from the pairs the pass's tails projected (pass_mode,
 //      x0_ready, proj_ready; with or without the loss), all columns free, no trace
+//   6  = 5 as ONE persistent launch over the pass's grid (RobustArgs above)
 // The host picks it from SolveParams (lm_spec, mvo_hip.hip); MVO_HIP_LM_GENERIC=1 keeps everything on 0.
 template <int NT, int SPEC = 0>
 __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, const WinDev* __restrict__ wins,
@@ -1455,9 +1499,10 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
                                            LmResult* __restrict__ results,
                                            int32_t* __restrict__ win_status,
                                            TraceRec* __restrict__ trace, int32_t* __restrict__ done_count,
-                                           const double* __restrict__ proj,    // prm.proj_ready: 10 doubles per pair
+                                           const double* proj,                 // prm.proj_ready: 10 doubles per pair
                                            const double* __restrict__ cls_in,  // prm.cls_ready: MVO_CLS_DOUBLES per window
-                                           double* __restrict__ pair_u) {      // pass mode: (u, |baseline|) per pair for the next pass
+                                           double* __restrict__ pair_u,        // pass mode: (u, |baseline|) per pair for the next pass
+                                           RobustArgs ra) {                    // SPEC 6 only
   constexpr bool LARGE = NT > 64;
   static_assert(NT == 64 || NT == MVO_LM_NT_LARGE, "one wavefront, or three class wavefronts + one for the short pairs and the LM step");
   if constexpr (SPEC != 0) {
@@ -1465,7 +1510,7 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
     prm.fix_length = 0;
     prm.trace_cap = 0;
     trace = nullptr;
-    if constexpr (SPEC == 5) {
+    if constexpr (SPEC == 5 || SPEC == 6) {
       prm.pass_mode = 1;
       prm.inline_eval = 0;
       prm.x0_ready = 1;
@@ -1485,7 +1530,13 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
   // the epilogue's unit baselines need, requested in the launch's first instructions together with the state
   constexpr int FOFF_FRAMES = LARGE ? MVO_HIP_MAX_FRAMES : 72;  // k_lm<64>: P <= 64, hence N <= 65
   __shared__ double sfoff[3 * FOFF_FRAMES];
-  const int w = (int)blockIdx.x + prm.win_base, tid = threadIdx.x;
+  constexpr bool PERSIST = SPEC == 6;  // every workgroup of the grid solves window 0 (replicated) and passes over its own tiles
+  static_assert(!PERSIST || NT == FOLD_THREADS, "the persistent solver runs the pass with its own workgroup");
+  __shared__ double su[PERSIST ? 4 * kRobustMaxPairs : 1];   // (u, |baseline|) of every pair at the candidate
+  __shared__ double red_buf[PERSIST ? 8 * kRobustMaxTiles : 1];
+  if (PERSIST && (gridDim.x != ra.n_wg || ra.n_wg > (uint32_t)kRobustMaxWorkgroups)) return;  // (host bug guard: nobody waits yet)
+  const int w = PERSIST ? 0 : (int)blockIdx.x + prm.win_base, tid = threadIdx.x;
+  const bool lead_wg = !PERSIST || blockIdx.x == 0;  // writes status words and the result
 #ifdef MVO_LM_STAMPS
   const unsigned long long stamp_entry_ = __builtin_amdgcn_s_memtime();
 #endif
@@ -1494,7 +1545,7 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
   const bool wave0 = wv == 0;
   LmState* __restrict__ gst = states + w;
   const bool fresh = prm.fresh != 0;
-  if (fresh && tid == 0) win_status[w] = 0;  // read by k_pass: set again when this window terminates
+  if (fresh && tid == 0 && lead_wg) win_status[w] = 0;  // read by k_pass: set again when this window terminates
   // every window of an upload has the same shape (SolveParams): no table look-up in front of everything,
   // and the status word comes in with the state image instead of a round trip of its own (a relaunch of
   // the robust path is one evaluation long: -1.4 k of 7 k prologue cycles at config 4r)
@@ -1584,7 +1635,13 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
   // SPEC 3 / 4: at most 32 pairs (a, b >= M) per frame -- the class wavefronts hold one pair per lane (HALF layout)
   // and class wavefront 2 has the registers to take the numeric half of the step (LmSolver)
   constexpr bool SPLIT = LARGE && (SPEC == 3 || SPEC == 4);
-  if (LARGE && !wave0) lm_class_wave<NT, SPLIT, SPLIT, SPLIT>(sh, prm, wv - 1, lane, M, N, P, need_pass, unit_slots, wp, partial, win.pair_off, fr, m0, m1, my_sums, proj);
+  // PERSIST: the evaluations of the whole solve, one per turn of this loop (everything else: one turn)
+  uint32_t grid_epoch = 0;
+  int par = 0;             // which projection buffer holds the evaluation to take in
+  bool grid_fail = false;
+  if (PERSIST) proj = ra.proj[0];
+  for (int turn = 0;; ++turn) {
+  if (LARGE && !wave0) lm_class_wave<NT, SPLIT, SPLIT, SPLIT, PERSIST>(sh, prm, wv - 1, lane, M, N, P, need_pass, unit_slots, wp, partial, win.pair_off, fr, m0, m1, my_sums, proj);
   int my_p0 = lane < P ? lane : 0;
   bool my_ok0 = lane < P;
   int my_a = 0, my_j = 0;  // k_lm<256>: the short pair's (a, b)
@@ -1634,7 +1691,7 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
       if (prm.proj_ready) {
         // pass mode, passes as launches of their own: the pass's tail projected every pair -- nothing to evaluate
         pair_ab(N, M, my_p0, pa, pb);
-        proj_load(proj, (size_t)win.pair_off + my_p0, o);
+        proj_load<PERSIST>(proj, (size_t)win.pair_off + my_p0, o);
       } else {
         if (!have_in) {
           if (!LARGE && prm.inline_eval) pair_load_lds(in0, my_p0, N, M, inl_sums, fr);
@@ -1734,7 +1791,7 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
       sB[tid][2] = beta[2];
     }
     __syncthreads();
-    double* __restrict__ pu = pair_u + 4 * (size_t)win.pair_off;
+    double* pu = PERSIST ? su : pair_u + 4 * (size_t)win.pair_off;  // PERSIST: every workgroup keeps its own copy in LDS
     const int n_long = N - 1 > M ? N - 1 - M : 0;
     for (int q = tid; q < n_long * M; q += NT) {  // long pairs, frame-major: q = a * n_long + (b - M)
       const int a = q / n_long, b = M + (q - a * n_long);
@@ -1742,7 +1799,7 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
       const double bx = sB[a][0] + sfoff[3 * bb], by = sB[a][1] + sfoff[3 * bb + 1], bz = sB[a][2] + sfoff[3 * bb + 2];
       const double nb = sqrt(bx * bx + by * by + bz * bz);
       const double inb = fast_rcp(nb);
-      double* __restrict__ o = pu + 4 * (size_t)pair_index(N, a, b);
+      double* o = pu + 4 * (size_t)pair_index(N, a, b);
       o[0] = bx * inb;
       o[1] = by * inb;
       o[2] = bz * inb;
@@ -1757,13 +1814,39 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
       free_baseline(sh, a, b, beta);
       const double nb = sqrt(beta[0] * beta[0] + beta[1] * beta[1] + beta[2] * beta[2]);
       const double inb = fast_rcp(nb);
-      double* __restrict__ o = pu + 4 * (size_t)pair_index(N, a, b);
+      double* o = pu + 4 * (size_t)pair_index(N, a, b);
       o[0] = beta[0] * inb;
       o[1] = beta[1] * inb;
       o[2] = beta[2] * inb;
       o[3] = nb;
     }
   }
+  if (!PERSIST || !need_pass) break;
+  // ---- PERSIST: the pass at the candidate over this workgroup's tiles, then the grid-wide hand-over ----
+  {
+    __syncthreads();  // su is complete
+    const uint32_t bw0 = blockIdx.x * FOLD_WAVES;
+    const uint32_t bw1 = bw0 + FOLD_WAVES < ra.n_waves ? bw0 + FOLD_WAVES : ra.n_waves;
+    const uint32_t bt0 = ra.wave_tiles[bw0], bt1 = ra.wave_tiles[bw1];
+    if (ra.robust) pass_wave_tiles<true>(ra.tiles, ra.wave_tiles, bw0 + (uint32_t)wv, ra.n_waves, bt0, ra.cbuf, ra.cstride, nullptr, su, red_buf, lane);
+    else pass_wave_tiles<false>(ra.tiles, ra.wave_tiles, bw0 + (uint32_t)wv, ra.n_waves, bt0, ra.cbuf, ra.cstride, nullptr, su, red_buf, lane);
+    block_store_partials(ra.tiles, bt0, bt1, red_buf, ra.partial, true);
+    PassOut po;
+    po.upairs = su;
+    po.proj = ra.proj[par ^ 1];
+    po.coherent_proj = 1;
+    block_finish_pairs(ra.pair_ticket, ra.tiles, bt0, bt1, ra.pairs_slots, red_buf, ra.partial, ra.pair_sums, po);
+    par ^= 1;
+    proj = ra.proj[par];
+    // every pair's projection is out once every workgroup has arrived (each waits for its own stores first)
+    if (!grid_sync(ra.gs, ra.n_wg, grid_epoch) || turn > prm.max_it + 8) {
+      grid_fail = true;
+      break;
+    }
+    need_pass = false;
+  }
+  }  // for (turn)
+  if (PERSIST && (grid_fail || !lead_wg)) return;  // only workgroup 0 reports; a failed wait reports nothing (the host repeats the solve)
   // the solver state leaves the registers: LDS image, then HBM (pass mode re-enters with it)
   constexpr bool ONE_LAUNCH = SPEC >= 1 && SPEC <= 4;  // the solve ends in this launch: nobody reads the state again
   if (wave0) {
