@@ -124,7 +124,12 @@ def measured_traffic(workload, kernel):
 
 
 def pass_kernel(workload):
-    return "k_pass<true>" if workload in ("config5", "config4r") else "k_fold<false, true, 0>"
+    # config 5: one window whose pass grid fits the chip in one round -- the passes run inside the persistent
+    # robust solver (k_lm<256, 6>: ten passes, LM steps and grid barriers in one launch; its bytes per launch are
+    # the ten passes' 24 B per residual block)
+    if workload == "config5":
+        return "void k_lm<256, 6>"
+    return "k_pass<true>" if workload == "config4r" else "k_fold<false, true, 0>"
 
 
 def roofline_of(timing, workload=None):

@@ -1378,7 +1378,13 @@ int do_solve(mvo_hip_context* h) {
     if (i == 0) tm.assembly_first_seconds = ms * 1e-3;
     else pass_seconds += ms * 1e-3;
   }
-  if (h->inline_eval) {
+  if (h->persistent_in_flight) {
+    // the passes run inside the persistent launch (k_lm<256, 6>): one pass per LM iteration; the launch -- everything
+    // behind the fold -- is attributed to them (an upper bound on their time: steps and hand-overs are in it)
+    tm.assembly_seconds = tm.device_seconds - tm.assembly_first_seconds;
+    tm.assembly_launches = 1;
+    tm.assembly_bytes = 24ull * h->n_obs * (uint64_t)(h->h_results[0].iterations > 0 ? h->h_results[0].iterations : 0);
+  } else if (h->inline_eval) {
     // the passes run inside k_lm: attribute the launch to them (an upper bound on their time)
     tm.assembly_seconds = tm.device_seconds;
     tm.assembly_launches = 1;

@@ -326,8 +326,10 @@ def test_split_phase_is_repeatable(solver):
     f2, s2 = solver.download()
     assert np.array_equal(f1, f2) and s1[0].final_cost == s2[0].final_cost
     t = solver.timing()
-    # 11 evaluations = the fold (which is the pass at x0 as well) + 10 k_pass launches
-    assert t["assembly_launches"] == 10 and t["residual_blocks"] == w.n_residual_blocks
+    # 11 evaluations = the fold (which is the pass at x0 as well) + 10 passes: inside ONE persistent launch
+    # (k_lm<256, 6>) for a single window of this size, as 10 k_pass launches otherwise (MVO_HIP_NO_PERSISTENT)
+    assert t["residual_blocks"] == w.n_residual_blocks
+    assert (t["assembly_launches"], t["lm_launches"]) in ((0, 1), (1, 1), (10, 11)), t
 
 
 def test_handle_reuse_across_shapes_and_modes(oracle):
