@@ -157,8 +157,9 @@ struct mvo_hip_context {
   hipError_t last_hip_error = hipSuccess;
   // device buffers
   DevBuf d_arena, d_m0, d_m1, d_c, d_partial, d_pair_u, d_states, d_ctl, d_trace, d_res, d_jac, d_pairsum, d_pticket,
-      d_proj,  // pass mode: T(6) q(3) cost(1) per pair, left by the passes' tails (project_pair8)
-      d_grid,  // the persistent robust solver's (k_lm<256, 6>) barrier counter and give-up flag (mvo_grid.h)
+      d_proj,  // pass mode: T(6) q(3) cost(1) per pair, left by the passes' tails (project_pair8); twice: the
+               // persistent robust solver (k_lm<256, 6>) alternates between the two halves
+      d_grid,  // its barrier counter and give-up flag (mvo_grid.h)
       d_cls;   // partitioned pass mode: MVO_CLS_DOUBLES class totals per window (k_class_sums), what the ranks all-reduce
   // The tables of one upload (and the rays of a small one) are staged in ONE pinned block and
   // reach the device in ONE copy into d_arena; these point into it (rays: or into d_m0 / d_m1).
@@ -634,7 +635,7 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
     HIP_TRY(h->d_m1.reserve(sizeof(double) * 3 * (n_obs + 1)));
   }
   if (h->pass_mode) HIP_TRY(h->d_c.reserve(sizeof(double) * 3 * h->c_elems));
-  HIP_TRY(h->d_partial.reserve(sizeof(double) * 8 * ((size_t)slot + 1) * 2));  // twice: the persistent robust solver alternates
+  HIP_TRY(h->d_partial.reserve(sizeof(double) * 8 * ((size_t)slot + 1)));
   HIP_TRY(h->d_pair_u.reserve(sizeof(double) * 4 * pairs.size()));
   HIP_TRY(h->d_pairsum.reserve(sizeof(double) * 8 * pairs.size()));
   {
@@ -647,9 +648,9 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
     for (const PairDev& pd : pairs) empty_pair |= pd.count == 0;
     if (empty_pair) HIP_TRY(hipMemsetAsync(h->d_pairsum.p, 0, sizeof(double) * 8 * pairs.size(), h->stream));
     if (h->pass_mode) {
-      HIP_TRY(h->d_proj.reserve(sizeof(double) * 10 * pairs.size()));
-      // a pair without residual blocks is never projected: zeros from here on
-      if (empty_pair) HIP_TRY(hipMemsetAsync(h->d_proj.p, 0, sizeof(double) * 10 * pairs.size(), h->stream));
+      HIP_TRY(h->d_proj.reserve(sizeof(double) * 10 * pairs.size() * 2));
+      // a pair without residual blocks is never projected: zeros from here on (both halves)
+      if (empty_pair) HIP_TRY(hipMemsetAsync(h->d_proj.p, 0, sizeof(double) * 10 * pairs.size() * 2, h->stream));
     }
     h->pairsum_foreign = false;
   }
@@ -751,7 +752,7 @@ hipError_t launch_fold(mvo_hip_context* h, bool write_c, bool fused = false) {
   int32_t* ticket = tails ? h->d_pticket.as<int32_t>() : nullptr;
   double* pairsum = h->d_pairsum.as<double>();
   const bool pass0 = write_c && fused;
-  const PassOut po{h->t.pair_u0, pass0 ? h->d_proj.as<double>() : nullptr};
+  const PassOut po{h->t.pair_u0, pass0 ? h->d_proj.as<double>() : nullptr, 0};
 #define MVO_FOLD_ARGS(cbuf, celems) \
   h->t.tiles, h->t.wave_tiles, h->n_waves, h->t.frames, h->t.m0, h->t.m1, cbuf, celems, h->d_partial.as<double>(), \
       ticket, h->t.pairs, pairsum, po
@@ -779,7 +780,7 @@ hipError_t launch_pass(mvo_hip_context* h, bool fused = false) {
   if (!blocks) return hipSuccess;
   const bool tails = fused && !h->env_no_tails;
   int32_t* ticket = tails ? h->d_pticket.as<int32_t>() : nullptr;
-  const PassOut po{h->d_pair_u.as<double>(), fused ? h->d_proj.as<double>() : nullptr};
+  const PassOut po{h->d_pair_u.as<double>(), fused ? h->d_proj.as<double>() : nullptr, 0};
   if (h->opt.use_loss_function)
     hipLaunchKernelGGL((k_pass<true>), dim3(blocks), dim3(FOLD_THREADS), pass_lds(h), h->stream,
                        h->t.tiles, h->t.wave_tiles, h->n_waves, h->d_c.as<double>(),
@@ -851,9 +852,11 @@ hipError_t launch_lm_persistent(mvo_hip_context* h, SolveParams prm) {
   ra.cbuf = h->d_c.as<double>();
   ra.cstride = (size_t)h->c_elems;
   ra.partial = h->d_partial.as<double>();
-  ra.partial_stride = 8 * ((size_t)h->n_slots + 1);
+  ra.pair_ticket = h->d_pticket.as<int32_t>();
   ra.pairs_slots = h->t.pairs;
-  ra.proj0 = h->d_proj.as<double>();
+  ra.pair_sums = h->d_pairsum.as<double>();
+  ra.proj[0] = h->d_proj.as<double>();
+  ra.proj[1] = h->d_proj.as<double>() + 10 * (size_t)h->W * h->P;
   ra.gs.count = h->d_grid.as<uint32_t>();
   ra.gs.error = h->d_grid.as<uint32_t>() + 32;
   ra.n_waves = h->n_waves;
@@ -935,7 +938,7 @@ hipError_t launch_lm_any(mvo_hip_context* h, SolveParams prm, bool from_pair_sum
 // launch-of-its-own form of the passes' tails (MVO_HIP_NO_TAILS)
 hipError_t launch_reduce_slots(mvo_hip_context* h, const double* upairs) {
   const uint32_t n = h->W * h->P;
-  const PassOut po{upairs, upairs ? h->d_proj.as<double>() : nullptr};
+  const PassOut po{upairs, upairs ? h->d_proj.as<double>() : nullptr, 0};
   hipLaunchKernelGGL(k_reduce_slots, dim3((n * 8 + 255) / 256), dim3(256), 0, h->stream,
                      h->t.pairs, n, h->d_partial.as<double>(), h->d_pairsum.as<double>(), po);
   return hipGetLastError();

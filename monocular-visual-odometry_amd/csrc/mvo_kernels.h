@@ -102,6 +102,8 @@ constexpr int MVO_MCX = MVO_MAXM + 1;  // classes per frame a: j = min(b, M) in 
 struct PassOut {
   const double* upairs;  // [W * P][4]: (u, |baseline|) per pair at the point under evaluation
   double* proj;          // [W * P][10]: T(6) q(3) cost(1) per pair (project_pair8); nullptr: sums only
+  int coherent_proj;     // the projections are read by other workgroups of THIS launch (persistent robust solver,
+                         // k_lm<256, 6>): stored device-coherently, like the slots
 };
 
 // Projected moments of one frame pair from its 8 pass sums, by the 8 consecutive lanes that hold them
@@ -148,8 +150,13 @@ __device__ __forceinline__ void pair_project_store(const PassOut& po, uint32_t p
   const double mine = project_pair8(acc, lane, u, up[3], extra);
   const int v = lane & 7;
   double* __restrict__ out = po.proj + 10 * (size_t)p;
-  out[v] = mine;
-  if (v < 2) out[8 + v] = extra;
+  if (po.coherent_proj) {
+    __hip_atomic_store(out + v, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (v < 2) __hip_atomic_store(out + 8 + v, extra, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    out[v] = mine;
+    if (v < 2) out[8 + v] = extra;
+  }
 }
 
 // The workgroup that stores the LAST slot of a frame pair adds that pair's slots up (what k_reduce_slots

@@ -993,8 +993,16 @@ __device__ __forceinline__ void pair_eval(const PairIn& in, const double (&beta)
 }
 
 // the pair's projected moments as the pass's tail left them (project_pair8): ten doubles, 16-byte loads
-__device__ __forceinline__ void proj_load(const double* proj, size_t pair, double (&o)[10]) {
-  const double2* q = reinterpret_cast<const double2*>(proj + 10 * pair);  // (HBM, or a workgroup's LDS copy: k_lm<256, 6>)
+// COHERENT: the projections were stored by other workgroups of THIS launch (persistent robust solver): device-scope loads
+template <bool COHERENT = false>
+__device__ __forceinline__ void proj_load(const double* __restrict__ proj, size_t pair, double (&o)[10]) {
+  if (COHERENT) {
+    const double* q = proj + 10 * pair;
+#pragma unroll
+    for (int j = 0; j < 10; ++j) o[j] = __hip_atomic_load(q + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  const double2* __restrict__ q = reinterpret_cast<const double2*>(proj + 10 * pair);
 #pragma unroll
   for (int j = 0; j < 5; ++j) {
     const double2 t = q[j];
@@ -1248,7 +1256,7 @@ __device__ __forceinline__ int lm_control_finish(LmRegs& r, LmShared& sh, const 
 // (lm_decide), wavefronts 1 and 3 multiply out the diagonal / the other blocks of the system and
 // wavefront 2 the gradient and its norm.  A class wavefront executes exactly the workgroup barriers wavefront 0 executes (marked
 // B0 / B1 / B1c / B2 on both sides).
-template <int NT, bool SPLIT, bool HALF_ONLY, bool SHORT_HERE>
+template <int NT, bool SPLIT, bool HALF_ONLY, bool SHORT_HERE, bool COHERENT_PROJ = false>
 __device__ __forceinline__ void lm_class_wave(LmShared& sh, const SolveParams& prm, int cw, int lane, int M, int N, int P,
                                               bool& need_pass, int unit_slots, const PairDev* __restrict__ wp,
                                               const double* partial, uint32_t pair_off, const double* __restrict__ fr,
@@ -1272,7 +1280,7 @@ __device__ __forceinline__ void lm_class_wave(LmShared& sh, const SolveParams& p
         const int a = cw + 3 * q, b = M + lane + 64 * rr;
         ok[q][rr] = a < M && b <= N - 2;
         if (rr < n_rounds && (q == 0 || cw + 3 < M))  // wave-uniform: rounds and frames that exist
-          proj_load(pw, (size_t)(ok[q][rr] ? pair_index(N, a, b) : 0), o[q][rr]);
+          proj_load<COHERENT_PROJ>(pw, (size_t)(ok[q][rr] ? pair_index(N, a, b) : 0), o[q][rr]);
       }
     const BlockRole br = block_role(M, lane);
 #pragma unroll
@@ -1437,86 +1445,37 @@ __device__ __forceinline__ void lm_class_wave(LmShared& sh, const SolveParams& p
 
 // ---- k_lm<256, 6>: the robust path of ONE window as ONE persistent launch -----------------------------------------
 // (IterativeRefinement.cpp:85-88 + :231-233: ceres::Solve with a loss function re-weights every residual at every
-// evaluation.)  The launch-per-evaluation path pays, per evaluation, a pass launch with its ticket tails, a k_lm
-// relaunch (state in and out of HBM, ~5 of its ~8 us) and two launch boundaries.  Here the grid of the PASS (one
-// workgroup per four wave-chunks of residual blocks, all resident, at most one per CU) stays for the whole solve, and
-// EVERY workgroup runs the LM step itself -- replicated: the same instruction stream on the same numbers, bit for bit
-// the same verdicts and candidates everywhere -- so that the step has nobody to hand its result to.  Per evaluation:
-//   1. every workgroup: class totals from the pairs' projections (its own LDS copy; evaluation 0: what the fold's tails
-//      left in HBM), system, verdict, step, candidate (the SPEC-5 evaluation, state in registers for the whole solve);
+// evaluation.)  The launch-per-evaluation path pays, per evaluation, a pass launch, a k_lm relaunch (state in and out
+// of HBM, ~5 of its ~8 us) and two launch boundaries.  Here the grid of the PASS (one workgroup per four wave-chunks of
+// residual blocks, all resident, at most one per CU) stays for the whole solve, and EVERY workgroup runs the LM step
+// itself -- replicated: the same instruction stream on the same numbers, bit for bit the same verdicts and candidates
+// everywhere -- so that the step has nobody to hand its result to.  Per evaluation:
+//   1. every workgroup: class totals from the pairs' projections (device-scope loads), system, verdict, step, candidate
+//      (the SPEC-5 evaluation, state in registers for the whole solve);
 //   2. every workgroup: unit baselines of ALL pairs at the candidate into its LDS (the epilogue's arithmetic);
-//   3. the pass over the workgroup's own tiles, its slots stored device-coherently;
-//   4. grid_sync (mvo_grid.h) -- the only wait, bounded, with a give-up flag;
-//   5. every workgroup: ALL pairs' slots (device-scope loads, every load of a thread in flight at once), added up in slot
-//      order and projected (project_pair8) into its LDS -- replicated again: no tickets, no tails, no projections in HBM.
-// The slots alternate between two buffers, so a workgroup that is one evaluation ahead never overwrites what another
-// still reads.  Same sums in the same order and the same projection as k_pass's tails + k_lm<256, 5>: identical results
-// (tests/test_gpu_persistent.py).  Workgroup 0 writes the result.  If a wait gives up the launch ends without a result,
-// the host sees that and repeats the solve launch by launch.
+//   3. the pass over the workgroup's own tiles, slots stored device-coherently, per-pair tickets, the workgroup that
+//      completes a pair adds its slots up and projects it (block_finish_pairs) into the OTHER projection buffer;
+//   4. grid_sync (mvo_grid.h) -- the only wait, bounded, with a give-up flag.
+// Two projection buffers alternate, so a workgroup that is one evaluation ahead never writes what another still reads;
+// slots and tickets are rewritten only behind the barrier.  Workgroup 0 writes the result.  If a wait gives up the
+// launch ends without a result, the host sees the error word and repeats the solve launch by launch.
 // Eligible (host, robust_persistent_ok): one window, pass workgroups <= kRobustMaxWorkgroups, pairs <=
 // kRobustMaxPairs, tiles per workgroup <= kRobustMaxTiles, the SPEC-5 conditions (all columns free, no trace).
-constexpr int kRobustMaxWorkgroups = 192, kRobustMaxPairs = 256, kRobustMaxTiles = 64;
+constexpr int kRobustMaxWorkgroups = 192, kRobustMaxPairs = 512, kRobustMaxTiles = 64;
 struct RobustArgs {
   const TileDev* tiles;
   const uint32_t* wave_tiles;
   const double* cbuf;
   size_t cstride;
-  double* partial;             // two slot buffers, partial_stride doubles apart
-  size_t partial_stride;
+  double* partial;
+  int32_t* pair_ticket;
   const PairDev* pairs_slots;  // the pairs with their slot ranges (k_lm's own `pairs` are the unit rows here)
-  const double* proj0;         // the projections the fold's tails wrote (evaluation 0)
+  double* pair_sums;
+  double* proj[2];             // [0]: what the fold's tails wrote (evaluation 0)
   GridSync gs;
   uint32_t n_waves, n_wg;
   int32_t robust;              // Cauchy(0.5) / plain (assembly_mode = PASSES)
 };
-
-// Step 5 above.  s_slot: (slot_begin, slot_end) of every pair, in LDS.  Items (pair, value) over the threads, ROUNDS
-// rounds; a thread first requests the first three slots of all its items (clamped indices, unconditional: one memory
-// latency), then adds them up in slot order (a pair with more than three slots -- spanning more than three workgroups --
-// finishes in a loop) and the eight lanes of a pair project it.
-template <int ROUNDS>
-__device__ __forceinline__ void robust_reduce_project(const double* part, const uint32_t* s_slot, const double* su,
-                                                      double* proj_lds, int P, int tid) {
-  constexpr int K = 3;
-  const int lane = tid & 63, n_items = 8 * P;
-  double v[ROUNDS][K];
-  uint32_t sb[ROUNDS], cnt[ROUNDS];
-#pragma unroll
-  for (int r = 0; r < ROUNDS; ++r) {
-    const int item = tid + FOLD_THREADS * r;
-    const bool ok = item < n_items;
-    const int p = ok ? item >> 3 : 0, vv = item & 7;
-    sb[r] = s_slot[2 * p];
-    cnt[r] = ok ? s_slot[2 * p + 1] - sb[r] : 0u;
-    if (FOLD_THREADS * r < n_items) {  // (uniform)
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        const uint32_t sl = sb[r] + ((uint32_t)k < cnt[r] ? (uint32_t)k : 0u);  // a slot of this pair, or slot sb (exists: >= 1 slot in all)
-        v[r][k] = __hip_atomic_load(part + (size_t)sl * 8 + vv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < ROUNDS; ++r) {
-    if (FOLD_THREADS * r < n_items) {  // (uniform)
-      const int item = tid + FOLD_THREADS * r;
-      const bool ok = item < n_items;
-      const int p = ok ? item >> 3 : 0, vv = item & 7;
-      double acc = 0.0;
-#pragma unroll
-      for (int k = 0; k < K; ++k) acc += (uint32_t)k < cnt[r] ? v[r][k] : 0.0;
-      for (uint32_t k = K; k < cnt[r]; ++k)
-        acc += __hip_atomic_load(part + (size_t)(sb[r] + k) * 8 + vv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const double u[3] = {su[4 * p], su[4 * p + 1], su[4 * p + 2]};
-      double extra;
-      const double mine = project_pair8(acc, lane, u, su[4 * p + 3], extra);
-      if (ok) {
-        proj_lds[10 * p + vv] = mine;
-        if (vv < 2) proj_lds[10 * p + 8 + vv] = extra;
-      }
-    }
-  }
-}
 
 // SPEC: the same kernel with the run-time switches of the common solves fixed at compile time, so that the
 // compiler sees one path instead of all of them (fewer live values around wavefront 0's loop, fewer hoisted
@@ -1575,15 +1534,7 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
   static_assert(!PERSIST || NT == FOLD_THREADS, "the persistent solver runs the pass with its own workgroup");
   __shared__ double su[PERSIST ? 4 * kRobustMaxPairs : 1];   // (u, |baseline|) of every pair at the candidate
   __shared__ double red_buf[PERSIST ? 8 * kRobustMaxTiles : 1];
-  __shared__ double proj_lds[PERSIST ? 10 * kRobustMaxPairs : 1];  // every pair projected, this workgroup's own copy
-  __shared__ uint32_t s_slot[PERSIST ? 2 * kRobustMaxPairs : 2];   // (slot_begin, slot_end) per pair
-  if (PERSIST && (gridDim.x != ra.n_wg || ra.n_wg > (uint32_t)kRobustMaxWorkgroups || prm.P > kRobustMaxPairs)) return;  // (host bug guard: nobody waits yet)
-  if (PERSIST)
-    for (int p = threadIdx.x; p < prm.P; p += NT) {  // (read behind the prologue's barriers)
-      const PairDev pd = ra.pairs_slots[p];
-      s_slot[2 * p] = pd.slot_begin;
-      s_slot[2 * p + 1] = pd.slot_end;
-    }
+  if (PERSIST && (gridDim.x != ra.n_wg || ra.n_wg > (uint32_t)kRobustMaxWorkgroups)) return;  // (host bug guard: nobody waits yet)
   const int w = PERSIST ? 0 : (int)blockIdx.x + prm.win_base, tid = threadIdx.x;
   const bool lead_wg = !PERSIST || blockIdx.x == 0;  // writes status words and the result
 #ifdef MVO_LM_STAMPS
@@ -1686,10 +1637,11 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
   constexpr bool SPLIT = LARGE && (SPEC == 3 || SPEC == 4);
   // PERSIST: the evaluations of the whole solve, one per turn of this loop (everything else: one turn)
   uint32_t grid_epoch = 0;
+  int par = 0;             // which projection buffer holds the evaluation to take in
   bool grid_fail = false;
-  if (PERSIST) proj = ra.proj0;
+  if (PERSIST) proj = ra.proj[0];
   for (int turn = 0;; ++turn) {
-  if (LARGE && !wave0) lm_class_wave<NT, SPLIT, SPLIT, SPLIT>(sh, prm, wv - 1, lane, M, N, P, need_pass, unit_slots, wp, partial, win.pair_off, fr, m0, m1, my_sums, proj);
+  if (LARGE && !wave0) lm_class_wave<NT, SPLIT, SPLIT, SPLIT, PERSIST>(sh, prm, wv - 1, lane, M, N, P, need_pass, unit_slots, wp, partial, win.pair_off, fr, m0, m1, my_sums, proj);
   int my_p0 = lane < P ? lane : 0;
   bool my_ok0 = lane < P;
   int my_a = 0, my_j = 0;  // k_lm<256>: the short pair's (a, b)
@@ -1739,7 +1691,7 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
       if (prm.proj_ready) {
         // pass mode, passes as launches of their own: the pass's tail projected every pair -- nothing to evaluate
         pair_ab(N, M, my_p0, pa, pb);
-        proj_load(proj, (size_t)win.pair_off + my_p0, o);
+        proj_load<PERSIST>(proj, (size_t)win.pair_off + my_p0, o);
       } else {
         if (!have_in) {
           if (!LARGE && prm.inline_eval) pair_load_lds(in0, my_p0, N, M, inl_sums, fr);
@@ -1878,16 +1830,19 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
     const uint32_t bt0 = ra.wave_tiles[bw0], bt1 = ra.wave_tiles[bw1];
     if (ra.robust) pass_wave_tiles<true>(ra.tiles, ra.wave_tiles, bw0 + (uint32_t)wv, ra.n_waves, bt0, ra.cbuf, ra.cstride, nullptr, su, red_buf, lane);
     else pass_wave_tiles<false>(ra.tiles, ra.wave_tiles, bw0 + (uint32_t)wv, ra.n_waves, bt0, ra.cbuf, ra.cstride, nullptr, su, red_buf, lane);
-    double* part = ra.partial + (size_t)(turn & 1) * ra.partial_stride;  // the slot buffers alternate
-    block_store_partials(ra.tiles, bt0, bt1, red_buf, part, true);
-    // every workgroup's slots are out once every workgroup has arrived (each waits for its own stores first)
+    block_store_partials(ra.tiles, bt0, bt1, red_buf, ra.partial, true);
+    PassOut po;
+    po.upairs = su;
+    po.proj = ra.proj[par ^ 1];
+    po.coherent_proj = 1;
+    block_finish_pairs(ra.pair_ticket, ra.tiles, bt0, bt1, ra.pairs_slots, red_buf, ra.partial, ra.pair_sums, po);
+    par ^= 1;
+    proj = ra.proj[par];
+    // every pair's projection is out once every workgroup has arrived (each waits for its own stores first)
     if (!grid_sync(ra.gs, ra.n_wg, grid_epoch) || turn > prm.max_it + 8) {
       grid_fail = true;
       break;
     }
-    robust_reduce_project<(8 * kRobustMaxPairs + FOLD_THREADS - 1) / FOLD_THREADS>(part, s_slot, su, proj_lds, P, tid);
-    __syncthreads();  // the projections are complete: the next evaluation adds its classes up from them
-    proj = proj_lds;
     need_pass = false;
   }
   }  // for (turn)
