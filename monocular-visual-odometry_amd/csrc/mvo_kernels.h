@@ -27,10 +27,13 @@
 // reduces its sums once; the tiles of a workgroup that continue the same pair are merged through
 // LDS into one SLOT (a slot never spans workgroups) -- no global atomics anywhere.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void block_store_partials(const TileDev* __restrict__ tiles, uint32_t bt0, uint32_t bt1,
+// `tiles` is the global tile table, or (persistent robust solver) the workgroup's own tiles copied to LDS: tiles[0] is
+// then tile bt0, which `bias` = bt0 says.
+__device__ __forceinline__ void block_store_partials(const TileDev* tiles, uint32_t bt0, uint32_t bt1,
                                                      const double* __restrict__ red,
-                                                     double* __restrict__ partial, bool coherent) {
+                                                     double* __restrict__ partial, bool coherent, uint32_t bias = 0) {
   __syncthreads();
+  tiles -= bias;
   const uint32_t nt = bt1 - bt0;
   for (uint32_t item = threadIdx.x; item < nt * 8; item += FOLD_THREADS) {
     const uint32_t lt = item >> 3, v = item & 7;
@@ -168,11 +171,12 @@ __device__ __forceinline__ void pair_project_store(const PassOut& po, uint32_t p
 // `red` (the workgroup's reduction buffer, free after block_store_partials) holds the to-do list.
 // po.proj != nullptr (the sums are those of a pass at the unit baselines po.upairs): the finishing workgroup
 // also projects the pair (project_pair8).
-__device__ __forceinline__ void block_finish_pairs(int32_t* pair_ticket, const TileDev* __restrict__ tiles, uint32_t bt0,
+__device__ __forceinline__ void block_finish_pairs(int32_t* pair_ticket, const TileDev* tiles, uint32_t bt0,
                                                    uint32_t bt1, const PairDev* __restrict__ pairs, double* red,
                                                    const double* partial, double* __restrict__ pair_sums,
-                                                   const PassOut& po) {
+                                                   const PassOut& po, uint32_t bias = 0) {
   if (pair_ticket == nullptr) return;
+  tiles -= bias;
   __shared__ uint32_t n_todo;
   // The slot stores above are device-coherent (written through the XCD's L2) and every wavefront has
   // waited for its own (s_waitcnt vmcnt(0) at the end of block_store_partials); the barrier below
@@ -316,14 +320,17 @@ __global__ __launch_bounds__(FOLD_THREADS) void k_fold(const TileDev* __restrict
 // ---------------------------------------------------------------------------------------
 // the tiles of wavefront gw: one evaluation of their residual blocks at the unit baselines in `upairs`; the tile's
 // 8 sums land in red[(tile - bt0) * 8 + value].  Shared by k_pass and the persistent robust solver (k_lm<256, 6>).
+// (tiles / bias: see block_store_partials; wave_tiles[0] is then the entry of wavefront `wbias`)
 template <bool ROBUST>
-__device__ __forceinline__ void pass_wave_tiles(const TileDev* __restrict__ tiles, const uint32_t* __restrict__ wave_tiles,
+__device__ __forceinline__ void pass_wave_tiles(const TileDev* tiles, const uint32_t* wave_tiles,
                                                 uint32_t gw, uint32_t n_waves, uint32_t bt0,
                                                 const double* __restrict__ cbuf, size_t cstride,
                                                 const int32_t* __restrict__ win_status,  // nullptr: every window is live
-                                                const double* upairs, double* red, int lane) {
+                                                const double* upairs, double* red, int lane, uint32_t bias = 0,
+                                                uint32_t wbias = 0) {
   if (gw >= n_waves) return;
-  const uint32_t t0 = wave_tiles[gw], t1 = wave_tiles[gw + 1];
+  tiles -= bias;
+  const uint32_t t0 = wave_tiles[gw - wbias], t1 = wave_tiles[gw + 1 - wbias];
   for (uint32_t t = t0; t < t1; ++t) {
     const TileDev tl = tiles[t];
     double S[8] = {0, 0, 0, 0, 0, 0, 0, 0};

@@ -33,7 +33,7 @@
 // Diagnostic build only (-DMVO_LM_STAMPS): thread 0 of window 0 accumulates the shader-clock
 // cycles spent in each phase of an LM iteration into a buffer of its own (mvo_lm_stamps).
 #ifdef MVO_LM_STAMPS
-__device__ unsigned long long mvo_lm_stamps[16];
+__device__ unsigned long long mvo_lm_stamps[24];
 // accumulated in LDS with fire-and-forget ds_add (a global read-modify-write per stamp would put
 // an L2 round trip into every measured phase); flushed once when the kernel ends
 #define MVO_STAMP_ADD(i, v) \
@@ -58,7 +58,17 @@ __device__ unsigned long long mvo_lm_stamps[16];
   } while (0)
 #define MVO_STAMP_PARAM , unsigned long long* stamp_acc_
 #define MVO_STAMP_ARG , stamp_acc_
+// the persistent robust solver's phases (workgroup 0, thread 0), slots 16..23 of mvo_lm_stamps
+#define MVO_RSTAMP(i)                                                                        \
+  do {                                                                                       \
+    if (PERSIST && blockIdx.x == 0 && threadIdx.x == 0) {                                    \
+      const unsigned long long now_ = __builtin_amdgcn_s_memtime();                          \
+      mvo_lm_stamps[16 + (i)] += now_ - rstamp_prev_;                                        \
+      rstamp_prev_ = now_;                                                                   \
+    }                                                                                        \
+  } while (0)
 #else
+#define MVO_RSTAMP(i) do { } while (0)
 #define MVO_STAMP(i) do { } while (0)
 #define MVO_ASTAMP(i) do { } while (0)
 #define MVO_STAMP_PARAM
@@ -1534,7 +1544,17 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
   static_assert(!PERSIST || NT == FOLD_THREADS, "the persistent solver runs the pass with its own workgroup");
   __shared__ double su[PERSIST ? 4 * kRobustMaxPairs : 1];   // (u, |baseline|) of every pair at the candidate
   __shared__ double red_buf[PERSIST ? 8 * kRobustMaxTiles : 1];
+  __shared__ TileDev s_tiles[PERSIST ? kRobustMaxTiles : 1];  // this workgroup's tiles and its wavefronts' first tiles:
+  __shared__ uint32_t s_wt[FOLD_WAVES + 1];                   // read once, not once per pass (two dependent L2 round trips)
   if (PERSIST && (gridDim.x != ra.n_wg || ra.n_wg > (uint32_t)kRobustMaxWorkgroups)) return;  // (host bug guard: nobody waits yet)
+  if (PERSIST) {  // (read behind the prologue's barriers)
+    const uint32_t bw0 = blockIdx.x * FOLD_WAVES;
+    const uint32_t bw1 = bw0 + FOLD_WAVES < ra.n_waves ? bw0 + FOLD_WAVES : ra.n_waves;
+    const uint32_t bt0 = ra.wave_tiles[bw0], bt1 = ra.wave_tiles[bw1];
+    if (bt1 - bt0 > (uint32_t)kRobustMaxTiles) return;  // (host bug guard; uniform over the grid only if the host checked)
+    if (threadIdx.x <= FOLD_WAVES) s_wt[threadIdx.x] = ra.wave_tiles[bw0 + threadIdx.x <= bw1 ? bw0 + threadIdx.x : bw1];
+    for (uint32_t t = threadIdx.x; t < bt1 - bt0; t += NT) s_tiles[t] = ra.tiles[bt0 + t];
+  }
   const int w = PERSIST ? 0 : (int)blockIdx.x + prm.win_base, tid = threadIdx.x;
   const bool lead_wg = !PERSIST || blockIdx.x == 0;  // writes status words and the result
 #ifdef MVO_LM_STAMPS
@@ -1640,6 +1660,9 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
   int par = 0;             // which projection buffer holds the evaluation to take in
   bool grid_fail = false;
   if (PERSIST) proj = ra.proj[0];
+#ifdef MVO_LM_STAMPS
+  unsigned long long rstamp_prev_ = __builtin_amdgcn_s_memtime();
+#endif
   for (int turn = 0;; ++turn) {
   if (LARGE && !wave0) lm_class_wave<NT, SPLIT, SPLIT, SPLIT, PERSIST>(sh, prm, wv - 1, lane, M, N, P, need_pass, unit_slots, wp, partial, win.pair_off, fr, m0, m1, my_sums, proj);
   int my_p0 = lane < P ? lane : 0;
@@ -1825,17 +1848,21 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
   // ---- PERSIST: the pass at the candidate over this workgroup's tiles, then the grid-wide hand-over ----
   {
     __syncthreads();  // su is complete
+    MVO_RSTAMP(0);  // the replicated evaluation and step, su
     const uint32_t bw0 = blockIdx.x * FOLD_WAVES;
     const uint32_t bw1 = bw0 + FOLD_WAVES < ra.n_waves ? bw0 + FOLD_WAVES : ra.n_waves;
-    const uint32_t bt0 = ra.wave_tiles[bw0], bt1 = ra.wave_tiles[bw1];
-    if (ra.robust) pass_wave_tiles<true>(ra.tiles, ra.wave_tiles, bw0 + (uint32_t)wv, ra.n_waves, bt0, ra.cbuf, ra.cstride, nullptr, su, red_buf, lane);
-    else pass_wave_tiles<false>(ra.tiles, ra.wave_tiles, bw0 + (uint32_t)wv, ra.n_waves, bt0, ra.cbuf, ra.cstride, nullptr, su, red_buf, lane);
-    block_store_partials(ra.tiles, bt0, bt1, red_buf, ra.partial, true);
+    const uint32_t bt0 = s_wt[0], bt1 = s_wt[bw1 - bw0];
+    if (ra.robust) pass_wave_tiles<true>(s_tiles, s_wt, bw0 + (uint32_t)wv, ra.n_waves, bt0, ra.cbuf, ra.cstride, nullptr, su, red_buf, lane, bt0, bw0);
+    else pass_wave_tiles<false>(s_tiles, s_wt, bw0 + (uint32_t)wv, ra.n_waves, bt0, ra.cbuf, ra.cstride, nullptr, su, red_buf, lane, bt0, bw0);
+    MVO_RSTAMP(1);  // pass over the own tiles
+    block_store_partials(s_tiles, bt0, bt1, red_buf, ra.partial, true, bt0);
+    MVO_RSTAMP(2);  // slots out (acknowledged)
     PassOut po;
     po.upairs = su;
     po.proj = ra.proj[par ^ 1];
     po.coherent_proj = 1;
-    block_finish_pairs(ra.pair_ticket, ra.tiles, bt0, bt1, ra.pairs_slots, red_buf, ra.partial, ra.pair_sums, po);
+    block_finish_pairs(ra.pair_ticket, s_tiles, bt0, bt1, ra.pairs_slots, red_buf, ra.partial, ra.pair_sums, po, bt0);
+    MVO_RSTAMP(3);  // tickets, finished pairs added up and projected
     par ^= 1;
     proj = ra.proj[par];
     // every pair's projection is out once every workgroup has arrived (each waits for its own stores first)
@@ -1843,6 +1870,7 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
       grid_fail = true;
       break;
     }
+    MVO_RSTAMP(4);  // grid barrier
     need_pass = false;
   }
   }  // for (turn)

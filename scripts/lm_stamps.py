@@ -34,3 +34,9 @@ for label, ws in (("config5 (Cauchy, tiled passes)", [scene.config2(seed=1005, o
         lib.mvo_hip_debug_stamps(buf, 0)
         n = max(1, buf[0])
         print(label, "evaluations", buf[0], " cycles/eval:", {names[i]: buf[i] // n for i in range(1, 8)})
+        rb = (C.c_ulonglong * 8)()
+        lib.mvo_hip_debug_stamps_persistent.argtypes = [C.POINTER(C.c_ulonglong)]
+        lib.mvo_hip_debug_stamps_persistent(rb)
+        if rb[0]:  # one window whose pass grid fits the chip: the persistent robust solver (k_lm<256, 6>), per pass
+            rn = ["evaluation + step + unit baselines", "pass over the own tiles", "slots out", "tickets + finished pairs projected", "grid barrier"]
+            print("    persistent solver, cycles per pass (workgroup 0):", {rn[i]: rb[i] // max(1, n - 1) for i in range(5)})
