@@ -128,7 +128,7 @@ def pass_kernel(workload):
     # robust solver (k_lm<256, 6>: ten passes, LM steps and grid barriers in one launch; its bytes per launch are
     # the ten passes' 24 B per residual block)
     if workload == "config5":
-        return "void k_lm<256, 6>"
+        return "k_lm<256, 6>"
     return "k_pass<true>" if workload == "config4r" else "k_fold<false, true, 0>"
 
 

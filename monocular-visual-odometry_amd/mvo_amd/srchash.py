@@ -12,8 +12,8 @@ _SOURCES = {
     "k_fold": ["mvo_kernels.h", "mvo_wave.h", "mvo_device.h"],
     "k_pass": ["mvo_kernels.h", "mvo_wave.h", "mvo_device.h"],
     "k_reduce_slots": ["mvo_kernels.h"],
-    "k_lm4": ["mvo_lm4.h", "mvo_lm.h", "mvo_kernels.h", "mvo_wave.h", "mvo_device.h"],
-    "k_lm": ["mvo_lm.h", "mvo_kernels.h", "mvo_wave.h", "mvo_device.h"],
+    "k_lm4": ["mvo_lm4.h", "mvo_lm.h", "mvo_grid.h", "mvo_kernels.h", "mvo_wave.h", "mvo_device.h"],
+    "k_lm": ["mvo_lm.h", "mvo_grid.h", "mvo_kernels.h", "mvo_wave.h", "mvo_device.h"],
     "k_scaler": ["mvo_scaler.hip", "mvo_wave.h"],
     "k_tracks": ["mvo_tracks.hip", "mvo_wave.h"],
     "k_ba": ["mvo_ba.hip", "mvo_wave.h"],
