@@ -345,21 +345,18 @@ __device__ __forceinline__ void gj_row_update(double (&a)[MVO_MAXC], double f) {
 // has a zero in that column.  The LM damping D^2 = diag / radius is never written into the matrix: a
 // row's diagonal entry is not touched by the steps before its own, so the damping is added when the
 // entry becomes the pivot (ddl = the lane's damping on active rows, 1 on the all-zero padding rows).  Each lane
-// keeps the reciprocal of its own pivot (myrinv); phimax collects the pivots for the validity test.
+// keeps the reciprocal of its own pivot (myrinv), which is also what the validity test looks at afterwards: a negative
+// pivot leaves a negative reciprocal (-0 for -inf), an infinite one +0, a NaN a NaN, a zero one an infinite step.
 // Look-ahead order: step J updates column J+1 first and starts the reciprocal of the NEXT pivot
 // (readlane -> v_rcp -> two Newton steps, a ~100-cycle dependent chain) before it touches the
 // remaining columns, whose independent updates then fill that latency.
 // n (wave-uniform): the active rows; the steps from n on would run on identity padding (the reference's
 // shipped window refines two frames: 6 of 15) and are skipped by one scalar branch.
 template <int J, bool FULL = false>
-__device__ __forceinline__ void gj_eliminate(double (&a)[MVO_MAXC], double& rhs, double& myrinv, unsigned& phimax,
+__device__ __forceinline__ void gj_eliminate(double (&a)[MVO_MAXC], double& rhs, double& myrinv,
                                              int lane, double ddl, double piv, double rinv, int n) {
   if constexpr (J < MVO_MAXC) {
     if (!FULL && J >= n) return;  // FULL: the caller checked n == MVO_MAXC (five refined frames, all columns free)
-    // largest high word of the pivots, as unsigned: a negative pivot (sign bit), an infinite one or a NaN
-    // (exponent 0x7ff) all end up >= 0x7ff00000 -- one scalar max per step
-    const unsigned hi = (unsigned)__double2hiint(piv);
-    phimax = hi > phimax ? hi : phimax;
     // `lane == J` is recomputed at every step: left to itself the compiler hoists the fifteen lane
     // masks out of the solver loop, 30 scalar registers that it then spills and reloads one by one
     int lane_here = lane;
@@ -375,7 +372,7 @@ __device__ __forceinline__ void gj_eliminate(double (&a)[MVO_MAXC], double& rhs,
       gj_row_update<J, J + 2>(a, f);
     }
     rhs -= f * row_bcast<J>(rhs);
-    gj_eliminate<J + 1, FULL>(a, rhs, myrinv, phimax, lane, ddl, piv_next, rinv_next, n);
+    gj_eliminate<J + 1, FULL>(a, rhs, myrinv, lane, ddl, piv_next, rinv_next, n);
   }
 }
 
@@ -750,15 +747,15 @@ __device__ __forceinline__ int lm_step(LmRegs& r, LmShared& sh, const SolveParam
   const double rhs0 = jsm * r.g;
   MVO_ASTAMP(10);
   double rhs = rhs0, myrinv = 1.0;
-  unsigned phimax = 0;
   {
     const double piv0 = bcast_lane(a[0] + ddl, 0);
-    gj_eliminate<0>(a, rhs, myrinv, phimax, lane, ddl, piv0, fast_rcp(piv0), n);
+    gj_eliminate<0>(a, rhs, myrinv, lane, ddl, piv0, fast_rcp(piv0), n);
   }
   MVO_ASTAMP(11);
   const double step = lane < n ? -(rhs * myrinv) : 0.0;
-  // a pivot < 0 or infinite, or a non-finite step (a zero pivot gives one): the linear solver failed
-  const bool ok = phimax < 0x7ff00000u && !__any(!isfinite(step));
+  // a pivot < 0 or infinite or NaN (its reciprocal is not > 0), or a non-finite step (a zero pivot gives one): the
+  // linear solver failed
+  const bool ok = !__any(!(myrinv > 0.0) || !isfinite(step));
   // model_cost_change = -(Js step)^T (r + Js step / 2) = -step^T b - step^T As step / 2 with
   // b = Js^T r, As = Js^T Js.  The step solves (As + D^2) step = -b, so As step = -b - D^2 step
   // and the change is (-step^T b + step^T D^2 step) / 2 -- no second pass over the matrix.
@@ -1208,14 +1205,13 @@ __device__ __forceinline__ void lm_solver_step(LmSolver& q, LmShared& sh, const 
   const double ddl = lane < n ? dd : 1.0;
   const double rhs0 = jsm * q.g;
   double rhs = rhs0, myrinv = 1.0;
-  unsigned phimax = 0;
   {
     const double piv0 = bcast_lane(a[0] + ddl, 0);
-    if (n == MVO_MAXC) gj_eliminate<0, true>(a, rhs, myrinv, phimax, lane, ddl, piv0, fast_rcp(piv0), n);
-    else gj_eliminate<0>(a, rhs, myrinv, phimax, lane, ddl, piv0, fast_rcp(piv0), n);
+    if (n == MVO_MAXC) gj_eliminate<0, true>(a, rhs, myrinv, lane, ddl, piv0, fast_rcp(piv0), n);
+    else gj_eliminate<0>(a, rhs, myrinv, lane, ddl, piv0, fast_rcp(piv0), n);
   }
   const double step = lane < n ? -(rhs * myrinv) : 0.0;
-  const bool ok = phimax < 0x7ff00000u && !__any(!isfinite(step));
+  const bool ok = !__any(!(myrinv > 0.0) || !isfinite(step));
   if (lane <= MVO_MAXC) sh.mcc_term[lane] = ok ? step * (dd * step - rhs0) : 0.0;  // (see lm_step)
   if (lane == 0) sh.step_ok = ok ? 1 : 0;
   if (!ok) return;
