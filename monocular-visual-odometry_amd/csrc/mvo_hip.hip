@@ -1892,7 +1892,7 @@ const char* mvo_hip_status_string(int status) {
 // diagnostic build: phase cycle counters of k_lm (window 0); [0] = iterations counted
 int mvo_hip_debug_stamps(unsigned long long* out8, int reset) {
   if (reset) {
-    unsigned long long z[24] = {0};
+    unsigned long long z[32] = {0};
     return hipMemcpyToSymbol(HIP_SYMBOL(mvo_lm_stamps), z, sizeof z) == hipSuccess ? 0 : 4;
   }
   return hipMemcpyFromSymbol(out8, HIP_SYMBOL(mvo_lm_stamps), 128) == hipSuccess ? 0 : 4;
@@ -1900,6 +1900,10 @@ int mvo_hip_debug_stamps(unsigned long long* out8, int reset) {
 // slots 16..23: the persistent robust solver's phases (MVO_RSTAMP, mvo_lm.h)
 int mvo_hip_debug_stamps_persistent(unsigned long long* out8) {
   return hipMemcpyFromSymbol(out8, HIP_SYMBOL(mvo_lm_stamps), 64, 128) == hipSuccess ? 0 : 4;
+}
+// slots 24..31: k_lm4's phases (workgroup 0), mvo_lm4.h
+int mvo_hip_debug_stamps_lm4(unsigned long long* out8) {
+  return hipMemcpyFromSymbol(out8, HIP_SYMBOL(mvo_lm_stamps), 64, 192) == hipSuccess ? 0 : 4;
 }
 #endif
 

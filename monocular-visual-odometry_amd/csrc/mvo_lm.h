@@ -33,7 +33,7 @@
 // Diagnostic build only (-DMVO_LM_STAMPS): thread 0 of window 0 accumulates the shader-clock
 // cycles spent in each phase of an LM iteration into a buffer of its own (mvo_lm_stamps).
 #ifdef MVO_LM_STAMPS
-__device__ unsigned long long mvo_lm_stamps[24];
+__device__ unsigned long long mvo_lm_stamps[32];  // 0..15 k_lm, 16..23 the persistent solver, 24..31 k_lm4
 // accumulated in LDS with fire-and-forget ds_add (a global read-modify-write per stamp would put
 // an L2 round trip into every measured phase); flushed once when the kernel ends
 #define MVO_STAMP_ADD(i, v) \

@@ -5,7 +5,8 @@
 // of an evaluation's instruction stream and uses 15 of the 64 lanes.  A wavefront issues one instruction
 // per ~4.4 cycles whatever the lane count, so four windows side by side -- window q in the 16-lane DPP
 // row q -- take the step for the price of one.  The evaluation itself (per-pair moments, class sums,
-// 3 x 3 blocks: already 35..60 lanes wide) runs window after window with the code of k_lm<64>.
+// 3 x 3 blocks: already 35..60 lanes wide) runs two windows at a time, side by side in one instruction
+// stream (lm4_evaluate2): the stages of k_lm<64>, same operations in the same order.
 //
 // The step is the same restatement of Ceres 1.14's TrustRegionMinimizer as lm_decide / lm_step
 // (mvo_lm.h), written without branches: what is wave-uniform there is row-uniform here, every `if` is a
@@ -28,31 +29,20 @@ struct Lm4Win {  // one window, kept across evaluations
   double cost;
 };
 
-struct Lm4Shared {
-  Lm4Win win[LM4_WINDOWS];
-  // scratch of ONE evaluation (the windows are evaluated one after the other)
-  double kk[MVO_MAXM][10], C1[MVO_MAXM * MCX][10], D[MVO_MAXM * MCX][10];
+// scratch of ONE evaluation.  Two of them: the windows are evaluated two at a time, side by side in one instruction
+// stream (lm4_evaluate2), so that one window's LDS round trips and dependent fp64 chains run under the other's.
+struct Lm4Eval {
+  double kk[MVO_MAXM][10];       // pair (k, k)
+  double Cd[MVO_MAXM][10];       // C1[k][k + 1] of lm_prefix_suffix: what the diagonal blocks add to D[k][k + 1]
+  double D[MVO_MAXM * MCX][10];  // D[k][j] = sum_{a <= k} sum_{j' >= j} class (a, j')
   double pairbuf[64 * 10];
 };
+constexpr int LM4_SIDE = 2;
 
-// what the evaluation helpers of mvo_lm.h expect of "sh", for window q
-struct Lm4View {
-  double (*zvec)[3];
-  double *zt, *zs, *zsp;
-  double (*G)[9];
-  double (*kk)[10];
-  double (*C1)[10];
-  double (*D)[10];
-  double* gz;
+struct Lm4Shared {
+  Lm4Win win[LM4_WINDOWS];
+  Lm4Eval ev[LM4_SIDE];
 };
-
-__device__ __forceinline__ Lm4View lm4_view(Lm4Shared& sh, int q) {
-  Lm4View v;
-  Lm4Win& w = sh.win[q];
-  v.zvec = w.zvec; v.zt = w.zt; v.zs = w.zs; v.zsp = w.zsp; v.G = w.G;
-  v.kk = sh.kk; v.C1 = sh.C1; v.D = sh.D; v.gz = w.gz;
-  return v;
-}
 
 // totals over each 16-lane row, left in every lane of the row
 __device__ __forceinline__ double row_sum_all(double v) {
@@ -343,10 +333,7 @@ __device__ __forceinline__ bool lm4_advance(Lm4Regs& r, Lm4Shared& sh, const Sol
 #pragma unroll
       for (int j = 0; j < 3; ++j) r.cv[j] = sel(valid, cv[j], r.cv[j]);
       r.ct = sel(valid, ct, r.ct);
-      if (valid) {
-        Lm4View v = lm4_view(sh, row);
-        lm_publish_point(v, prm, M, l, r.cv, r.ct);
-      }
+      if (valid) lm_publish_point(win, prm, M, l, r.cv, r.ct);
       r.phase = sel(valid, (int)PH_EVAL_CAND, r.phase);
       go = go || valid;
     }
@@ -356,67 +343,217 @@ __device__ __forceinline__ bool lm4_advance(Lm4Regs& r, Lm4Shared& sh, const Sol
   return go;
 }
 
-// One evaluation of window q at its published point: per-pair moments, class sums, prefix / suffix,
-// 3 x 3 blocks and gradient -- the stages of k_lm<64>, on all 64 lanes.
-__device__ __forceinline__ void lm4_evaluate(Lm4Shared& sh, int q, const PairIn& in0, bool my_ok0, int lane, int M,
-                                             int N, int hsel_q, const BlockRole& br) {
-  Lm4View v = lm4_view(sh, q);
+#ifdef MVO_LM_STAMPS
+// diagnostic build: cycles of workgroup 0 per phase, slots 24..31 of mvo_lm_stamps (24 = turns of the main loop,
+// 25 per-pair stage, 26 tables, 27 unused, 28 blocks + gradient, 29 lm4_advance, 30 prologue, 31 epilogue)
+#define LM4_STAMP(i)                                                \
+  do {                                                              \
+    if (blockIdx.x == 0 && threadIdx.x == 0) {                      \
+      const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+      mvo_lm_stamps[24 + (i)] += now_ - lm4_prev_;                  \
+      lm4_prev_ = now_;                                             \
+    }                                                               \
+  } while (0)
+#define LM4_STAMP_PARAM , unsigned long long& lm4_prev_
+#define LM4_STAMP_ARG , lm4_prev_
+#else
+#define LM4_STAMP(i) do { } while (0)
+#define LM4_STAMP_PARAM
+#define LM4_STAMP_ARG
+#endif
+
+// what a lane does in the stages of an evaluation (fixed for the launch)
+struct Lm4Role {
+  int kT, vT;             // tables: frame k, value v (lanes < 10 M)
+  bool onT;
+  double mT[MVO_MAXM];    // 1.0 for the frames a <= k that exist, else 0.0
+  BlockRole br;           // blocks / gradient
+};
+__device__ __forceinline__ Lm4Role lm4_role(int M, int lane) {
+  Lm4Role ro;
+  ro.kT = lane / 10;
+  ro.vT = lane - 10 * ro.kT;
+  ro.onT = ro.kT < M;  // (M <= 5: lanes >= 50 are off)
+#pragma unroll
+  for (int a = 0; a < MVO_MAXM; ++a) ro.mT[a] = (a <= ro.kT && a < M) ? 1.0 : 0.0;
+  ro.br = block_role(M, lane);
+  return ro;
+}
+
+// One evaluation of the windows QA and QA + 1 at their published points: the stages of k_lm<64> -- per-pair projected
+// moments; class sums, their prefix over a and suffix over j; 3 x 3 blocks and gradient -- for both windows in ONE
+// instruction stream.  Every stage is written loads first, for both windows, then arithmetic, then stores under one
+// predicate, so that the scheduler sees two independent chains in each basic block.
+//
+// Tables (stages 2 and 3 of lm_prefix_suffix in one): lane (k, v) adds up, for every class j, the classes (a, j) of the
+// frames a <= min(k, j) in the order a = 0, 1, ... (= C1[k][j]), then the suffix over j from M down (= D[k][j]); the
+// long class j = M is the sum of the pairs b = M .. N-2 in pair order.  Same operations in the same order as
+// lm_prefix_suffix<true>, one LDS round trip instead of N - M + 2.  Frames a > k take part through a factor 0.0 in a
+// fused multiply-add (exact: C + x * 1 = C + x, C + x * 0 = C), frames a >= M and classes j >= M that do not exist read
+// pair 0 instead (a valid row; their factor is 0.0 / their sum is never used).
+template <int QA>
+__device__ __forceinline__ void lm4_evaluate2(Lm4Shared& sh, const PairIn& inA, const PairIn& inB, bool my_ok0, int lane,
+                                              int M, int N, int hselA, int hselB, const Lm4Role& ro LM4_STAMP_PARAM) {
+  constexpr int NW = LM4_SIDE;
+  // ---- (1) per-pair projected moments ----
   {
-    double o[10], beta[3];
-    free_baseline(v, in0.a, in0.b < M - 1 ? in0.b : M - 1, beta);
-    pair_eval(in0, beta, 0, o);
+    double o[NW][10];
+    const int kmax = inA.b < M - 1 ? inA.b : M - 1;  // (a, b) of a lane's pair are the same in every window
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      double beta[3];
+      free_baseline(sh.win[QA + w], inA.a, kmax, beta);
+      pair_eval(w == 0 ? inA : inB, beta, 0, o[w]);
+    }
     if (my_ok0) {
-      double* __restrict__ dst = sh.pairbuf + lane * 10;
 #pragma unroll
-      for (int e = 0; e < 10; ++e) dst[e] = o[e];
-      if (in0.a == in0.b) {
+      for (int w = 0; w < NW; ++w) {
+        double* __restrict__ dst = sh.ev[w].pairbuf + lane * 10;
 #pragma unroll
-        for (int e = 0; e < 10; ++e) sh.kk[in0.a][e] = o[e];
+        for (int e = 0; e < 10; ++e) dst[e] = o[w][e];
+      }
+      if (inA.a == inA.b) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+#pragma unroll
+          for (int e = 0; e < 10; ++e) sh.ev[w].kk[inA.a][e] = o[w][e];
       }
     }
   }
   wave0_sync();
-  const int jA = lane / 10, vA = lane - 10 * jA;
-  if (lane < MCX * 10) {
-    double x[MVO_MAXM];
-    const int cnt = (jA < M) ? 1 : (jA == M ? N - 1 - M : 0);
-    int rowp[MVO_MAXM];
+  LM4_STAMP(1);
+  // ---- (2) + (3) class sums, prefix over a, suffix over j ----
+  {
+    const int cnt = N - 1 - M;
+    int ra[MVO_MAXM];  // first pair of frame a (wave-uniform)
 #pragma unroll
-    for (int a = 0; a < MVO_MAXM; ++a) {
-      x[a] = 0.0;
-      rowp[a] = (a < M && a <= jA && jA <= M) ? pair_index(N, a, jA) : -1;
-    }
-    for (int i = 0; i < cnt; ++i) {
+    for (int a = 0; a < MVO_MAXM; ++a) ra[a] = a < M ? pair_index(N, a, a) : 0;
+    double x[NW][MVO_MAXM][MVO_MAXM], L[NW][MVO_MAXM];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const double* __restrict__ pb = sh.ev[w].pairbuf + ro.vT;
 #pragma unroll
       for (int a = 0; a < MVO_MAXM; ++a) {
-        const double t = sh.pairbuf[(rowp[a] >= 0 ? rowp[a] + i : 0) * 10 + vA];
-        x[a] += rowp[a] >= 0 ? t : 0.0;
+#pragma unroll
+        for (int j = a; j < MVO_MAXM; ++j) x[w][a][j] = pb[(j < M ? ra[a] + (j - a) : 0) * 10];
+        L[w][a] = 0.0;
       }
     }
-    double acc = 0.0;
+#pragma unroll 4
+    for (int i = 0; i < cnt; ++i) {
 #pragma unroll
-    for (int a = 0; a < MVO_MAXM; ++a) {
-      acc += (a < M && a <= jA && jA <= M) ? x[a] : 0.0;
-      sh.C1[a * MCX + jA][vA] = acc;
+      for (int w = 0; w < NW; ++w)
+#pragma unroll
+        for (int a = 0; a < MVO_MAXM; ++a)
+          L[w][a] += sh.ev[w].pairbuf[((a < M ? ra[a] + (M - a) : 0) + i) * 10 + ro.vT];
+    }
+    double C[NW][MVO_MAXM], acc[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+#pragma unroll
+      for (int j = 0; j < MVO_MAXM; ++j) {
+        double c = 0.0;
+#pragma unroll
+        for (int a = 0; a <= j; ++a) c = fma(x[w][a][j], ro.mT[a], c);
+        C[w][j] = c;
+      }
+      double cl = 0.0;
+#pragma unroll
+      for (int a = 0; a < MVO_MAXM; ++a) cl = fma(L[w][a], ro.mT[a], cl);
+      acc[w] = 0.0 + cl;
+    }
+    if (ro.onT) {
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        Lm4Eval& ev = sh.ev[w];
+        ev.D[ro.kT * MCX + M][ro.vT] = acc[w];
+        double cd = 0.0;  // C1[k][k + 1]
+#pragma unroll
+        for (int j = MVO_MAXM - 1; j >= 0; --j) {
+          if (j < M) {
+            acc[w] += C[w][j];
+            ev.D[ro.kT * MCX + j][ro.vT] = acc[w];
+          }
+          cd = (j == ro.kT + 1) ? C[w][j] : cd;
+        }
+        ev.Cd[ro.kT][ro.vT] = cd;
+        if (ro.kT == M - 1 && ro.vT == 9) sh.win[QA + w].cost = acc[w];  // all classes: D[M-1][0], cost entry
+      }
     }
   }
   wave0_sync();
-  if (lane < MVO_MAXM * 10) {
-    double x[MCX];
+  LM4_STAMP(2);
+  // ---- (4) 3 x 3 blocks of J^T J (lm_block_rows<0>) and the gradient (lm_gradient_entry) ----
+  {
+    const int k4 = ro.br.k4, l4 = ro.br.l4, i4 = ro.br.i4;
+    const bool diag = k4 == l4;
+    const int hs[NW] = {hselA, hselB};
+    double Wv[NW][9], Ts[NW][9], gk[NW][3], Gl[NW][9];
 #pragma unroll
-    for (int j = 0; j < MCX; ++j) x[j] = sh.C1[jA * MCX + j][vA];
-    double acc = 0.0;
+    for (int w = 0; w < NW; ++w) {
+      const Lm4Eval& ev = sh.ev[w];
+      const Lm4Win& win = sh.win[QA + w];
+      const double* __restrict__ wsrc = ev.D[k4 * MCX + (diag ? k4 + 1 : l4)];
+      const double* __restrict__ csrc = ev.Cd[k4 > 0 ? k4 - 1 : 0];
+      const double* __restrict__ ksrc = ev.kk[k4];
 #pragma unroll
-    for (int j = MCX - 1; j >= 0; --j) {
-      acc += x[j];
-      sh.D[jA * MCX + j][vA] = acc;
+      for (int v = 0; v < 9; ++v) {
+        Wv[w][v] = wsrc[v] + ((diag && k4 > 0) ? csrc[v] : 0.0);
+        Ts[w][v] = ksrc[v];
+      }
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr) gk[w][rr] = win.G[k4][3 * rr + i4];
+#pragma unroll
+      for (int e = 0; e < 9; ++e) Gl[w][e] = win.G[l4][e];
     }
-    if (jA == MVO_MAXM - 1 && vA == 9) sh.win[q].cost = acc;  // all classes: prefix over every a, suffix from j = 0
+    if (lane < ro.br.nB4) {
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        double val[3];
+        {
+          double gw[3];  // (G_k^T W)[i][m]
+#pragma unroll
+          for (int m = 0; m < 3; ++m)
+            gw[m] = gk[w][0] * Wv[w][sym6(0, m)] + gk[w][1] * Wv[w][sym6(1, m)] + gk[w][2] * Wv[w][sym6(2, m)];
+#pragma unroll
+          for (int jj = 0; jj < 3; ++jj) val[jj] = gw[0] * Gl[w][jj] + gw[1] * Gl[w][3 + jj] + gw[2] * Gl[w][6 + jj];
+        }
+        {  // the pair (k, k): direction columns only (rows i < 2 of the diagonal blocks)
+          double gw[3];
+#pragma unroll
+          for (int m = 0; m < 3; ++m)
+            gw[m] = gk[w][0] * Ts[w][sym6(0, m)] + gk[w][1] * Ts[w][sym6(1, m)] + gk[w][2] * Ts[w][sym6(2, m)];
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            const double add = val[jj] + (gw[0] * Gl[w][jj] + gw[1] * Gl[w][3 + jj] + gw[2] * Gl[w][6 + jj]);
+            val[jj] = (diag && i4 < 2) ? add : val[jj];
+          }
+        }
+        double* __restrict__ Hw = sh.win[QA + w].H[hs[w] ^ 1];
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj)
+          if (!diag || jj >= i4) {  // diagonal blocks: the upper entry is mirrored, H stays symmetric
+            Hw[(3 * k4 + i4) * MVO_MAXC + 3 * l4 + jj] = val[jj];
+            Hw[(3 * l4 + jj) * MVO_MAXC + 3 * k4 + i4] = val[jj];
+          }
+      }
+    } else if (lane < ro.br.nB4 + 3 * M) {
+      // gradient entry (k, i) = G_k^T y_k, y_k = D[k][k+1] + C1[k-1][k] + (i < 2 ? pair (k, k) : 0), values 6..8
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        double gi = 0.0;
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+          // Wv = D[k][k+1] + (k > 0 ? C1[k-1][k] : 0) as lm_gradient_entry forms it (these lanes have k4 == l4)
+          const double yv = Wv[w][6 + v] + (i4 < 2 ? Ts[w][6 + v] : 0.0);
+          gi += gk[w][v] * yv;
+        }
+        sh.win[QA + w].gz[3 * k4 + i4] = gi;
+      }
+    }
   }
   wave0_sync();
-  lm_block_rows<0>(v, br, lane, sh.win[q].H[hsel_q ^ 1]);
-  lm_gradient_entry(v, lane >= br.nB4 && lane < br.nB4 + 3 * M, br.k4, br.i4);
-  wave0_sync();
+  LM4_STAMP(4);
 }
 
 // Workgroup b solves the windows win_base + 4 b .. + 3 (those below win_end).
@@ -426,6 +563,9 @@ __global__ __launch_bounds__(64) void k_lm4(SolveParams prm, int win_end, int un
                                             LmResult* __restrict__ results, int32_t* __restrict__ win_status,
                                             int32_t* __restrict__ done_count) {
   __shared__ Lm4Shared sh;
+#ifdef MVO_LM_STAMPS
+  unsigned long long lm4_prev_ = __builtin_amdgcn_s_memtime();
+#endif
   const int lane = threadIdx.x, row = lane >> 4, l = lane & 15;
   const int M = prm.M, N = prm.N, P = prm.P;
   const int fix = prm.fix_length;
@@ -479,34 +619,28 @@ __global__ __launch_bounds__(64) void k_lm4(SolveParams prm, int win_end, int un
   r.status = row_exists ? 0 : 1;
   r.phase = PH_EVAL_X0;
   r.xv[0] = x0w[0]; r.xv[1] = x0w[1]; r.xv[2] = x0w[2]; r.xt = x0w[3];  // IR.cpp:95-109
-  {
-    Lm4View v = lm4_view(sh, row);
-    lm_publish_point(v, prm, M, l, r.xv, r.xt);
-  }
+  lm_publish_point(sh.win[row], prm, M, l, r.xv, r.xt);
   wave0_sync();
-  const BlockRole br = block_role(M, lane);
+  const Lm4Role ro = lm4_role(M, lane);
 
   unsigned long long need = __ballot(r.status == 0 && l == 0);  // bit 16 q: window q awaits an evaluation
+  LM4_STAMP(6);
   while (need) {
-    for (int q = 0; q < LM4_WINDOWS; ++q) {
-      if (!((need >> (16 * q)) & 1ull)) continue;
-      // the inputs of window q (q is wave-uniform: scalar selects)
-      PairIn cur = in[0];
-#pragma unroll
-      for (int t = 1; t < LM4_WINDOWS; ++t) {
-        const bool take = q == t;
-#pragma unroll
-        for (int e = 0; e < 7; ++e) cur.S[e] = take ? in[t].S[e] : cur.S[e];
-#pragma unroll
-        for (int e = 0; e < 3; ++e) cur.off[e] = take ? in[t].off[e] : cur.off[e];
-      }
-      const int hsel_q = __builtin_amdgcn_readlane(r.hsel, 16 * q);
-      lm4_evaluate(sh, q, cur, my_ok0, lane, M, N, hsel_q, br);
-    }
+#ifdef MVO_LM_STAMPS
+    if (blockIdx.x == 0 && threadIdx.x == 0) mvo_lm_stamps[24] += 1;
+#endif
+    // two windows at a time; a window of the two that has terminated is evaluated along (nobody reads the result)
+    if (need & 0x00010001ull)
+      lm4_evaluate2<0>(sh, in[0], in[1], my_ok0, lane, M, N, __builtin_amdgcn_readlane(r.hsel, 0),
+                       __builtin_amdgcn_readlane(r.hsel, 16), ro LM4_STAMP_ARG);
+    if (need & 0x0001000100000000ull)
+      lm4_evaluate2<2>(sh, in[2], in[3], my_ok0, lane, M, N, __builtin_amdgcn_readlane(r.hsel, 32),
+                       __builtin_amdgcn_readlane(r.hsel, 48), ro LM4_STAMP_ARG);
     const bool act = (need >> (16 * row)) & 1ull;
     const bool go = lm4_advance(r, sh, prm, M, n, lane, act);
     wave0_sync();
     need = __ballot(go && l == 0);
+    LM4_STAMP(5);
   }
 
   if (row_exists) {
@@ -541,4 +675,5 @@ __global__ __launch_bounds__(64) void k_lm4(SolveParams prm, int win_end, int un
       atomicAdd(done_count, 1);
     }
   }
+  LM4_STAMP(7);
 }
