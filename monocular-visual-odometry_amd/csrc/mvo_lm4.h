@@ -345,17 +345,19 @@ __device__ __forceinline__ bool lm4_advance(Lm4Regs& r, Lm4Shared& sh, const Sol
 
 #ifdef MVO_LM_STAMPS
 // diagnostic build: cycles of workgroup 0 per phase, slots 24..31 of mvo_lm_stamps (24 = turns of the main loop,
-// 25 per-pair stage, 26 tables, 27 unused, 28 blocks + gradient, 29 lm4_advance, 30 prologue, 31 epilogue)
+// 25 per-pair stage, 26 tables, 27 unused, 28 blocks + gradient, 29 lm4_advance, 30 prologue, 31 epilogue); kept in
+// registers and written once at the end (a global read-modify-write per stamp would put an L2 round trip into every phase)
+struct Lm4Stamps {
+  unsigned long long prev, acc[8];
+};
 #define LM4_STAMP(i)                                                \
   do {                                                              \
-    if (blockIdx.x == 0 && threadIdx.x == 0) {                      \
-      const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
-      mvo_lm_stamps[24 + (i)] += now_ - lm4_prev_;                  \
-      lm4_prev_ = now_;                                             \
-    }                                                               \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();   \
+    lm4_st_.acc[(i)] += now_ - lm4_st_.prev;                        \
+    lm4_st_.prev = now_;                                            \
   } while (0)
-#define LM4_STAMP_PARAM , unsigned long long& lm4_prev_
-#define LM4_STAMP_ARG , lm4_prev_
+#define LM4_STAMP_PARAM , Lm4Stamps& lm4_st_
+#define LM4_STAMP_ARG , lm4_st_
 #else
 #define LM4_STAMP(i) do { } while (0)
 #define LM4_STAMP_PARAM
@@ -498,7 +500,8 @@ __device__ __forceinline__ void lm4_evaluate2(Lm4Shared& sh, const PairIn& inA, 
       const double* __restrict__ ksrc = ev.kk[k4];
 #pragma unroll
       for (int v = 0; v < 9; ++v) {
-        Wv[w][v] = wsrc[v] + ((diag && k4 > 0) ? csrc[v] : 0.0);
+        const double cv = csrc[v];  // (loaded by every lane: a load under the condition would be a branch)
+        Wv[w][v] = wsrc[v] + ((diag && k4 > 0) ? cv : 0.0);
         Ts[w][v] = ksrc[v];
       }
 #pragma unroll
@@ -557,6 +560,9 @@ __device__ __forceinline__ void lm4_evaluate2(Lm4Shared& sh, const PairIn& inA, 
 }
 
 // Workgroup b solves the windows win_base + 4 b .. + 3 (those below win_end).
+// MS: 0 = any shape; 5 = windows with M = 5 refined frames and a free length (the reference's usual window,
+// BASELINE configs[2]): M, the 15 unknowns and every "does this frame / class exist" test are compile-time constants.
+template <int MS>
 __global__ __launch_bounds__(64) void k_lm4(SolveParams prm, int win_end, int unit_slots,
                                             const double* __restrict__ frames, const double* __restrict__ init_x,
                                             const PairDev* __restrict__ pairs, const double* partial,
@@ -564,9 +570,16 @@ __global__ __launch_bounds__(64) void k_lm4(SolveParams prm, int win_end, int un
                                             int32_t* __restrict__ done_count) {
   __shared__ Lm4Shared sh;
 #ifdef MVO_LM_STAMPS
-  unsigned long long lm4_prev_ = __builtin_amdgcn_s_memtime();
+  Lm4Stamps lm4_st_;
+  lm4_st_.prev = __builtin_amdgcn_s_memtime();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) lm4_st_.acc[i] = 0;
 #endif
   const int lane = threadIdx.x, row = lane >> 4, l = lane & 15;
+  if constexpr (MS != 0) {  // (prm is this thread's copy: what the host guarantees becomes a constant for every callee)
+    prm.M = MS;
+    prm.fix_length = 0;
+  }
   const int M = prm.M, N = prm.N, P = prm.P;
   const int fix = prm.fix_length;
   const int n = fix ? 2 * M : 3 * M;
@@ -627,7 +640,7 @@ __global__ __launch_bounds__(64) void k_lm4(SolveParams prm, int win_end, int un
   LM4_STAMP(6);
   while (need) {
 #ifdef MVO_LM_STAMPS
-    if (blockIdx.x == 0 && threadIdx.x == 0) mvo_lm_stamps[24] += 1;
+    lm4_st_.acc[0] += 1;
 #endif
     // two windows at a time; a window of the two that has terminated is evaluated along (nobody reads the result)
     if (need & 0x00010001ull)
@@ -676,4 +689,10 @@ __global__ __launch_bounds__(64) void k_lm4(SolveParams prm, int win_end, int un
     }
   }
   LM4_STAMP(7);
+#ifdef MVO_LM_STAMPS
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) mvo_lm_stamps[24 + i] += lm4_st_.acc[i];
+  }
+#endif
 }

