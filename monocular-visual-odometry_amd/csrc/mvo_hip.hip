@@ -915,7 +915,8 @@ hipError_t launch_lm4_range(mvo_hip_context* h, SolveParams prm, uint32_t win0, 
   const uint32_t groups = (win1 - win0 + LM4_WINDOWS - 1) / LM4_WINDOWS;
   // the usual window (five refined frames, free lengths) has a kernel of its own; MVO_HIP_LM_GENERIC: never
   auto kern = prm.M == 5 && !prm.fix_length && !h->env_lm_generic ? k_lm4<5> : k_lm4<0>;
-  hipLaunchKernelGGL(kern, dim3(groups), dim3(64), 0, stream, prm, (int)win1, from_pair_sums ? 1 : 0, h->t.frames,
+  hipLaunchKernelGGL(kern, dim3(groups), dim3(64), 0, stream, prm, (int)win1, from_pair_sums ? 1 : 0,
+                     h->results_on_host ? 1 : 0, h->t.frames,
                      h->t.initx, from_pair_sums ? h->t.pairs_unit : h->t.pairs,
                      from_pair_sums ? h->d_pairsum.as<double>() : h->d_partial.as<double>(),
                      h->results_on_host ? h->h_results : h->d_results, h->d_status,

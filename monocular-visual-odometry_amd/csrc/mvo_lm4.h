@@ -352,7 +352,9 @@ struct Lm4Stamps {
 };
 #define LM4_STAMP(i)                                                \
   do {                                                              \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     \
     const unsigned long long now_ = __builtin_amdgcn_s_memtime();   \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              \
     lm4_st_.acc[(i)] += now_ - lm4_st_.prev;                        \
     lm4_st_.prev = now_;                                            \
   } while (0)
@@ -562,8 +564,9 @@ __device__ __forceinline__ void lm4_evaluate2(Lm4Shared& sh, const PairIn& inA, 
 // Workgroup b solves the windows win_base + 4 b .. + 3 (those below win_end).
 // MS: 0 = any shape; 5 = windows with M = 5 refined frames and a free length (the reference's usual window,
 // BASELINE configs[2]): M, the 15 unknowns and every "does this frame / class exist" test are compile-time constants.
+// host_marks: the result records lie in pinned host memory and the host may poll their marks (few windows).
 template <int MS>
-__global__ __launch_bounds__(64) void k_lm4(SolveParams prm, int win_end, int unit_slots,
+__global__ __launch_bounds__(64) void k_lm4(SolveParams prm, int win_end, int unit_slots, int host_marks,
                                             const double* __restrict__ frames, const double* __restrict__ init_x,
                                             const PairDev* __restrict__ pairs, const double* partial,
                                             LmResult* __restrict__ results, int32_t* __restrict__ win_status,
@@ -656,6 +659,7 @@ __global__ __launch_bounds__(64) void k_lm4(SolveParams prm, int win_end, int un
     LM4_STAMP(5);
   }
 
+  LM4_STAMP(3);
   if (row_exists) {
     LmResult* __restrict__ res = results + w_row;
     if (l < MVO_MAXM) {
@@ -679,15 +683,18 @@ __global__ __launch_bounds__(64) void k_lm4(SolveParams prm, int win_end, int un
       res->nunsucc = r.nunsucc;
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // see k_lm: the record is out before its mark
-  if (row_exists) {
-    if (l == 0) {
-      LmResult* __restrict__ res = results + w_row;
-      __hip_atomic_store(&res->pad, kResultWritten, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      win_status[w_row] = 1;
-      atomicAdd(done_count, 1);
-    }
+  if (host_marks) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // see k_lm: the record is out before its mark
+    if (row_exists && l == 0)
+      __hip_atomic_store(&results[w_row].pad, kResultWritten, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  } else if (row_exists && l == 0) {
+    // records in device memory, copied by the stream behind this kernel: no system-scope release (an L2 write-back per
+    // wavefront, a thousand of them arriving together)
+    results[w_row].pad = kResultWritten;
   }
+  if (row_exists && l == 0) win_status[w_row] = 1;
+  // one count per wavefront: the windows of a batch end together, and 4096 atomics on one address take 17 us
+  if (lane == 0) atomicAdd(done_count, win_end - wbase < LM4_WINDOWS ? win_end - wbase : LM4_WINDOWS);
   LM4_STAMP(7);
 #ifdef MVO_LM_STAMPS
   if (blockIdx.x == 0 && threadIdx.x == 0) {

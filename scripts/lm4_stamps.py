@@ -8,7 +8,7 @@ capi.LIB_PATH = os.path.join(ROOT, "monocular-visual-odometry_amd", "libmvo_hip_
 lib = capi.load()
 lib.mvo_hip_debug_stamps.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 lib.mvo_hip_debug_stamps_lm4.argtypes = [C.POINTER(C.c_ulonglong)]
-names = ["turns", "per-pair", "tables", "-", "blocks+gradient", "advance", "prologue", "epilogue"]
+names = ["turns", "per-pair", "tables", "loop exit", "blocks+gradient", "advance", "prologue", "epilogue"]
 fixed = dict(max_num_iterations=10, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 ws = [scene.config3_window(i) for i in range(W)]
@@ -22,4 +22,4 @@ with capi.Solver(0) as s:
     lib.mvo_hip_debug_stamps_lm4(b)
     n = max(1, b[0])
     print("k_lm4,", W, "windows: turns", b[0], " cycles per turn (4 windows evaluated + one step):",
-          {names[i]: b[i] // n for i in range(1, 6)}, "total", sum(b[1:6]) // n, " per launch: prologue", b[6], "epilogue", b[7])
+          {names[i]: b[i] // n for i in range(1, 6)}, "total", (sum(b[1:6]) - b[3]) // n, " per launch: prologue", b[6], "loop exit", b[3], "epilogue", b[7])
