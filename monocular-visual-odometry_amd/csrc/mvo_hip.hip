@@ -215,6 +215,9 @@ struct mvo_hip_context {
   std::vector<double> v_initx;
   std::vector<int32_t> v_clamped;  // per window: bit 2k = scale_k clamped low, bit 2k+1 = high (IR.cpp:350-363)
   bool lm_started = false;  // false until the first k_lm launch of the current solve
+  bool lm4_marked = false;  // the current solve is one k_lm4 launch whose completion is read off the records' marks
+  int32_t lm4_mark = 0;
+  uint32_t lm4_seq = 0;
   // The done counter is never cleared between solves: a solve is complete when it has advanced by W
   // past done_base (one fill less per solve).  done_ready = the counter holds done_base.
   uint32_t done_base = 0;
@@ -406,6 +409,7 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
   HIP_TRY(hipSetDevice(h->device));
   h->uploaded = false;
   h->solved = false;
+  h->lm4_marked = false;
   h->sums_external = false;
   const uint32_t P = num_pairs(M, N);
   h->W = W;
@@ -908,19 +912,21 @@ bool lm4_eligible(const mvo_hip_context* h) {
   const double rounds1 = std::ceil(h->W / slots), rounds4 = std::ceil(h->W / (4.0 * slots));
   return rounds1 > 1.35 * rounds4;
 }
+// marks_only: the launch covers every window of the solve and nothing else counts them: completion is checked on the
+// records' marks (h->lm4_mark, new for every solve) instead of the done counter
 hipError_t launch_lm4_range(mvo_hip_context* h, SolveParams prm, uint32_t win0, uint32_t win1, hipStream_t stream,
-                            bool from_pair_sums) {
+                            bool from_pair_sums, bool marks_only = false) {
   prm.fresh = 1;
   prm.win_base = (int32_t)win0;
   const uint32_t groups = (win1 - win0 + LM4_WINDOWS - 1) / LM4_WINDOWS;
   // the usual window (five refined frames, free lengths) has a kernel of its own; MVO_HIP_LM_GENERIC: never
   auto kern = prm.M == 5 && !prm.fix_length && !h->env_lm_generic ? k_lm4<5> : k_lm4<0>;
   hipLaunchKernelGGL(kern, dim3(groups), dim3(64), 0, stream, prm, (int)win1, from_pair_sums ? 1 : 0,
-                     h->results_on_host ? 1 : 0, h->t.frames,
+                     h->results_on_host ? 1 : 0, marks_only ? h->lm4_mark : kResultWritten, h->t.frames,
                      h->t.initx, from_pair_sums ? h->t.pairs_unit : h->t.pairs,
                      from_pair_sums ? h->d_pairsum.as<double>() : h->d_partial.as<double>(),
                      h->results_on_host ? h->h_results : h->d_results, h->d_status,
-                     h->d_done);
+                     marks_only ? (int32_t*)nullptr : h->d_done);
   return hipGetLastError();
 }
 
@@ -990,6 +996,7 @@ int partial_begin(mvo_hip_context* h) {
   h->done_base = 0;
   h->done_ready = false;  // until this partitioned solve has been seen to complete (it may be abandoned)
   h->solved = false;
+  h->lm4_marked = false;
   {
     int rc = clean_tickets(h);
     if (rc == MVO_HIP_OK) rc = partial_reserve(h);
@@ -1062,6 +1069,7 @@ int do_solve_partitioned(mvo_hip_context* h) {
   if (h->trace_cap > 0) HIP_TRY(h->d_trace.reserve(sizeof(TraceRec) * (size_t)h->trace_cap));
   h->lm_started = false;
   h->solved = false;
+  h->lm4_marked = false;
   HIP_TRY(hipMemsetAsync(h->d_status, 0, (size_t)((char*)h->d_done - (char*)h->d_status) + 16, s));
   h->done_base = 0;
   h->done_ready = false;
@@ -1186,6 +1194,7 @@ int do_solve(mvo_hip_context* h) {
   }
   h->done_ready = false;  // until this solve has been seen to complete
   h->solved = false;
+  h->lm4_marked = false;
   const uint32_t done_base = h->done_base;
   // Up to 64 windows the result records (208 B each) are written by k_lm straight into the pinned host
   // mirror: one command less on the stream (~4 us of a 45-us default-size solve).
@@ -1262,7 +1271,10 @@ int do_solve(mvo_hip_context* h) {
       ++asm_launches;
     }
     if (lm4_eligible(h) && fold_blocks) {
-      HIP_TRY(launch_lm4_range(h, prm, 0, h->W, s, true));
+      // (records polled in the host mirror carry the fixed mark: the host clears them before every solve)
+      h->lm4_marked = !h->results_on_host;
+      if (h->lm4_marked) h->lm4_mark = kResultWritten + 0x10000 * (int32_t)(1 + (h->lm4_seq++ & 0xfff));
+      HIP_TRY(launch_lm4_range(h, prm, 0, h->W, s, true, h->lm4_marked));
       h->lm_started = true;
     } else {
       HIP_TRY(launch_lm_any(h, prm, fold_blocks != 0 || h->sums_external));
@@ -1352,7 +1364,12 @@ int do_solve(mvo_hip_context* h) {
     HIP_TRY(hipMemcpyAsync(h->h_ctl, h->d_done, 16 + sizeof(LmResult) * h->W, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     h->copy_pending = false;
-    if ((uint32_t)h->h_done[0] - done_base != h->W) {
+    if (h->lm4_marked) {
+      // k_lm4 over the whole batch counts nothing (launch_lm4_range): every record must carry this solve's mark
+      for (uint32_t w = 0; w < h->W; ++w)
+        if (h->h_results[w].pad != h->lm4_mark) return MVO_HIP_ERR_DEVICE;
+      h->h_done[0] = (int32_t)done_base;  // (the counter did not move)
+    } else if ((uint32_t)h->h_done[0] - done_base != h->W) {
       if (h->persistent_in_flight) return persistent_fallback(h);
       return MVO_HIP_ERR_DEVICE;  // every window must have terminated
     }

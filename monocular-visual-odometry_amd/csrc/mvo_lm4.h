@@ -565,8 +565,12 @@ __device__ __forceinline__ void lm4_evaluate2(Lm4Shared& sh, const PairIn& inA, 
 // MS: 0 = any shape; 5 = windows with M = 5 refined frames and a free length (the reference's usual window,
 // BASELINE configs[2]): M, the 15 unknowns and every "does this frame / class exist" test are compile-time constants.
 // host_marks: the result records lie in pinned host memory and the host may poll their marks (few windows).
+// mark: what a finished window's record carries in `pad`.  done_count may be null: then the marks are the only
+// completion signal (the host passes a new mark every solve and checks every record after the copy) -- the windows of
+// a batch end together, and a thousand wavefronts' atomics on ONE address take 6 us at the end of the kernel (four
+// thousand, one per window: 17 us).
 template <int MS>
-__global__ __launch_bounds__(64) void k_lm4(SolveParams prm, int win_end, int unit_slots, int host_marks,
+__global__ __launch_bounds__(64) void k_lm4(SolveParams prm, int win_end, int unit_slots, int host_marks, int mark,
                                             const double* __restrict__ frames, const double* __restrict__ init_x,
                                             const PairDev* __restrict__ pairs, const double* partial,
                                             LmResult* __restrict__ results, int32_t* __restrict__ win_status,
@@ -686,15 +690,15 @@ __global__ __launch_bounds__(64) void k_lm4(SolveParams prm, int win_end, int un
   if (host_marks) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // see k_lm: the record is out before its mark
     if (row_exists && l == 0)
-      __hip_atomic_store(&results[w_row].pad, kResultWritten, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&results[w_row].pad, mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   } else if (row_exists && l == 0) {
     // records in device memory, copied by the stream behind this kernel: no system-scope release (an L2 write-back per
     // wavefront, a thousand of them arriving together)
-    results[w_row].pad = kResultWritten;
+    results[w_row].pad = mark;
   }
   if (row_exists && l == 0) win_status[w_row] = 1;
-  // one count per wavefront: the windows of a batch end together, and 4096 atomics on one address take 17 us
-  if (lane == 0) atomicAdd(done_count, win_end - wbase < LM4_WINDOWS ? win_end - wbase : LM4_WINDOWS);
+  if (done_count != nullptr && lane == 0)
+    atomicAdd(done_count, win_end - wbase < LM4_WINDOWS ? win_end - wbase : LM4_WINDOWS);
   LM4_STAMP(7);
 #ifdef MVO_LM_STAMPS
   if (blockIdx.x == 0 && threadIdx.x == 0) {
