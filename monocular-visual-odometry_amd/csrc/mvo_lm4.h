@@ -21,7 +21,7 @@
 
 constexpr int LM4_WINDOWS = 4;
 
-struct Lm4Win {  // one window, kept across evaluations
+struct alignas(16) Lm4Win {  // one window, kept across evaluations
   double zvec[MVO_MAXM][3], zt[MVO_MAXM], zs[MVO_MAXM], zsp[MVO_MAXM];
   double G[MVO_MAXM][9];
   double H[2][MVO_MAXC * MVO_MAXC];  // the accepted system and the one assembled at z (roles swap: hsel)
@@ -31,7 +31,7 @@ struct Lm4Win {  // one window, kept across evaluations
 
 // scratch of ONE evaluation.  Two of them: the windows are evaluated two at a time, side by side in one instruction
 // stream (lm4_evaluate2), so that one window's LDS round trips and dependent fp64 chains run under the other's.
-struct Lm4Eval {
+struct alignas(16) Lm4Eval {     // (rows of ten doubles: every row starts on a 16-byte boundary)
   double kk[MVO_MAXM][10];       // pair (k, k)
   double Cd[MVO_MAXM][10];       // C1[k][k + 1] of lm_prefix_suffix: what the diagonal blocks add to D[k][k + 1]
   double D[MVO_MAXM * MCX][10];  // D[k][j] = sum_{a <= k} sum_{j' >= j} class (a, j')
@@ -39,7 +39,7 @@ struct Lm4Eval {
 };
 constexpr int LM4_SIDE = 2;
 
-struct Lm4Shared {
+struct alignas(16) Lm4Shared {
   Lm4Win win[LM4_WINDOWS];
   Lm4Eval ev[LM4_SIDE];
 };
@@ -492,16 +492,19 @@ __device__ __forceinline__ void lm4_evaluate2(Lm4Shared& sh, const PairIn& inA, 
     const int k4 = ro.br.k4, l4 = ro.br.l4, i4 = ro.br.i4;
     const bool diag = k4 == l4;
     const int hs[NW] = {hselA, hselB};
-    double Wv[NW][9], Ts[NW][9], gk[NW][3], Gl[NW][9];
+    // a block-row lane reads the values 0..5 of its rows (the moments), a gradient lane 6..8 (P S u): six loads from a
+    // lane-dependent offset (a gradient lane's last three run into the next row -- inside Lm4Eval -- and are ignored)
+    const int vo = lane < ro.br.nB4 ? 0 : 6;
+    double Wv[NW][6], Ts[NW][6], gk[NW][3], Gl[NW][9];
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
       const Lm4Eval& ev = sh.ev[w];
       const Lm4Win& win = sh.win[QA + w];
-      const double* __restrict__ wsrc = ev.D[k4 * MCX + (diag ? k4 + 1 : l4)];
-      const double* __restrict__ csrc = ev.Cd[k4 > 0 ? k4 - 1 : 0];
-      const double* __restrict__ ksrc = ev.kk[k4];
+      const double* __restrict__ wsrc = ev.D[k4 * MCX + (diag ? k4 + 1 : l4)] + vo;
+      const double* __restrict__ csrc = ev.Cd[k4 > 0 ? k4 - 1 : 0] + vo;
+      const double* __restrict__ ksrc = ev.kk[k4] + vo;
 #pragma unroll
-      for (int v = 0; v < 9; ++v) {
+      for (int v = 0; v < 6; ++v) {
         const double cv = csrc[v];  // (loaded by every lane: a load under the condition would be a branch)
         Wv[w][v] = wsrc[v] + ((diag && k4 > 0) ? cv : 0.0);
         Ts[w][v] = ksrc[v];
@@ -550,7 +553,7 @@ __device__ __forceinline__ void lm4_evaluate2(Lm4Shared& sh, const PairIn& inA, 
 #pragma unroll
         for (int v = 0; v < 3; ++v) {
           // Wv = D[k][k+1] + (k > 0 ? C1[k-1][k] : 0) as lm_gradient_entry forms it (these lanes have k4 == l4)
-          const double yv = Wv[w][6 + v] + (i4 < 2 ? Ts[w][6 + v] : 0.0);
+          const double yv = Wv[w][v] + (i4 < 2 ? Ts[w][v] : 0.0);
           gi += gk[w][v] * yv;
         }
         sh.win[QA + w].gz[3 * k4 + i4] = gi;
