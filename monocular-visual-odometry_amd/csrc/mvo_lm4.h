@@ -250,8 +250,10 @@ __device__ __forceinline__ bool lm4_advance(Lm4Regs& r, Lm4Shared& sh, const Sol
     r.hsel = sel(take_z, r.hsel ^ 1, r.hsel);
     r.g = sel(take_z, l < n ? gz : 0.0, r.g);
     r.hdiag = sel(take_z, l < n ? hd : 0.0, r.hdiag);
-    const double js0 = 1.0 / (1.0 + sqrt(fmax(r.hdiag, 0.0)));  // jacobi_scaling, fixed at iteration 0
-    r.js = sel(init0, js0, r.js);
+    if (__any(init0)) {  // (a square root and a division: only in the turn that follows a row's first evaluation)
+      const double js0 = 1.0 / (1.0 + sqrt(fmax(r.hdiag, 0.0)));  // jacobi_scaling, fixed at iteration 0
+      r.js = sel(init0, js0, r.js);
+    }
     // gradient_max_norm = || x - Plus(x, -g) ||_inf
     double pv[3], pt;
     frames_plus4(lane, M, fix, r.xv, r.xt, r.g, -1.0, pv, pt);
