@@ -18,6 +18,12 @@
 
 #define FOLD_THREADS 256
 #define FOLD_WAVES 4
+#ifndef FOLD_BATCH
+#define FOLD_BATCH 6
+#endif
+#ifndef PASS_BATCH
+#define PASS_BATCH 4
+#endif
 
 // ---------------------------------------------------------------------------------------
 // Work decomposition of the observation passes.  The host cuts the flat residual-block range
@@ -264,35 +270,53 @@ __global__ __launch_bounds__(FOLD_THREADS) void k_fold(const TileDev* __restrict
       double S[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       double prod = 1.0;     // PASS0 == 2: running product of (1 + 4 r^2) of this lane
       int32_t prod_exp = 0;  // exponent split off so far
-      for (uint32_t i0 = lane; i0 < tl.count; i0 += 64 * 128) {
-        const uint32_t i1 = (tl.count - i0) > 64 * 128 ? i0 + 64 * 128 : tl.count;
-#pragma unroll 4
-        for (uint32_t i = i0; i < i1; i += 64) {
-          const double x0 = p0[3 * i], y0 = p0[3 * i + 1], z0 = p0[3 * i + 2];
-          const double x1 = p1[3 * i], y1 = p1[3 * i + 1], z1 = p1[3 * i + 2];
-          const double px = a0 * x0 + a1 * y0 + a2 * z0;  // R0 * m0
-          const double py = a3 * x0 + a4 * y0 + a5 * z0;
-          const double pz = a6 * x0 + a7 * y0 + a8 * z0;
-          const double qx = b0 * x1 + b1 * y1 + b2 * z1;  // R1 * m1
-          const double qy = b3 * x1 + b4 * y1 + b5 * z1;
-          const double qz = b6 * x1 + b7 * y1 + b8 * z1;
-          const double vx = py * qz - pz * qy;  // c = p x q
-          const double vy = pz * qx - px * qz;
-          const double vz = px * qy - py * qx;
-          if (WRITE_C) {
-            cx[i] = vx;
-            cy[i] = vy;
-            cz[i] = vz;
+      // BATCH residual blocks per lane and trip, every load of a trip issued before the first use: a tile costs
+      // ceil(count / (64 BATCH)) memory round trips (a remainder loop of single iterations costs one EACH).  Slots
+      // past the tile's end re-read the lane's first block of the trip (an L1 hit) and are left out of the sums.
+      // (64-bit indices: with 32-bit ones 3 * i may wrap as far as the compiler knows, and it then neither merges a
+      // ray's three 8-byte loads into a 16- and an 8-byte one nor addresses the slots off one base)
+      // (the variants that are also a pass carry more state: four slots keep them at four wavefronts per SIMD, which
+      // the one-round launch geometry assumes)
+      constexpr int BATCH = PASS0 ? 4 : FOLD_BATCH;
+      for (size_t i0 = lane; i0 < tl.count; i0 += 64 * 128) {
+        const size_t i1 = (tl.count - i0) > 64 * 128 ? i0 + 64 * 128 : tl.count;
+        for (size_t i = i0; i < i1; i += 64 * BATCH) {
+          double x0[BATCH], y0[BATCH], z0[BATCH], x1[BATCH], y1[BATCH], z1[BATCH];
+#pragma unroll
+          for (int u = 0; u < BATCH; ++u) {
+            const size_t j = i + 64 * u < i1 ? i + 64 * u : i;
+            x0[u] = p0[3 * j]; y0[u] = p0[3 * j + 1]; z0[u] = p0[3 * j + 2];
+            x1[u] = p1[3 * j]; y1[u] = p1[3 * j + 1]; z1[u] = p1[3 * j + 2];
           }
-          if (MOMENTS) {
-            S[0] += vx * vx;
-            S[1] += vx * vy;
-            S[2] += vx * vz;
-            S[3] += vy * vy;
-            S[4] += vy * vz;
-            S[5] += vz * vz;
+#pragma unroll
+          for (int u = 0; u < BATCH; ++u) {
+            const bool on = i + 64 * u < i1;
+            const double px = a0 * x0[u] + a1 * y0[u] + a2 * z0[u];  // R0 * m0
+            const double py = a3 * x0[u] + a4 * y0[u] + a5 * z0[u];
+            const double pz = a6 * x0[u] + a7 * y0[u] + a8 * z0[u];
+            const double qx = b0 * x1[u] + b1 * y1[u] + b2 * z1[u];  // R1 * m1
+            const double qy = b3 * x1[u] + b4 * y1[u] + b5 * z1[u];
+            const double qz = b6 * x1[u] + b7 * y1[u] + b8 * z1[u];
+            const double vx = py * qz - pz * qy;  // c = p x q
+            const double vy = pz * qx - px * qz;
+            const double vz = px * qy - py * qx;
+            if (on) {
+              if (WRITE_C) {
+                cx[i + 64 * u] = vx;
+                cy[i + 64 * u] = vy;
+                cz[i + 64 * u] = vz;
+              }
+              if (MOMENTS) {
+                S[0] += vx * vx;
+                S[1] += vx * vy;
+                S[2] += vx * vz;
+                S[3] += vy * vy;
+                S[4] += vy * vz;
+                S[5] += vz * vz;
+              }
+              if (PASS0) pass_accum<PASS0 == 2>(vx, vy, vz, u0, u1, u2, S, prod);
+            }
           }
-          if (PASS0) pass_accum<PASS0 == 2>(vx, vy, vz, u0, u1, u2, S, prod);
         }
         if (PASS0 == 2) {  // <= 128 factors <= 5 since the last split: far from overflow
           int e;
@@ -345,16 +369,26 @@ __device__ __forceinline__ void pass_wave_tiles(const TileDev* tiles, const uint
       const uint32_t len = tl.count + head;
       double prod = 1.0;     // running product of (1 + 4 r^2) of this lane
       int32_t prod_exp = 0;  // exponent split off so far
-      for (uint32_t i0 = 2 * lane; i0 < len; i0 += 128 * 64) {
-        const uint32_t i1 = (len - i0) > 128 * 64 ? i0 + 128 * 64 : len;
-#pragma unroll 2
-        for (uint32_t i = i0; i < i1; i += 128) {
-          const double2 x = *reinterpret_cast<const double2*>(cx + i);
-          const double2 y = *reinterpret_cast<const double2*>(cy + i);
-          const double2 z = *reinterpret_cast<const double2*>(cz + i);
-          const bool v0 = i >= head, v1 = (i + 1) < len;  // neighbours' elements and pads are not data
-          pass_accum<ROBUST>(v0 ? x.x : 0.0, v0 ? y.x : 0.0, v0 ? z.x : 0.0, u0, u1, u2, S, prod);
-          pass_accum<ROBUST>(v1 ? x.y : 0.0, v1 ? y.y : 0.0, v1 ? z.y : 0.0, u0, u1, u2, S, prod);
+      // PASS_BATCH x two elements per lane and trip, every load of a trip issued before the first use (see k_fold);
+      // slots past the tile's end re-read the lane's first pair of the trip and enter as zeros (no-ops of pass_accum)
+      for (size_t i0 = 2 * lane; i0 < len; i0 += 128 * 64) {
+        const size_t i1 = (len - i0) > 128 * 64 ? i0 + 128 * 64 : len;
+        for (size_t i = i0; i < i1; i += 128 * PASS_BATCH) {
+          double2 x[PASS_BATCH], y[PASS_BATCH], z[PASS_BATCH];
+#pragma unroll
+          for (int u = 0; u < PASS_BATCH; ++u) {
+            const size_t j = i + 128 * u < i1 ? i + 128 * u : i;
+            x[u] = *reinterpret_cast<const double2*>(cx + j);
+            y[u] = *reinterpret_cast<const double2*>(cy + j);
+            z[u] = *reinterpret_cast<const double2*>(cz + j);
+          }
+#pragma unroll
+          for (int u = 0; u < PASS_BATCH; ++u) {
+            const size_t j = i + 128 * u;
+            const bool v0 = j >= head && j < i1, v1 = (j + 1) < len;  // neighbours' elements and pads are not data
+            pass_accum<ROBUST>(v0 ? x[u].x : 0.0, v0 ? y[u].x : 0.0, v0 ? z[u].x : 0.0, u0, u1, u2, S, prod);
+            pass_accum<ROBUST>(v1 ? x[u].y : 0.0, v1 ? y[u].y : 0.0, v1 ? z[u].y : 0.0, u0, u1, u2, S, prod);
+          }
         }
         if (ROBUST) {  // <= 128 factors <= 5 since the last split: far from overflow
           int e;

@@ -6,6 +6,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -o fold_variants scripts/exp/fold_variants.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("hip error %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
@@ -87,8 +88,9 @@ __global__ __launch_bounds__(256) void kD(const double* m0, const double* m1, si
   if (lane == 0) out[gw] = t;
 }
 
-int main() {
-  const size_t n = 9830400;  // ~config 4, multiple of 128 * 4096
+int main(int argc, char** argv) {
+  // ~config 4 (multiple of 128 * 4096); `fold_variants 4` = four times that: ~config 3, 1.9 GB
+  const size_t n = 9830400 * (size_t)(argc > 1 ? atoi(argv[1]) : 1);
   const size_t waves = 4096, chunk = n / waves;
   std::vector<double> h(3 * n);
   for (size_t i = 0; i < 3 * n; ++i) h[i] = 0.001 * (double)((i * 2654435761u) % 1000) - 0.5;
