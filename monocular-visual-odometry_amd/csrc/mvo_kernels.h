@@ -19,10 +19,10 @@
 #define FOLD_THREADS 256
 #define FOLD_WAVES 4
 #ifndef FOLD_BATCH
-#define FOLD_BATCH 6
+#define FOLD_BATCH 4
 #endif
 #ifndef PASS_BATCH
-#define PASS_BATCH 4
+#define PASS_BATCH 1
 #endif
 
 // ---------------------------------------------------------------------------------------
@@ -275,9 +275,9 @@ __global__ __launch_bounds__(FOLD_THREADS) void k_fold(const TileDev* __restrict
       // past the tile's end re-read the lane's first block of the trip (an L1 hit) and are left out of the sums.
       // (64-bit indices: with 32-bit ones 3 * i may wrap as far as the compiler knows, and it then neither merges a
       // ray's three 8-byte loads into a 16- and an 8-byte one nor addresses the slots off one base)
-      // (the variants that are also a pass carry more state: four slots keep them at four wavefronts per SIMD, which
-      // the one-round launch geometry assumes)
-      constexpr int BATCH = PASS0 ? 4 : FOLD_BATCH;
+      // (4, 5, 6, 7 slots measured alike at every size; more than four would push the variants that are also a pass
+      // over 128 registers, and the one-round launch geometry assumes four wavefronts per SIMD)
+      constexpr int BATCH = FOLD_BATCH;
       for (size_t i0 = lane; i0 < tl.count; i0 += 64 * 128) {
         const size_t i1 = (tl.count - i0) > 64 * 128 ? i0 + 64 * 128 : tl.count;
         for (size_t i = i0; i < i1; i += 64 * BATCH) {
