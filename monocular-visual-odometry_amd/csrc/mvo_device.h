@@ -87,9 +87,8 @@ struct LmState {
                             // ignored and HandleInvalidStep runs instead of the verdict (lm_decide)
 };
 
-struct LmResult {
+struct LmResult {  // (200 B: what crosses PCIe per window and what the host's write-back loop reads -- nothing it does not use)
   double vec[MVO_MAXM][3];
-  double t[MVO_MAXM];
   double scale[MVO_MAXM];  // s(t): the write-back value of IR.cpp:240-246, so that a download is a copy
   double initial_cost, final_cost;
   int32_t termination, reason, iterations, nsucc, nunsucc, pad;  // pad = kResultWritten once written

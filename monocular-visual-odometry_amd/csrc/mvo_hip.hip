@@ -1432,6 +1432,14 @@ int do_download(mvo_hip_context* h, mvo_hip_frame* frames, mvo_hip_summary* summ
   if (!h->uploaded || !h->solved) return MVO_HIP_ERR_STATE;  // nothing solved yet: the result records are stale
   for (uint32_t w = 0; w < h->W; ++w) {
     const LmResult& r = h->h_results[w];
+    // (the records were just written by the copy engine or the GPU: every line is a miss; ask for them ahead)
+    if (w + 8 < h->W) {
+      const char* nx = reinterpret_cast<const char*>(&h->h_results[w + 8]);
+      __builtin_prefetch(nx);
+      __builtin_prefetch(nx + 64);
+      __builtin_prefetch(nx + 128);
+      __builtin_prefetch(nx + 192);
+    }
     if (frames) {
       // IR.cpp:240-246: refined frames get scale = s(t) and the optimised direction
       for (uint32_t k = 0; k < h->M; ++k) {

@@ -1907,7 +1907,6 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
       res->vec[lane][0] = usable ? st.b_vec[lane][0] : x0[0];
       res->vec[lane][1] = usable ? st.b_vec[lane][1] : x0[1];
       res->vec[lane][2] = usable ? st.b_vec[lane][2] : x0[2];
-      res->t[lane] = bt;
       res->scale[lane] = d_scale(bt, prm.max_len, prm.min_len);
     }
     if (lane == 0) {

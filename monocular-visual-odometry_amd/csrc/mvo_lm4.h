@@ -679,7 +679,6 @@ __global__ __launch_bounds__(64) void k_lm4(SolveParams prm, int win_end, int un
       res->vec[l][0] = usable ? r.bv[0] : x0w[0];
       res->vec[l][1] = usable ? r.bv[1] : x0w[1];
       res->vec[l][2] = usable ? r.bv[2] : x0w[2];
-      res->t[l] = bt;
       res->scale[l] = d_scale(bt, prm.max_len, prm.min_len);
     }
     if (l == 0) {
