@@ -1366,8 +1366,10 @@ int do_solve(mvo_hip_context* h) {
     h->copy_pending = false;
     if (h->lm4_marked) {
       // k_lm4 over the whole batch counts nothing (launch_lm4_range): every record must carry this solve's mark
-      for (uint32_t w = 0; w < h->W; ++w)
+      for (uint32_t w = 0; w < h->W; ++w) {
+        if (w + 16 < h->W) __builtin_prefetch(&h->h_results[w + 16].pad);  // (freshly copied: every record is a miss)
         if (h->h_results[w].pad != h->lm4_mark) return MVO_HIP_ERR_DEVICE;
+      }
       h->h_done[0] = (int32_t)done_base;  // (the counter did not move)
     } else if ((uint32_t)h->h_done[0] - done_base != h->W) {
       if (h->persistent_in_flight) return persistent_fallback(h);
@@ -1439,6 +1441,8 @@ int do_download(mvo_hip_context* h, mvo_hip_frame* frames, mvo_hip_summary* summ
       __builtin_prefetch(nx + 64);
       __builtin_prefetch(nx + 128);
       __builtin_prefetch(nx + 192);
+      if (frames)  // ... and the caller's frame records, which are written in part (lines to be owned first)
+        for (uint32_t k = 0; k < h->M; ++k) __builtin_prefetch(&frames[(size_t)(w + 8) * h->N + k].vec[0], 1);
     }
     if (frames) {
       // IR.cpp:240-246: refined frames get scale = s(t) and the optimised direction
