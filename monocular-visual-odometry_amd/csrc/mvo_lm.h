@@ -814,9 +814,15 @@ __device__ __forceinline__ void lm_block_rows(SH& sh, const BlockRole& br, int l
     const bool diag = WHICH == 0 ? k4 == l4 : WHICH == 1;
     const double* __restrict__ wsrc = sh.D[k4 * MCX + (diag ? k4 + 1 : l4)];
     const double* __restrict__ csrc = sh.C1[(k4 > 0 ? k4 - 1 : 0) * MCX + k4];
-    double Wv[6], gk[3], Gl[9];
+    // every load of the stage up front, unconditionally: a load under a lane's condition is a branch, and each such
+    // region is an LDS round trip of its own behind the previous one
+    double Wv[6], gk[3], Gl[9], Ts[6];
 #pragma unroll
-    for (int v = 0; v < 6; ++v) Wv[v] = wsrc[v] + ((diag && k4 > 0) ? csrc[v] : 0.0);
+    for (int v = 0; v < 6; ++v) {
+      const double cv = csrc[v];
+      Wv[v] = wsrc[v] + ((diag && k4 > 0) ? cv : 0.0);
+      Ts[v] = (WHICH == 2) ? 0.0 : sh.kk[k4][v];  // (the pair (k, k): only the diagonal blocks use it)
+    }
 #pragma unroll
     for (int rr = 0; rr < 3; ++rr) gk[rr] = sh.G[k4][3 * rr + i4];
 #pragma unroll
@@ -830,7 +836,6 @@ __device__ __forceinline__ void lm_block_rows(SH& sh, const BlockRole& br, int l
       for (int jj = 0; jj < 3; ++jj) val[jj] = gw[0] * Gl[jj] + gw[1] * Gl[3 + jj] + gw[2] * Gl[6 + jj];
     }
     if (diag && i4 < 2) {  // the pair (k,k): direction columns only
-      const double* Ts = sh.kk[k4];
       double gw[3];
 #pragma unroll
       for (int m = 0; m < 3; ++m) gw[m] = gk[0] * Ts[sym6(0, m)] + gk[1] * Ts[sym6(1, m)] + gk[2] * Ts[sym6(2, m)];
@@ -855,7 +860,8 @@ __device__ __forceinline__ void lm_gradient_entry(SH& sh, bool on, int k4, int i
     double gi = 0.0;
 #pragma unroll
     for (int v = 0; v < 3; ++v) {
-      const double yv = dk[6 + v] + (k4 > 0 ? ck[6 + v] : 0.0) + (i4 < 2 ? sh.kk[k4][6 + v] : 0.0);
+      const double cv = ck[6 + v], kv = sh.kk[k4][6 + v];  // (loaded by every lane: see lm_block_rows)
+      const double yv = dk[6 + v] + (k4 > 0 ? cv : 0.0) + (i4 < 2 ? kv : 0.0);
       gi += sh.G[k4][3 * v + i4] * yv;
     }
     sh.gz[3 * k4 + i4] = gi;
