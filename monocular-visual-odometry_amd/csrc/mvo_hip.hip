@@ -195,6 +195,14 @@ struct mvo_hip_context {
   bool env_persistent_test_fail = false;
   bool persistent_failed = false;  // a persistent launch ended without a result once: not tried again on this handle
   bool persistent_in_flight = false;
+  // fold + LM loop as one launch (k_lm<256, 7>): MVO_HIP_NO_FUSED keeps them apart; so does a handle on which such a
+  // launch once ended without a result.  fused_count: what the device's count of finished pairs reads before a launch
+  // (it is never reset on the device; d_grid word 16, error word 48 -- words 0 / 32 belong to the persistent solver,
+  // whose launches clear the whole block)
+  bool env_no_fused = false, env_fused_test_fail = false;
+  bool fused_failed = false, fused_in_flight = false;
+  uint32_t fused_count = 0;
+  bool fused_ready = false;  // d_grid exists and holds fused_count
   int n_cus = 0;
   // d_ctl = [window status: W int32, padded][done counter: 4 int32][results: W LmResult];
   // the last two are mirrored in pinned host memory by one copy
@@ -756,7 +764,7 @@ hipError_t launch_fold(mvo_hip_context* h, bool write_c, bool fused = false) {
   int32_t* ticket = tails ? h->d_pticket.as<int32_t>() : nullptr;
   double* pairsum = h->d_pairsum.as<double>();
   const bool pass0 = write_c && fused;
-  const PassOut po{h->t.pair_u0, pass0 ? h->d_proj.as<double>() : nullptr, 0};
+  const PassOut po{h->t.pair_u0, pass0 ? h->d_proj.as<double>() : nullptr, 0, 0};
 #define MVO_FOLD_ARGS(cbuf, celems) \
   h->t.tiles, h->t.wave_tiles, h->n_waves, h->t.frames, h->t.m0, h->t.m1, cbuf, celems, h->d_partial.as<double>(), \
       ticket, h->t.pairs, pairsum, po
@@ -784,7 +792,7 @@ hipError_t launch_pass(mvo_hip_context* h, bool fused = false) {
   if (!blocks) return hipSuccess;
   const bool tails = fused && !h->env_no_tails;
   int32_t* ticket = tails ? h->d_pticket.as<int32_t>() : nullptr;
-  const PassOut po{h->d_pair_u.as<double>(), fused ? h->d_proj.as<double>() : nullptr, 0};
+  const PassOut po{h->d_pair_u.as<double>(), fused ? h->d_proj.as<double>() : nullptr, 0, 0};
   if (h->opt.use_loss_function)
     hipLaunchKernelGGL((k_pass<true>), dim3(blocks), dim3(FOLD_THREADS), pass_lds(h), h->stream,
                        h->t.tiles, h->t.wave_tiles, h->n_waves, h->d_c.as<double>(),
@@ -846,11 +854,13 @@ hipError_t launch_lm_persistent(mvo_hip_context* h, SolveParams prm) {
   if (e != hipSuccess) return e;
   e = hipMemsetAsync(h->d_grid.p, 0, 256, h->stream);
   if (e != hipSuccess) return e;
+  h->fused_count = 0;  // (the fused launch's count of finished pairs lives in the same block)
+  h->fused_ready = true;
   prm.fresh = 1;
   prm.win_base = 0;
   prm.x0_ready = 1;
   prm.proj_ready = 1;
-  RobustArgs ra;
+  RobustArgs ra{};
   ra.tiles = h->t.tiles;
   ra.wave_tiles = h->t.wave_tiles;
   ra.cbuf = h->d_c.as<double>();
@@ -874,6 +884,62 @@ hipError_t launch_lm_persistent(mvo_hip_context* h, SolveParams prm) {
                      h->d_pairsum.as<double>(), h->d_states.as<LmState>(),
                      h->results_on_host ? h->h_results : h->d_results, h->d_status, h->d_trace.as<TraceRec>(), h->d_done,
                      h->d_proj.as<double>(), h->d_cls.as<double>(), h->d_pair_u.as<double>(), ra);
+  h->lm_started = true;
+  return hipGetLastError();
+}
+
+// ---- one small window without a loss: fold and LM loop as ONE launch (k_lm<256, 7>, mvo_lm.h) ----
+// The grid is the fold's; workgroup 0 goes on with the LM loop once every pair is finished.  Only where the fold does
+// not want more than one workgroup per CU anyway (k_lm's workgroups own their CU's registers) and the window takes
+// the specialised kernel with the solver wavefront (lm_spec == 3).  Never while HIP events time the launches: the
+// fold's own duration is what `roofline` is made of.
+bool fused_ok(const mvo_hip_context* h, const SolveParams& prm) {
+  if (h->env_no_fused || h->fused_failed || h->env_lm_generic || h->env_no_tails || h->profiling) return false;
+  if (h->W != 1 || h->pass_mode || h->inline_eval || h->sums_external || prm.trace_cap != 0) return false;
+  if (lm_spec(prm, false) != 3) return false;
+  const uint32_t blocks = (h->n_waves + FOLD_WAVES - 1) / FOLD_WAVES;
+  return blocks >= 1 && (int)blocks <= h->n_cus / 2 && h->max_block_tiles <= (uint32_t)kRobustMaxTiles &&
+         h->h_pairs.size() == h->P;
+}
+hipError_t launch_lm_fused(mvo_hip_context* h, SolveParams prm) {
+  const uint32_t blocks = (h->n_waves + FOLD_WAVES - 1) / FOLD_WAVES;
+  hipError_t e = h->d_grid.reserve(256);
+  if (e != hipSuccess) return e;
+  if (!h->fused_ready) {
+    e = hipMemsetAsync(h->d_grid.p, 0, 256, h->stream);
+    if (e != hipSuccess) return e;
+    h->fused_count = 0;
+    h->fused_ready = true;
+  }
+  uint32_t nonempty = 0;
+  for (const PairDev& pd : h->h_pairs) nonempty += pd.count != 0 ? 1u : 0u;
+  prm.fresh = 1;
+  prm.win_base = 0;
+  RobustArgs ra{};
+  ra.tiles = h->t.tiles;
+  ra.wave_tiles = h->t.wave_tiles;
+  ra.partial = h->d_partial.as<double>();
+  ra.pair_ticket = h->d_pticket.as<int32_t>();
+  ra.pairs_slots = h->t.pairs;
+  ra.pair_sums = h->d_pairsum.as<double>();
+  ra.gs.count = h->d_grid.as<uint32_t>() + 16;
+  ra.gs.error = h->d_grid.as<uint32_t>() + 48;
+  ra.n_waves = h->n_waves;
+  ra.n_wg = blocks;
+  ra.target = h->fused_count + nonempty;
+  ra.spin_limit = kGridSpinLimit;
+  // test aid (MVO_HIP_FUSED_TEST_FAIL, read at mvo_hip_create): a target the count cannot reach and a short wait --
+  // workgroup 0 gives up without a result, which is what the fall-back path is for
+  if (h->env_fused_test_fail) {
+    ra.target += 1;
+    ra.spin_limit = 2000;
+  }
+  h->fused_count += nonempty;
+  hipLaunchKernelGGL((k_lm<MVO_LM_NT_LARGE, 7>), dim3(blocks), dim3(MVO_LM_NT_LARGE), 0, h->stream, prm, 1, h->t.wins,
+                     h->t.frames, h->t.initx, h->t.pairs_unit, h->d_pairsum.as<double>(), h->t.m0, h->t.m1,
+                     h->d_pairsum.as<double>(), h->d_states.as<LmState>(),
+                     h->results_on_host ? h->h_results : h->d_results, h->d_status, h->d_trace.as<TraceRec>(), h->d_done,
+                     (const double*)nullptr, (const double*)nullptr, (double*)nullptr, ra);
   h->lm_started = true;
   return hipGetLastError();
 }
@@ -947,7 +1013,7 @@ hipError_t launch_lm_any(mvo_hip_context* h, SolveParams prm, bool from_pair_sum
 // launch-of-its-own form of the passes' tails (MVO_HIP_NO_TAILS)
 hipError_t launch_reduce_slots(mvo_hip_context* h, const double* upairs) {
   const uint32_t n = h->W * h->P;
-  const PassOut po{upairs, upairs ? h->d_proj.as<double>() : nullptr, 0};
+  const PassOut po{upairs, upairs ? h->d_proj.as<double>() : nullptr, 0, 0};
   hipLaunchKernelGGL(k_reduce_slots, dim3((n * 8 + 255) / 256), dim3(256), 0, h->stream,
                      h->t.pairs, n, h->d_partial.as<double>(), h->d_pairsum.as<double>(), po);
   return hipGetLastError();
@@ -1160,6 +1226,16 @@ static int persistent_fallback(mvo_hip_context* h) {
   return do_solve(h);
 }
 
+// the fused launch ended without a result (its workgroup 0 gave up waiting): two launches from now on
+static int fused_fallback(mvo_hip_context* h) {
+  h->fused_failed = true;
+  h->fused_in_flight = false;
+  h->fused_ready = false;
+  h->done_ready = false;
+  h->tickets_clean = false;
+  return do_solve(h);
+}
+
 int do_solve(mvo_hip_context* h) {
   if (!h->uploaded) return MVO_HIP_ERR_STATE;
   const auto t_begin = std::chrono::steady_clock::now();
@@ -1175,6 +1251,7 @@ int do_solve(mvo_hip_context* h) {
 
   h->lm_started = false;
   h->persistent_in_flight = false;
+  h->fused_in_flight = false;
   // No per-solve fills: the first k_lm launch starts from a zero state of its own and clears its
   // window's status word (SolveParams::fresh); the done counter only ever counts up (done_base).
   if (!h->done_ready) {
@@ -1264,13 +1341,17 @@ int do_solve(mvo_hip_context* h) {
     // one fold+moment pass, then the whole LM loop in a single launch.  S_p never changes without a
     // loss: the fold's last workgroup adds the slots up per pair, every k_lm lane loads the sums of its
     // (up to four) pairs once and keeps them in registers.
-    if (fold_blocks && !h->sums_external) {
+    h->fused_in_flight = fold_blocks != 0 && fused_ok(h, prm);
+    if (h->fused_in_flight) {
+      HIP_TRY(launch_lm_fused(h, prm));  // fold and LM loop in one launch
+    } else if (fold_blocks && !h->sums_external) {
       HIP_TRY(timed_begin());
       HIP_TRY(launch_fold(h, false, true));
       HIP_TRY(timed_end());
       ++asm_launches;
     }
-    if (lm4_eligible(h) && fold_blocks) {
+    if (h->fused_in_flight) {
+    } else if (lm4_eligible(h) && fold_blocks) {
       // (records polled in the host mirror carry the fixed mark: the host clears them before every solve)
       h->lm4_marked = !h->results_on_host;
       if (h->lm4_marked) h->lm4_mark = kResultWritten + 0x10000 * (int32_t)(1 + (h->lm4_seq++ & 0xfff));
@@ -1356,6 +1437,7 @@ int do_solve(mvo_hip_context* h) {
     for (uint32_t w = 0; w < h->W; ++w)
       if (h->h_results[w].pad != kResultWritten) {
         if (h->persistent_in_flight) return persistent_fallback(h);
+        if (h->fused_in_flight) return fused_fallback(h);
         return MVO_HIP_ERR_DEVICE;  // every window must have terminated
       }
     h->h_done[0] = (int32_t)(done_base + h->W);
@@ -1373,6 +1455,7 @@ int do_solve(mvo_hip_context* h) {
       h->h_done[0] = (int32_t)done_base;  // (the counter did not move)
     } else if ((uint32_t)h->h_done[0] - done_base != h->W) {
       if (h->persistent_in_flight) return persistent_fallback(h);
+      if (h->fused_in_flight) return fused_fallback(h);
       return MVO_HIP_ERR_DEVICE;  // every window must have terminated
     }
   }
@@ -1509,6 +1592,8 @@ int mvo_hip_create(int device_ordinal, uint32_t max_windows, uint32_t max_frames
   h->env_no_tails = std::getenv("MVO_HIP_NO_TAILS") != nullptr;
   h->env_lm_generic = std::getenv("MVO_HIP_LM_GENERIC") != nullptr;
   h->env_no_persistent = std::getenv("MVO_HIP_NO_PERSISTENT") != nullptr;
+  h->env_no_fused = std::getenv("MVO_HIP_NO_FUSED") != nullptr;
+  h->env_fused_test_fail = std::getenv("MVO_HIP_FUSED_TEST_FAIL") != nullptr;
   h->env_persistent_test_fail = std::getenv("MVO_HIP_PERSISTENT_TEST_FAIL") != nullptr;
   {
     int cus = 0;

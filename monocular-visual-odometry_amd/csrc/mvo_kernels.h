@@ -113,6 +113,7 @@ struct PassOut {
   double* proj;          // [W * P][10]: T(6) q(3) cost(1) per pair (project_pair8); nullptr: sums only
   int coherent_proj;     // the projections are read by other workgroups of THIS launch (persistent robust solver,
                          // k_lm<256, 6>): stored device-coherently, like the slots
+  int coherent_sums;     // ... the pairs' sums are (fold and LM loop in one launch, k_lm<256, 7>)
 };
 
 // Projected moments of one frame pair from its 8 pass sums, by the 8 consecutive lanes that hold them
@@ -177,11 +178,12 @@ __device__ __forceinline__ void pair_project_store(const PassOut& po, uint32_t p
 // `red` (the workgroup's reduction buffer, free after block_store_partials) holds the to-do list.
 // po.proj != nullptr (the sums are those of a pass at the unit baselines po.upairs): the finishing workgroup
 // also projects the pair (project_pair8).
-__device__ __forceinline__ void block_finish_pairs(int32_t* pair_ticket, const TileDev* tiles, uint32_t bt0,
-                                                   uint32_t bt1, const PairDev* __restrict__ pairs, double* red,
-                                                   const double* partial, double* __restrict__ pair_sums,
-                                                   const PassOut& po, uint32_t bias = 0) {
-  if (pair_ticket == nullptr) return;
+// Returns the number of pairs this workgroup finished (the same value in every thread).
+__device__ __forceinline__ uint32_t block_finish_pairs(int32_t* pair_ticket, const TileDev* tiles, uint32_t bt0,
+                                                       uint32_t bt1, const PairDev* __restrict__ pairs, double* red,
+                                                       const double* partial, double* __restrict__ pair_sums,
+                                                       const PassOut& po, uint32_t bias = 0) {
+  if (pair_ticket == nullptr) return 0;
   tiles -= bias;
   __shared__ uint32_t n_todo;
   // The slot stores above are device-coherent (written through the XCD's L2) and every wavefront has
@@ -213,37 +215,22 @@ __device__ __forceinline__ void block_finish_pairs(int32_t* pair_ticket, const T
     double acc = 0.0;
     for (uint32_t sl = pd.slot_begin; sl < pd.slot_end; ++sl)
       acc += __hip_atomic_load(partial + (size_t)sl * 8 + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    pair_sums[(size_t)p * 8 + v] = acc;
+    if (po.coherent_sums) __hip_atomic_store(pair_sums + (size_t)p * 8 + v, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else pair_sums[(size_t)p * 8 + v] = acc;
     // (the 8 items of a pair are 8 consecutive lanes, all inside the loop together: 8 | FOLD_THREADS)
     if (project) pair_project_store(po, p, acc, (int)(threadIdx.x & 63));
   }
+  return nq;
 }
 
-// ---------------------------------------------------------------------------------------
-// k_fold: reads m0, m1 (48 B / residual block, caller's interleaved layout), optionally writes
-// c (24 B / block) and/or accumulates S = sum c c^T.
-// ---------------------------------------------------------------------------------------
-// PASS0 (robust path): besides storing c, the fold is also the evaluation pass at the starting point --
-// u(x0) per pair is known before it starts (pair_u0, computed by the host at upload), c is in registers:
-// one of the max_it + 1 passes over c saved.  1: w = 1, 2: Cauchy(0.5); sums as in k_pass.
-template <bool WRITE_C, bool MOMENTS, int PASS0 = 0>
-__global__ __launch_bounds__(FOLD_THREADS) void k_fold(const TileDev* __restrict__ tiles,
-                                                       const uint32_t* __restrict__ wave_tiles, uint32_t n_waves,
-                                                       const double* __restrict__ frames,
-                                                       const double* __restrict__ m0,
-                                                       const double* __restrict__ m1,
-                                                       double* __restrict__ cbuf, size_t cstride,
-                                                       double* partial, int32_t* pair_ticket,
-                                                       const PairDev* __restrict__ pairs,
-                                                       double* __restrict__ pair_sums, PassOut po) {
-  static_assert(!(MOMENTS && PASS0), "either the plain moments or the pass sums");
-  extern __shared__ double red[];  // [tiles of this workgroup][8]
-  const int lane = threadIdx.x & 63;
-  const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const uint32_t bw0 = blockIdx.x * FOLD_WAVES;
-  const uint32_t bw1 = bw0 + FOLD_WAVES < n_waves ? bw0 + FOLD_WAVES : n_waves;
-  const uint32_t bt0 = wave_tiles[bw0], bt1 = wave_tiles[bw1];
-  const uint32_t gw = bw0 + wv;
+// the tiles of wavefront gw: c = (R0 m0) x (R1 m1) per residual block, optionally stored, and the tile's 8 sums into
+// red[(tile - bt0) * 8 + value].  Shared by k_fold and the fused fold + LM launch (k_lm<256, 7>).
+template <bool WRITE_C, bool MOMENTS, int PASS0>
+__device__ __forceinline__ void fold_wave_tiles(const TileDev* __restrict__ tiles, const uint32_t* __restrict__ wave_tiles,
+                                                uint32_t gw, uint32_t n_waves, uint32_t bt0,
+                                                const double* __restrict__ frames, const double* __restrict__ m0,
+                                                const double* __restrict__ m1, double* __restrict__ cbuf, size_t cstride,
+                                                double* red, int lane, const PassOut& po) {
   if (gw < n_waves) {
     const uint32_t t0 = wave_tiles[gw], t1 = wave_tiles[gw + 1];
     for (uint32_t t = t0; t < t1; ++t) {
@@ -331,6 +318,34 @@ __global__ __launch_bounds__(FOLD_THREADS) void k_fold(const TileDev* __restrict
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_fold: reads m0, m1 (48 B / residual block, caller's interleaved layout), optionally writes
+// c (24 B / block) and/or accumulates S = sum c c^T.
+// ---------------------------------------------------------------------------------------
+// PASS0 (robust path): besides storing c, the fold is also the evaluation pass at the starting point --
+// u(x0) per pair is known before it starts (pair_u0, computed by the host at upload), c is in registers:
+// one of the max_it + 1 passes over c saved.  1: w = 1, 2: Cauchy(0.5); sums as in k_pass.
+template <bool WRITE_C, bool MOMENTS, int PASS0 = 0>
+__global__ __launch_bounds__(FOLD_THREADS) void k_fold(const TileDev* __restrict__ tiles,
+                                                       const uint32_t* __restrict__ wave_tiles, uint32_t n_waves,
+                                                       const double* __restrict__ frames,
+                                                       const double* __restrict__ m0,
+                                                       const double* __restrict__ m1,
+                                                       double* __restrict__ cbuf, size_t cstride,
+                                                       double* partial, int32_t* pair_ticket,
+                                                       const PairDev* __restrict__ pairs,
+                                                       double* __restrict__ pair_sums, PassOut po) {
+  static_assert(!(MOMENTS && PASS0), "either the plain moments or the pass sums");
+  extern __shared__ double red[];  // [tiles of this workgroup][8]
+  const int lane = threadIdx.x & 63;
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t bw0 = blockIdx.x * FOLD_WAVES;
+  const uint32_t bw1 = bw0 + FOLD_WAVES < n_waves ? bw0 + FOLD_WAVES : n_waves;
+  const uint32_t bt0 = wave_tiles[bw0], bt1 = wave_tiles[bw1];
+  const uint32_t gw = bw0 + wv;
+  fold_wave_tiles<WRITE_C, MOMENTS, PASS0>(tiles, wave_tiles, gw, n_waves, bt0, frames, m0, m1, cbuf, cstride, red, lane, po);
   if (MOMENTS || PASS0) {
     block_store_partials(tiles, bt0, bt1, red, partial, pair_ticket != nullptr);
     block_finish_pairs(pair_ticket, tiles, bt0, bt1, pairs, red, partial, pair_sums, po);

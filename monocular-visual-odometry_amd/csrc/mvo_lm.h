@@ -910,6 +910,8 @@ struct PairIn {
 };
 
 // per-pair inputs: moments (sum of the pair's slots) and the fixed-frame offset n_b v_b (b >= M)
+// COHERENT: the sums were stored by other workgroups of THIS launch (k_lm<256, 7>): device-scope loads
+template <bool COHERENT = false>
 __device__ __forceinline__ void pair_load(PairIn& in, int p, int N, int M, bool unit_slots,
                                           const PairDev* __restrict__ wp, const double* partial,
                                           uint32_t pair_off, const double* __restrict__ fr) {
@@ -917,7 +919,8 @@ __device__ __forceinline__ void pair_load(PairIn& in, int p, int N, int M, bool 
     pair_ab(N, M, p, in.a, in.b);
     const double* ps = partial + (size_t)(pair_off + p) * 8;
 #pragma unroll
-    for (int v = 0; v < 7; ++v) in.S[v] = ps[v];
+    for (int v = 0; v < 7; ++v)
+      in.S[v] = COHERENT ? __hip_atomic_load(ps + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ps[v];
   } else {
     const PairDev pd = wp[p];
     in.a = (int)pd.a;
@@ -1380,11 +1383,11 @@ __device__ __forceinline__ void lm_class_wave(LmShared& sh, const SolveParams& p
       for (int q = 0; q < NA; ++q)
         if (q == 0 || (two && !half)) {
           if (n_rounds <= 1) {
-            pair_load(in[q][0], my_p[q][0], N, M, unit_slots != 0, wp, partial, pair_off, fr);
+            pair_load<COHERENT_PROJ>(in[q][0], my_p[q][0], N, M, unit_slots != 0, wp, partial, pair_off, fr);
           } else {
 #pragma unroll
             for (int rr = 0; rr < ROUNDS; ++rr)
-              pair_load(in[q][rr], my_p[q][rr], N, M, unit_slots != 0, wp, partial, pair_off, fr);
+              pair_load<COHERENT_PROJ>(in[q][rr], my_p[q][rr], N, M, unit_slots != 0, wp, partial, pair_off, fr);
           }
         }
       have_in = !prm.pass_mode;
@@ -1487,6 +1490,9 @@ struct RobustArgs {
   GridSync gs;
   uint32_t n_waves, n_wg;
   int32_t robust;              // Cauchy(0.5) / plain (assembly_mode = PASSES)
+  // SPEC 7 (fold and LM loop in one launch): gs.count counts finished pairs and is never reset -- workgroup 0 goes on when
+  // it has reached `target` (the host knows what it was before the launch and how many pairs have residual blocks)
+  uint32_t target, spin_limit;
 };
 
 // SPEC: the same kernel with the run-time switches of the common solves fixed at compile time, so that the
@@ -1500,6 +1506,10 @@ struct RobustArgs {
 //   5  the robust path's relaunch: one evaluation per launch from the pairs the pass's tails projected (pass_mode,
 //      x0_ready, proj_ready; with or without the loss), all columns free, no trace
 //   6  = 5 as ONE persistent launch over the pass's grid (RobustArgs above)
+//   7  = 3 with the fold in the same launch: the grid is the FOLD's, every workgroup folds its tiles and leaves through
+//      the ticket tail as in k_fold; workgroup 0 then waits until every pair is finished (a count of finished pairs,
+//      bounded polling, nobody waits for workgroup 0) and runs the LM loop.  One small window whose fold does not need
+//      more than a workgroup per CU (config 2: 118): saves the boundary between two dependent launches
 // The host picks it from SolveParams (lm_spec, mvo_hip.hip); MVO_HIP_LM_GENERIC=1 keeps everything on 0.
 template <int NT, int SPEC = 0>
 __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, const WinDev* __restrict__ wins,
@@ -1545,7 +1555,7 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
   constexpr bool PERSIST = SPEC == 6;  // every workgroup of the grid solves window 0 (replicated) and passes over its own tiles
   static_assert(!PERSIST || NT == FOLD_THREADS, "the persistent solver runs the pass with its own workgroup");
   __shared__ double su[PERSIST ? 4 * kRobustMaxPairs : 1];   // (u, |baseline|) of every pair at the candidate
-  __shared__ double red_buf[PERSIST ? 8 * kRobustMaxTiles : 1];
+  __shared__ double red_buf[(PERSIST || SPEC == 7) ? 8 * kRobustMaxTiles : 1];
   __shared__ TileDev s_tiles[PERSIST ? kRobustMaxTiles : 1];  // this workgroup's tiles and its wavefronts' first tiles:
   __shared__ uint32_t s_wt[FOLD_WAVES + 1];                   // read once, not once per pass (two dependent L2 round trips)
   if (PERSIST && (gridDim.x != ra.n_wg || ra.n_wg > (uint32_t)kRobustMaxWorkgroups)) return;  // (host bug guard: nobody waits yet)
@@ -1557,7 +1567,33 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
     if (threadIdx.x <= FOLD_WAVES) s_wt[threadIdx.x] = ra.wave_tiles[bw0 + threadIdx.x <= bw1 ? bw0 + threadIdx.x : bw1];
     for (uint32_t t = threadIdx.x; t < bt1 - bt0; t += NT) s_tiles[t] = ra.tiles[bt0 + t];
   }
-  const int w = PERSIST ? 0 : (int)blockIdx.x + prm.win_base, tid = threadIdx.x;
+  constexpr bool FUSED = SPEC == 7;
+  static_assert(!FUSED || NT == FOLD_THREADS, "the fused launch folds with its own workgroups");
+  if (FUSED) {
+    // ---- the fold, as k_fold<false, true, 0> runs it: this workgroup's tiles, slots out, ticket tail ----
+    const uint32_t bw0 = blockIdx.x * FOLD_WAVES;
+    const uint32_t bw1 = bw0 + FOLD_WAVES < ra.n_waves ? bw0 + FOLD_WAVES : ra.n_waves;
+    const uint32_t bt0 = ra.wave_tiles[bw0], bt1 = ra.wave_tiles[bw1];
+    // (host bug guards; a workgroup that leaves here never reports its pairs: workgroup 0 gives up, the host falls back)
+    if (gridDim.x != ra.n_wg || bt1 - bt0 > (uint32_t)kRobustMaxTiles) return;
+    const uint32_t fwv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    PassOut po;
+    po.upairs = nullptr;
+    po.proj = nullptr;
+    po.coherent_proj = 0;
+    po.coherent_sums = 1;  // read by workgroup 0 of this launch, maybe on another XCD
+    fold_wave_tiles<false, true, 0>(ra.tiles, ra.wave_tiles, bw0 + fwv, ra.n_waves, bt0, frames, m0, m1, nullptr, 0, red_buf,
+                                    (int)(threadIdx.x & 63), po);
+    block_store_partials(ra.tiles, bt0, bt1, red_buf, ra.partial, true);
+    const uint32_t nq = block_finish_pairs(ra.pair_ticket, ra.tiles, bt0, bt1, ra.pairs_slots, red_buf, ra.partial,
+                                           ra.pair_sums, po);
+    // the sums of the pairs this workgroup finished are out (every wavefront waits for its own stores) before they count
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0 && nq) __hip_atomic_fetch_add(ra.gs.count, nq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (blockIdx.x != 0) return;
+  }
+  const int w = (PERSIST || FUSED) ? 0 : (int)blockIdx.x + prm.win_base, tid = threadIdx.x;
   const bool lead_wg = !PERSIST || blockIdx.x == 0;  // writes status words and the result
 #ifdef MVO_LM_STAMPS
   const unsigned long long stamp_entry_ = __builtin_amdgcn_s_memtime();
@@ -1638,6 +1674,28 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
     stamp_lds_[6] = stamp_prev_ - stamp_entry_;
   }
 #endif
+  if (FUSED) {
+    // every pair's sums are complete once the count of finished pairs has reached the target.  Bounded: a fold workgroup
+    // that never reports (it cannot: nobody waits but this workgroup) ends the wait with the error word raised and no
+    // result, and the host repeats the solve as two launches.
+    __shared__ uint32_t fused_ok_s;
+    if (tid == 0) {
+      uint32_t ok = 1;
+      for (uint32_t spins = 0;; ++spins) {
+        const uint32_t c = __hip_atomic_load(ra.gs.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((int32_t)(c - ra.target) >= 0) break;
+        if (spins >= ra.spin_limit) {
+          __hip_atomic_store(ra.gs.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = 0;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      fused_ok_s = ok;
+    }
+    __syncthreads();
+    if (!fused_ok_s) return;
+  }
   bool need_pass = false;
   if (sh.phase == PH_START) {
     r.phase = PH_EVAL_X0;
@@ -1656,7 +1714,7 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
   //            i-th pair with b < M (a = 0: b = 0..M-1, a = 1: b = 1..M-1, ...), then the LM step.
   // SPEC 3 / 4: at most 32 pairs (a, b >= M) per frame -- the class wavefronts hold one pair per lane (HALF layout)
   // and class wavefront 2 has the registers to take the numeric half of the step (LmSolver)
-  constexpr bool SPLIT = LARGE && (SPEC == 3 || SPEC == 4);
+  constexpr bool SPLIT = LARGE && (SPEC == 3 || SPEC == 4 || SPEC == 7);
   // PERSIST: the evaluations of the whole solve, one per turn of this loop (everything else: one turn)
   uint32_t grid_epoch = 0;
   int par = 0;             // which projection buffer holds the evaluation to take in
@@ -1666,7 +1724,7 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
   unsigned long long rstamp_prev_ = __builtin_amdgcn_s_memtime();
 #endif
   for (int turn = 0;; ++turn) {
-  if (LARGE && !wave0) lm_class_wave<NT, SPLIT, SPLIT, SPLIT, PERSIST>(sh, prm, wv - 1, lane, M, N, P, need_pass, unit_slots, wp, partial, win.pair_off, fr, m0, m1, my_sums, proj);
+  if (LARGE && !wave0) lm_class_wave<NT, SPLIT, SPLIT, SPLIT, PERSIST || FUSED>(sh, prm, wv - 1, lane, M, N, P, need_pass, unit_slots, wp, partial, win.pair_off, fr, m0, m1, my_sums, proj);
   int my_p0 = lane < P ? lane : 0;
   bool my_ok0 = lane < P;
   int my_a = 0, my_j = 0;  // k_lm<256>: the short pair's (a, b)
@@ -1863,6 +1921,7 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
     po.upairs = su;
     po.proj = ra.proj[par ^ 1];
     po.coherent_proj = 1;
+    po.coherent_sums = 0;
     block_finish_pairs(ra.pair_ticket, s_tiles, bt0, bt1, ra.pairs_slots, red_buf, ra.partial, ra.pair_sums, po, bt0);
     MVO_RSTAMP(3);  // tickets, finished pairs added up and projected
     par ^= 1;
@@ -1878,7 +1937,7 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
   }  // for (turn)
   if (PERSIST && (grid_fail || !lead_wg)) return;  // only workgroup 0 reports; a failed wait reports nothing (the host repeats the solve)
   // the solver state leaves the registers: LDS image, then HBM (pass mode re-enters with it)
-  constexpr bool ONE_LAUNCH = SPEC >= 1 && SPEC <= 4;  // the solve ends in this launch: nobody reads the state again
+  constexpr bool ONE_LAUNCH = (SPEC >= 1 && SPEC <= 4) || SPEC == 7;  // the solve ends in this launch: nobody reads the state again
   if (wave0) {
     regs_store(r, sh.st, lane);
     if (lane == 0) sh.phase = hsel;
