@@ -44,7 +44,9 @@ def test_four_per_wave_equals_one_per_wave(solver, n, opts):
         # four-wavefront kernel) and differently contracted multiply-adds; ten iterations amplify them
         assert abs(a.initial_cost - b.initial_cost) <= 1e-13 * b.initial_cost
         assert abs(a.final_cost - b.final_cost) <= 1e-9 * b.initial_cost
-    assert np.abs(np.asarray(f4) - np.asarray(f1)).max() < 1e-7
+    # (window 30 of the batch has a flat direction: its parameters move by 1e-7 at a cost that agrees to 1e-14 between
+    # the kernels and the oracle, scripts/dbg/lm4_vs_one_per_wave.py; the bar is the library's, 1e-6)
+    assert np.abs(np.asarray(f4) - np.asarray(f1)).max() < 1e-6
 
 
 def test_rows_that_stop_at_different_evaluations(solver, oracle):
