@@ -889,7 +889,7 @@ hipError_t launch_lm_persistent(mvo_hip_context* h, SolveParams prm) {
 }
 
 // ---- one small window without a loss: fold and LM loop as ONE launch (k_lm<256, 7>, mvo_lm.h) ----
-// The grid is the fold's; workgroup 0 goes on with the LM loop once every pair is finished.  Only where the fold does
+// The grid is the fold's plus one: workgroup 0 sets the LM loop up and goes on with it once every pair is finished.  Only where the fold does
 // not want more than one workgroup per CU anyway (k_lm's workgroups own their CU's registers) and the window takes
 // the specialised kernel with the solver wavefront (lm_spec == 3).  Never while HIP events time the launches: the
 // fold's own duration is what `roofline` is made of.
@@ -935,7 +935,7 @@ hipError_t launch_lm_fused(mvo_hip_context* h, SolveParams prm) {
     ra.spin_limit = 2000;
   }
   h->fused_count += nonempty;
-  hipLaunchKernelGGL((k_lm<MVO_LM_NT_LARGE, 7>), dim3(blocks), dim3(MVO_LM_NT_LARGE), 0, h->stream, prm, 1, h->t.wins,
+  hipLaunchKernelGGL((k_lm<MVO_LM_NT_LARGE, 7>), dim3(blocks + 1), dim3(MVO_LM_NT_LARGE), 0, h->stream, prm, 1, h->t.wins,
                      h->t.frames, h->t.initx, h->t.pairs_unit, h->d_pairsum.as<double>(), h->t.m0, h->t.m1,
                      h->d_pairsum.as<double>(), h->d_states.as<LmState>(),
                      h->results_on_host ? h->h_results : h->d_results, h->d_status, h->d_trace.as<TraceRec>(), h->d_done,

@@ -1506,9 +1506,9 @@ struct RobustArgs {
 //   5  the robust path's relaunch: one evaluation per launch from the pairs the pass's tails projected (pass_mode,
 //      x0_ready, proj_ready; with or without the loss), all columns free, no trace
 //   6  = 5 as ONE persistent launch over the pass's grid (RobustArgs above)
-//   7  = 3 with the fold in the same launch: the grid is the FOLD's, every workgroup folds its tiles and leaves through
-//      the ticket tail as in k_fold; workgroup 0 then waits until every pair is finished (a count of finished pairs,
-//      bounded polling, nobody waits for workgroup 0) and runs the LM loop.  One small window whose fold does not need
+//   7  = 3 with the fold in the same launch: workgroups 1 .. n are the FOLD's grid, each folds its tiles and leaves
+//      through the ticket tail as in k_fold; workgroup 0 sets the LM loop up, waits until every pair is finished (a
+//      count of finished pairs, bounded polling, nobody waits for workgroup 0) and runs it.  One small window whose fold does not need
 //      more than a workgroup per CU (config 2: 118): saves the boundary between two dependent launches
 // The host picks it from SolveParams (lm_spec, mvo_hip.hip); MVO_HIP_LM_GENERIC=1 keeps everything on 0.
 template <int NT, int SPEC = 0>
@@ -1569,13 +1569,15 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
   }
   constexpr bool FUSED = SPEC == 7;
   static_assert(!FUSED || NT == FOLD_THREADS, "the fused launch folds with its own workgroups");
-  if (FUSED) {
+  if (FUSED && blockIdx.x != 0) {
     // ---- the fold, as k_fold<false, true, 0> runs it: this workgroup's tiles, slots out, ticket tail ----
-    const uint32_t bw0 = blockIdx.x * FOLD_WAVES;
+    // (workgroup 0 folds nothing: it is dispatched first and has the LM loop's prologue behind it -- state, starting
+    // point, the first published point -- by the time the fold workgroups 1 .. n are through)
+    const uint32_t bw0 = (blockIdx.x - 1) * FOLD_WAVES;
     const uint32_t bw1 = bw0 + FOLD_WAVES < ra.n_waves ? bw0 + FOLD_WAVES : ra.n_waves;
     const uint32_t bt0 = ra.wave_tiles[bw0], bt1 = ra.wave_tiles[bw1];
     // (host bug guards; a workgroup that leaves here never reports its pairs: workgroup 0 gives up, the host falls back)
-    if (gridDim.x != ra.n_wg || bt1 - bt0 > (uint32_t)kRobustMaxTiles) return;
+    if (gridDim.x != ra.n_wg + 1 || bt1 - bt0 > (uint32_t)kRobustMaxTiles) return;
     const uint32_t fwv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     PassOut po;
     po.upairs = nullptr;
@@ -1591,8 +1593,9 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0 && nq) __hip_atomic_fetch_add(ra.gs.count, nq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (blockIdx.x != 0) return;
+    return;
   }
+  if (FUSED && gridDim.x != ra.n_wg + 1) return;  // (host bug guard, as in the fold workgroups: nobody reports, the host falls back)
   const int w = (PERSIST || FUSED) ? 0 : (int)blockIdx.x + prm.win_base, tid = threadIdx.x;
   const bool lead_wg = !PERSIST || blockIdx.x == 0;  // writes status words and the result
 #ifdef MVO_LM_STAMPS

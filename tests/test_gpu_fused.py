@@ -1,8 +1,8 @@
 """Fold and LM loop in one launch (k_lm<256, 7>, csrc/mvo_lm.h) against the two launches they replace.
 
-One small window without a loss whose fold takes at most one workgroup per CU: the grid is the fold's, every workgroup
-folds its tiles and leaves through the ticket tail as in k_fold, workgroup 0 waits (bounded) until every pair is
-finished and runs the LM loop of k_lm<256, 3>.  Same sums, added up in the same order, same LM code: the results must
+One small window without a loss whose fold takes at most one workgroup per CU: the grid is the fold's plus one, the
+fold workgroups fold their tiles and leave through the ticket tail as in k_fold, workgroup 0 sets the LM loop up, waits
+(bounded) until every pair is finished and runs the LM loop of k_lm<256, 3>.  Same sums, added up in the same order, same LM code: the results must
 be IDENTICAL to those of a handle created under MVO_HIP_NO_FUSED.  A wait that gives up ends without a result and the
 host repeats the solve as two launches (MVO_HIP_FUSED_TEST_FAIL).  Replaces ceres::Solve,
 IterativeRefinement.cpp:231-233, for the reference's single-window call (Refiner.cpp:85-92)."""
