@@ -196,14 +196,13 @@ struct mvo_hip_context {
   bool persistent_failed = false;  // a persistent launch ended without a result once: not tried again on this handle
   bool persistent_in_flight = false;
   // fold + LM loop as one launch (k_lm<256, 7>): MVO_HIP_NO_FUSED keeps them apart; so does a handle on which such a
-  // launch once ended without a result.  fused_count: what the device's count of finished fold workgroups reads before a launch
+  // launch once ended without a result.  fused_count: what the device's count of finished pairs reads before a launch
   // (it is never reset on the device; d_grid word 16, error word 48 -- words 0 / 32 belong to the persistent solver,
   // whose launches clear the whole block)
   bool env_no_fused = false, env_fused_test_fail = false;
   bool fused_failed = false, fused_in_flight = false;
   uint32_t fused_count = 0;
   bool fused_ready = false;  // d_grid exists and holds fused_count
-  bool pairsum_stale = false;  // the last solve was a fused launch: the slots are there, d_pairsum was not written
   int n_cus = 0;
   // d_ctl = [window status: W int32, padded][done counter: 4 int32][results: W LmResult];
   // the last two are mirrored in pinned host memory by one copy
@@ -855,7 +854,7 @@ hipError_t launch_lm_persistent(mvo_hip_context* h, SolveParams prm) {
   if (e != hipSuccess) return e;
   e = hipMemsetAsync(h->d_grid.p, 0, 256, h->stream);
   if (e != hipSuccess) return e;
-  h->fused_count = 0;  // (the fused launch's count lives in the same block)
+  h->fused_count = 0;  // (the fused launch's count of finished pairs lives in the same block)
   h->fused_ready = true;
   prm.fresh = 1;
   prm.win_base = 0;
@@ -899,7 +898,8 @@ bool fused_ok(const mvo_hip_context* h, const SolveParams& prm) {
   if (h->W != 1 || h->pass_mode || h->inline_eval || h->sums_external || prm.trace_cap != 0) return false;
   if (lm_spec(prm, false) != 3) return false;
   const uint32_t blocks = (h->n_waves + FOLD_WAVES - 1) / FOLD_WAVES;
-  return blocks >= 1 && (int)blocks <= h->n_cus / 2 && h->max_block_tiles <= (uint32_t)kRobustMaxTiles;
+  return blocks >= 1 && (int)blocks <= h->n_cus / 2 && h->max_block_tiles <= (uint32_t)kRobustMaxTiles &&
+         h->h_pairs.size() == h->P;
 }
 hipError_t launch_lm_fused(mvo_hip_context* h, SolveParams prm) {
   const uint32_t blocks = (h->n_waves + FOLD_WAVES - 1) / FOLD_WAVES;
@@ -911,6 +911,8 @@ hipError_t launch_lm_fused(mvo_hip_context* h, SolveParams prm) {
     h->fused_count = 0;
     h->fused_ready = true;
   }
+  uint32_t nonempty = 0;
+  for (const PairDev& pd : h->h_pairs) nonempty += pd.count != 0 ? 1u : 0u;
   prm.fresh = 1;
   prm.win_base = 0;
   RobustArgs ra{};
@@ -924,7 +926,7 @@ hipError_t launch_lm_fused(mvo_hip_context* h, SolveParams prm) {
   ra.gs.error = h->d_grid.as<uint32_t>() + 48;
   ra.n_waves = h->n_waves;
   ra.n_wg = blocks;
-  ra.target = h->fused_count + blocks;
+  ra.target = h->fused_count + nonempty;
   ra.spin_limit = kGridSpinLimit;
   // test aid (MVO_HIP_FUSED_TEST_FAIL, read at mvo_hip_create): a target the count cannot reach and a short wait --
   // workgroup 0 gives up without a result, which is what the fall-back path is for
@@ -932,10 +934,9 @@ hipError_t launch_lm_fused(mvo_hip_context* h, SolveParams prm) {
     ra.target += 1;
     ra.spin_limit = 2000;
   }
-  h->fused_count += blocks;
-  // (unit_slots = 0: the LM lanes walk their pair's slots in d_partial)
-  hipLaunchKernelGGL((k_lm<MVO_LM_NT_LARGE, 7>), dim3(blocks + 1), dim3(MVO_LM_NT_LARGE), 0, h->stream, prm, 0, h->t.wins,
-                     h->t.frames, h->t.initx, h->t.pairs, h->d_partial.as<double>(), h->t.m0, h->t.m1,
+  h->fused_count += nonempty;
+  hipLaunchKernelGGL((k_lm<MVO_LM_NT_LARGE, 7>), dim3(blocks + 1), dim3(MVO_LM_NT_LARGE), 0, h->stream, prm, 1, h->t.wins,
+                     h->t.frames, h->t.initx, h->t.pairs_unit, h->d_pairsum.as<double>(), h->t.m0, h->t.m1,
                      h->d_pairsum.as<double>(), h->d_states.as<LmState>(),
                      h->results_on_host ? h->h_results : h->d_results, h->d_status, h->d_trace.as<TraceRec>(), h->d_done,
                      (const double*)nullptr, (const double*)nullptr, (double*)nullptr, ra);
@@ -1341,7 +1342,6 @@ int do_solve(mvo_hip_context* h) {
     // loss: the fold's last workgroup adds the slots up per pair, every k_lm lane loads the sums of its
     // (up to four) pairs once and keeps them in registers.
     h->fused_in_flight = fold_blocks != 0 && fused_ok(h, prm);
-    h->pairsum_stale = h->fused_in_flight;
     if (h->fused_in_flight) {
       HIP_TRY(launch_lm_fused(h, prm));  // fold and LM loop in one launch
     } else if (fold_blocks && !h->sums_external) {
@@ -1854,10 +1854,6 @@ int mvo_hip_debug_pair_sums(mvo_hip_handle h, double* sums) {
   if (!h || !sums) return MVO_HIP_ERR_INVALID_ARGUMENT;
   if (!h->uploaded || !h->d_pairsum.p) return MVO_HIP_ERR_STATE;
   HIP_TRY(hipSetDevice(h->device));
-  if (h->pairsum_stale) {  // fold and LM loop ran as one launch: the LM lanes added the slots up in registers
-    HIP_TRY(launch_reduce_slots(h));
-    h->pairsum_stale = false;
-  }
   HIP_TRY(hipMemcpyAsync(sums, h->d_pairsum.p, sizeof(double) * 8 * (size_t)h->W * h->P, hipMemcpyDeviceToHost,
                          h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));

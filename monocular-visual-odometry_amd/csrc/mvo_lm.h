@@ -927,28 +927,10 @@ __device__ __forceinline__ void pair_load(PairIn& in, int p, int N, int M, bool 
     in.b = (int)pd.b;
 #pragma unroll
     for (int v = 0; v < 7; ++v) in.S[v] = 0.0;
-    if (COHERENT) {
-      // four slots at a time, every load of a round issued before the first add (a pair has a handful); slots past the
-      // pair's end re-read its first one and are left out -- the same additions in the same order as the loop below
-      for (uint32_t sl0 = pd.slot_begin; sl0 < pd.slot_end; sl0 += 4) {
-        double t[4][7];
+    for (uint32_t sl = pd.slot_begin; sl < pd.slot_end; ++sl) {
+      const double* ps = partial + (size_t)sl * 8;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const double* ps = partial + (size_t)(sl0 + u < pd.slot_end ? sl0 + u : sl0) * 8;
-#pragma unroll
-          for (int v = 0; v < 7; ++v) t[u][v] = __hip_atomic_load(ps + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int v = 0; v < 7; ++v) in.S[v] = (sl0 + u < pd.slot_end) ? in.S[v] + t[u][v] : in.S[v];
-      }
-    } else {
-      for (uint32_t sl = pd.slot_begin; sl < pd.slot_end; ++sl) {
-        const double* ps = partial + (size_t)sl * 8;
-#pragma unroll
-        for (int v = 0; v < 7; ++v) in.S[v] += ps[v];
-      }
+      for (int v = 0; v < 7; ++v) in.S[v] += ps[v];
     }
   }
   in.off[0] = in.off[1] = in.off[2] = 0.0;
@@ -1508,8 +1490,8 @@ struct RobustArgs {
   GridSync gs;
   uint32_t n_waves, n_wg;
   int32_t robust;              // Cauchy(0.5) / plain (assembly_mode = PASSES)
-  // SPEC 7 (fold and LM loop in one launch): gs.count counts fold workgroups that are through and is never reset --
-  // workgroup 0 goes on when it has reached `target` (the host knows what it was before the launch)
+  // SPEC 7 (fold and LM loop in one launch): gs.count counts finished pairs and is never reset -- workgroup 0 goes on when
+  // it has reached `target` (the host knows what it was before the launch and how many pairs have residual blocks)
   uint32_t target, spin_limit;
 };
 
@@ -1525,9 +1507,8 @@ struct RobustArgs {
 //      x0_ready, proj_ready; with or without the loss), all columns free, no trace
 //   6  = 5 as ONE persistent launch over the pass's grid (RobustArgs above)
 //   7  = 3 with the fold in the same launch: workgroups 1 .. n are the FOLD's grid, each folds its tiles and leaves
-//      its slots out as in k_fold (no ticket tail: the LM lanes add their pair's slots up themselves); workgroup 0 sets
-//      the LM loop up, waits until every fold workgroup is through (a count, bounded polling, nobody waits for
-//      workgroup 0) and runs it.  One small window whose fold does not need
+//      through the ticket tail as in k_fold; workgroup 0 sets the LM loop up, waits until every pair is finished (a
+//      count of finished pairs, bounded polling, nobody waits for workgroup 0) and runs it.  One small window whose fold does not need
 //      more than a workgroup per CU (config 2: 118): saves the boundary between two dependent launches
 // The host picks it from SolveParams (lm_spec, mvo_hip.hip); MVO_HIP_LM_GENERIC=1 keeps everything on 0.
 template <int NT, int SPEC = 0>
@@ -1601,16 +1582,17 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
     PassOut po;
     po.upairs = nullptr;
     po.proj = nullptr;
-    po.coherent_proj = po.coherent_sums = 0;
+    po.coherent_proj = 0;
+    po.coherent_sums = 1;  // read by workgroup 0 of this launch, maybe on another XCD
     fold_wave_tiles<false, true, 0>(ra.tiles, ra.wave_tiles, bw0 + fwv, ra.n_waves, bt0, frames, m0, m1, nullptr, 0, red_buf,
                                     (int)(threadIdx.x & 63), po);
-    // No ticket tail here: the LM workgroup's lanes own one pair each and add its (few) slots up themselves, in slot
-    // order like the tail would (pair_load) -- a ticket round trip, a second read of the slots and a store of the sums
-    // less between the last ray and the first evaluation.  The slots are out (block_store_partials: device-coherent
-    // stores, every wavefront waits for its own) before this workgroup counts.
     block_store_partials(ra.tiles, bt0, bt1, red_buf, ra.partial, true);
+    const uint32_t nq = block_finish_pairs(ra.pair_ticket, ra.tiles, bt0, bt1, ra.pairs_slots, red_buf, ra.partial,
+                                           ra.pair_sums, po);
+    // the sums of the pairs this workgroup finished are out (every wavefront waits for its own stores) before they count
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(ra.gs.count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0 && nq) __hip_atomic_fetch_add(ra.gs.count, nq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
   if (FUSED && gridDim.x != ra.n_wg + 1) return;  // (host bug guard, as in the fold workgroups: nobody reports, the host falls back)
@@ -1696,7 +1678,7 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
   }
 #endif
   if (FUSED) {
-    // every slot is out once the count of fold workgroups that are through has reached the target.  Bounded: a fold workgroup
+    // every pair's sums are complete once the count of finished pairs has reached the target.  Bounded: a fold workgroup
     // that never reports (it cannot: nobody waits but this workgroup) ends the wait with the error word raised and no
     // result, and the host repeats the solve as two launches.
     __shared__ uint32_t fused_ok_s;
