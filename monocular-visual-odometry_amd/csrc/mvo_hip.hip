@@ -449,12 +449,17 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
   // do not pay one reduction per handful of blocks.
   const uint32_t waves_per_cu = h->env_waves_per_cu;  // MVO_HIP_WAVES_PER_CU, tuning knob for experiments
   const uint64_t kMinChunk = 256, kMaxWaveTiles = 255;
-  // Batched windows without a loss run the fold in kMaxOverlapChunks launches next to the LM loops of
-  // the chunks before (do_solve): every one of those launches must fill the chip by itself.
+  // MVO_HIP_OVERLAP=1 (off by default since round 3): batched windows without a loss run the fold in
+  // kMaxOverlapChunks launches next to the LM loops of the chunks before (do_solve); every one of those launches
+  // must fill the chip by itself.  It paid in round 1, when a window's LM loop took four times what it takes now;
+  // measured again at the end of round 3 (scripts/exp/lm4_crossover.py, config-3 windows, device time per batch):
+  // 512 / 768 / 1024 windows 200 / 253 / 305 us overlapped against 118 / 156 / 189 us fold-then-LM -- the LM
+  // wavefronts own their SIMDs' registers and push the fold's wavefronts off them, and the chunked fold loses
+  // bandwidth.  Kept as an experiment switch with its test.
   const int overlap_chunks = h->env_overlap_chunks ? h->env_overlap_chunks : kOverlapChunks;  // MVO_HIP_OVERLAP_CHUNKS
   const bool want_overlap = !h->pass_mode && !h->inline_eval && W >= 256 && P <= 256 && !lm4_eligible(h) &&
                             n_obs >= (uint64_t)kMinChunk * 256 * waves_per_cu * overlap_chunks &&
-                            !std::getenv("MVO_HIP_NO_OVERLAP");
+                            std::getenv("MVO_HIP_OVERLAP") != nullptr && !std::getenv("MVO_HIP_NO_OVERLAP");
   // Batches that k_lm4 takes (thousands of windows of <= 64 pairs): the fold runs in four launches and the
   // LM loops of the windows already folded start beside it -- STAGGERED by kernel: the bulk on k_lm4 (four
   // windows per wavefront, ~160 us per launch whatever its size), the windows folded too late for that on
@@ -972,11 +977,12 @@ bool lm4_eligible(const mvo_hip_context* h) {
   if (h->pass_mode || h->inline_eval || h->P > 64 || h->W < 4 || h->trace_cap != 0) return false;
   if (h->opt.assembly_mode & MVO_HIP_ASSEMBLY_ONE_PER_WAVE) return false;
   if (h->opt.assembly_mode & MVO_HIP_ASSEMBLY_FOUR_PER_WAVE) return true;
-  // one wavefront per SIMD (512 registers each): 1024 slots.  A k_lm4 wavefront runs ~1.35 x as long as a
-  // k_lm<64> one (config 3: 159 us against 119 us for eleven evaluations) and carries four windows.
+  // one wavefront per SIMD (512 registers each): 1024 slots.  A k_lm4 wavefront runs ~1.1-1.45 x as long as a
+  // k_lm<64> one (config-3 windows, eleven evaluations: 95-103 us against 66 us for a few hundred wavefronts, 88 us
+  // for 1024 of them, scripts/exp/lm4_crossover.py) and carries four windows.
   const double slots = 1024.0;
   const double rounds1 = std::ceil(h->W / slots), rounds4 = std::ceil(h->W / (4.0 * slots));
-  return rounds1 > 1.35 * rounds4;
+  return rounds1 > 1.45 * rounds4;
 }
 // marks_only: the launch covers every window of the solve and nothing else counts them: completion is checked on the
 // records' marks (h->lm4_mark, new for every solve) instead of the done counter
