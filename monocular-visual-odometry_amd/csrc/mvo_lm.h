@@ -462,6 +462,66 @@ __device__ __forceinline__ void lm_prefix_suffix(const double (*cls)[10], const 
   wave0_sync();
 }
 
+// Stages (2) and (3) in one for k_lm<64> evaluating its own pairs (the form k_lm4 uses, mvo_lm4.h): lane (k, v) adds
+// up, for every class j, the classes (a, j) of the frames a <= min(k, j) in the order a = 0, 1, ... (= C1[k][j]) straight
+// from the per-pair rows, then the suffix over j from M down (= D[k][j]) -- the same operations in the same order as
+// lm_prefix_suffix<true>, ONE LDS round trip instead of N - M + 2 (the long class's pairs cost one each there).
+// Frames a > k take part through a factor 0.0 in a fused multiply-add (exact); frames a >= M and classes j >= M that
+// do not exist read pair 0 instead (a valid row: their factor is 0.0 / their sum is never used).  Written: D[k][0..M]
+// for every k < MVO_MAXM (rows k >= M repeat row M - 1: the cost is read from D[MVO_MAXM - 1][0]) and C1[k][k + 1],
+// which is all the product stage and the verdict read.
+__device__ __forceinline__ void lm_tables_from_pairs(const double* pairbuf, double (*C1)[10], double (*D)[10], int M,
+                                                     int N, int lane) {
+  const int kT = lane / 10, vT = lane - 10 * kT;
+  const bool onT = kT < MVO_MAXM;
+  double mT[MVO_MAXM];
+#pragma unroll
+  for (int a = 0; a < MVO_MAXM; ++a) mT[a] = (a <= kT && a < M) ? 1.0 : 0.0;
+  const int cnt = N - 1 - M;
+  int ra[MVO_MAXM];  // first pair of frame a (wave-uniform)
+#pragma unroll
+  for (int a = 0; a < MVO_MAXM; ++a) ra[a] = a < M ? pair_index(N, a, a) : 0;
+  const double* __restrict__ pb = pairbuf + vT;
+  double x[MVO_MAXM][MVO_MAXM], L[MVO_MAXM];
+#pragma unroll
+  for (int a = 0; a < MVO_MAXM; ++a) {
+#pragma unroll
+    for (int j = a; j < MVO_MAXM; ++j) x[a][j] = pb[(j < M ? ra[a] + (j - a) : 0) * 10];
+    L[a] = 0.0;
+  }
+#pragma unroll 4
+  for (int i = 0; i < cnt; ++i) {
+#pragma unroll
+    for (int a = 0; a < MVO_MAXM; ++a) L[a] += pb[((a < M ? ra[a] + (M - a) : 0) + i) * 10];
+  }
+  double C[MVO_MAXM];
+#pragma unroll
+  for (int j = 0; j < MVO_MAXM; ++j) {
+    double c = 0.0;
+#pragma unroll
+    for (int a = 0; a <= j; ++a) c = fma(x[a][j], mT[a], c);
+    C[j] = c;
+  }
+  double cl = 0.0;
+#pragma unroll
+  for (int a = 0; a < MVO_MAXM; ++a) cl = fma(L[a], mT[a], cl);
+  double acc = 0.0 + cl;
+  if (onT) {
+    D[kT * MCX + M][vT] = acc;
+    double cd = 0.0;  // C1[k][k + 1]
+#pragma unroll
+    for (int j = MVO_MAXM - 1; j >= 0; --j) {
+      if (j < M) {
+        acc += C[j];
+        D[kT * MCX + j][vT] = acc;
+      }
+      cd = (j == kT + 1) ? C[j] : cd;
+    }
+    if (kT + 1 < MVO_MAXM) C1[kT * MCX + kT + 1][vT] = cd;
+  }
+  wave0_sync();
+}
+
 // k_lm<256>, wavefront 0: the cost at z = the total of all classes' cost entries, in the order the tables
 // would give it (D[M-1][0][9]: per j the prefix over a, then the suffix from j = M down to 0) -- the verdict
 // on z needs nothing else, so wavefront 0 does not wait for any table.
@@ -1822,7 +1882,7 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
       } else {
         LmTables tb = lm_tables(sh, 0);
         if (prm.cls_ready) lm_prefix_suffix<false>(sh.cls, nullptr, tb.C1, tb.D, M, N, lane);
-        else lm_prefix_suffix<true>(sh.cls, pairbuf, tb.C1, tb.D, M, N, lane);
+        else lm_tables_from_pairs(pairbuf, tb.C1, tb.D, M, N, lane);
         MVO_STAMP(3);
         lm_block_rows<0>(tb, br, lane, hsel ? sh.st.H : sh.Hz);
         lm_gradient_entry(tb, lane >= br.nB4 && lane < br.nB4 + 3 * M, br.k4, br.i4);
