@@ -990,11 +990,15 @@ hipError_t launch_lm4_range(mvo_hip_context* h, SolveParams prm, uint32_t win0, 
                             bool from_pair_sums, bool marks_only = false) {
   prm.fresh = 1;
   prm.win_base = (int32_t)win0;
-  const uint32_t groups = (win1 - win0 + LM4_WINDOWS - 1) / LM4_WINDOWS;
+  // windows per wavefront: four, or two when four would leave more than half of the 1024 SIMDs without a wavefront
+  // (MVO_HIP_LM4_WPW = 2 | 4 forces either, for experiments)
+  uint32_t wpw = win1 - win0 <= 2048 ? 2 : 4;
+  if (const char* e = std::getenv("MVO_HIP_LM4_WPW")) wpw = std::atoi(e) == 2 ? 2 : 4;
+  const uint32_t groups = (win1 - win0 + wpw - 1) / wpw;
   // the usual window (five refined frames, free lengths) has a kernel of its own; MVO_HIP_LM_GENERIC: never
   auto kern = prm.M == 5 && !prm.fix_length && !h->env_lm_generic ? k_lm4<5> : k_lm4<0>;
   hipLaunchKernelGGL(kern, dim3(groups), dim3(64), 0, stream, prm, (int)win1, from_pair_sums ? 1 : 0,
-                     h->results_on_host ? 1 : 0, marks_only ? h->lm4_mark : kResultWritten, h->t.frames,
+                     h->results_on_host ? 1 : 0, marks_only ? h->lm4_mark : kResultWritten, (int)wpw, h->t.frames,
                      h->t.initx, from_pair_sums ? h->t.pairs_unit : h->t.pairs,
                      from_pair_sums ? h->d_pairsum.as<double>() : h->d_partial.as<double>(),
                      h->results_on_host ? h->h_results : h->d_results, h->d_status,

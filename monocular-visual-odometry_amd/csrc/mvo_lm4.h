@@ -574,8 +574,10 @@ __device__ __forceinline__ void lm4_evaluate2(Lm4Shared& sh, const PairIn& inA, 
 // completion signal (the host passes a new mark every solve and checks every record after the copy) -- the windows of
 // a batch end together, and a thousand wavefronts' atomics on ONE address take 6 us at the end of the kernel (four
 // thousand, one per window: 17 us).
+// wpw: windows per wavefront, 4 or 2 (rows 2 and 3 then carry no window: one side-by-side evaluation per turn instead
+// of two, under the same step -- batches that would leave most SIMDs without a wavefront at four per wavefront).
 template <int MS>
-__global__ __launch_bounds__(64) void k_lm4(SolveParams prm, int win_end, int unit_slots, int host_marks, int mark,
+__global__ __launch_bounds__(64) void k_lm4(SolveParams prm, int win_end, int unit_slots, int host_marks, int mark, int wpw,
                                             const double* __restrict__ frames, const double* __restrict__ init_x,
                                             const PairDev* __restrict__ pairs, const double* partial,
                                             LmResult* __restrict__ results, int32_t* __restrict__ win_status,
@@ -595,9 +597,9 @@ __global__ __launch_bounds__(64) void k_lm4(SolveParams prm, int win_end, int un
   const int M = prm.M, N = prm.N, P = prm.P;
   const int fix = prm.fix_length;
   const int n = fix ? 2 * M : 3 * M;
-  const int wbase = prm.win_base + LM4_WINDOWS * (int)blockIdx.x;
+  const int wbase = prm.win_base + wpw * (int)blockIdx.x;
   const int w_row = wbase + row;
-  const bool row_exists = w_row < win_end;
+  const bool row_exists = row < wpw && w_row < win_end;
   const int w_ld = row_exists ? w_row : win_end - 1;  // loads of a row without a window: any valid one
 
   // every global load of the prologue first: the starting points and the pairs' inputs of the four windows
@@ -612,7 +614,7 @@ __global__ __launch_bounds__(64) void k_lm4(SolveParams prm, int win_end, int un
   PairIn in[LM4_WINDOWS];
 #pragma unroll
   for (int q = 0; q < LM4_WINDOWS; ++q) {
-    const int wq = wbase + q < win_end ? wbase + q : win_end - 1;
+    const int wq = (q < wpw && wbase + q < win_end) ? wbase + q : win_end - 1;
     pair_load(in[q], my_p0, N, M, unit_slots != 0, pairs + (size_t)wq * P, partial, (uint32_t)wq * (uint32_t)P,
               frames + (size_t)MVO_FRAME_DOUBLES * wq * N);
   }
@@ -702,7 +704,7 @@ __global__ __launch_bounds__(64) void k_lm4(SolveParams prm, int win_end, int un
   }
   if (row_exists && l == 0) win_status[w_row] = 1;
   if (done_count != nullptr && lane == 0)
-    atomicAdd(done_count, win_end - wbase < LM4_WINDOWS ? win_end - wbase : LM4_WINDOWS);
+    atomicAdd(done_count, win_end - wbase < wpw ? win_end - wbase : wpw);
   LM4_STAMP(7);
 #ifdef MVO_LM_STAMPS
   if (blockIdx.x == 0 && threadIdx.x == 0) {
