@@ -980,6 +980,10 @@ bool lm4_eligible(const mvo_hip_context* h) {
   // one wavefront per SIMD (512 registers each): 1024 slots.  A k_lm4 wavefront runs ~1.1-1.45 x as long as a
   // k_lm<64> one (config-3 windows, eleven evaluations: 95-103 us against 66 us for a few hundred wavefronts, 88 us
   // for 1024 of them, scripts/exp/lm4_crossover.py) and carries four windows.
+  // Up to 2048 windows k_lm4 carries TWO per wavefront (launch_lm4_range): one round of the slots either way, and the
+  // shared step wins from ~640 windows on (config-3 windows, device time per batch, two per wavefront against one:
+  // 512: 116 / 116 us, 768: 152 / 156, 1024: 175 / 189, 1536: 229 / 297, 2048: 278 / 357).
+  if (h->W <= 2048) return h->W > 640;
   const double slots = 1024.0;
   const double rounds1 = std::ceil(h->W / slots), rounds4 = std::ceil(h->W / (4.0 * slots));
   return rounds1 > 1.45 * rounds4;
