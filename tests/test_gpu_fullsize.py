@@ -158,7 +158,8 @@ def test_config3_fold_lm_overlap_equals_the_single_pass(solver, oracle):
     import os
 
     ws = [scene.config3_window(i) for i in range(1024)]
-    opt = capi.make_options(**FIXED10)
+    # (one window per wavefront: batches of this size go four -- two -- per wavefront by default, which never overlaps)
+    opt = capi.make_options(assembly_mode=capi.ASSEMBLY_ONE_PER_WAVE, **FIXED10)
     os.environ["MVO_HIP_OVERLAP"] = "1"
     try:
         fo, so = solver.refine_batch(ws, opt)
