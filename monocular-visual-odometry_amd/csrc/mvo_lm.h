@@ -1553,6 +1553,9 @@ struct RobustArgs {
   // SPEC 7 (fold and LM loop in one launch): gs.count counts finished pairs and is never reset -- workgroup 0 goes on when
   // it has reached `target` (the host knows what it was before the launch and how many pairs have residual blocks)
   uint32_t target, spin_limit;
+  // SPEC 6: the counter the NEXT persistent launch on this handle will use (the launches alternate between two): zeroed
+  // by this launch, so that no clearing command stands in front of any of them
+  uint32_t* next_count;
 };
 
 // SPEC: the same kernel with the run-time switches of the common solves fixed at compile time, so that the
@@ -1619,6 +1622,8 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
   __shared__ TileDev s_tiles[PERSIST ? kRobustMaxTiles : 1];  // this workgroup's tiles and its wavefronts' first tiles:
   __shared__ uint32_t s_wt[FOLD_WAVES + 1];                   // read once, not once per pass (two dependent L2 round trips)
   if (PERSIST && (gridDim.x != ra.n_wg || ra.n_wg > (uint32_t)kRobustMaxWorkgroups)) return;  // (host bug guard: nobody waits yet)
+  if (PERSIST && blockIdx.x == 0 && threadIdx.x == 0 && ra.next_count != nullptr)  // (the launch before this one used it and is over)
+    __hip_atomic_store(ra.next_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (PERSIST) {  // (read behind the prologue's barriers)
     const uint32_t bw0 = blockIdx.x * FOLD_WAVES;
     const uint32_t bw1 = bw0 + FOLD_WAVES < ra.n_waves ? bw0 + FOLD_WAVES : ra.n_waves;
