@@ -202,7 +202,8 @@ struct mvo_hip_context {
   bool env_no_fused = false, env_fused_test_fail = false;
   bool fused_failed = false, fused_in_flight = false;
   uint32_t fused_count = 0;
-  bool fused_ready = false;  // d_grid exists and holds fused_count
+  bool fused_ready = false;  // d_grid exists, holds fused_count and a zeroed counter for the next persistent launch
+  uint32_t grid_seq = 0;     // persistent launches on this handle since d_grid was last cleared
   int n_cus = 0;
   // d_ctl = [window status: W int32, padded][done counter: 4 int32][results: W LmResult];
   // the last two are mirrored in pinned host memory by one copy
@@ -857,10 +858,16 @@ hipError_t launch_lm_persistent(mvo_hip_context* h, SolveParams prm) {
   const uint32_t blocks = (h->n_waves + FOLD_WAVES - 1) / FOLD_WAVES;
   hipError_t e = h->d_grid.reserve(256);
   if (e != hipSuccess) return e;
-  e = hipMemsetAsync(h->d_grid.p, 0, 256, h->stream);
-  if (e != hipSuccess) return e;
-  h->fused_count = 0;  // (the fused launch's count of finished pairs lives in the same block)
-  h->fused_ready = true;
+  // d_grid (64 words): [0] / [8] the counters of the persistent launches, used in turn -- every launch zeroes the other
+  // one for its successor, so only the first launch on a handle (and the one after a failure) needs a clearing
+  // command --, [32] their error word, [16] / [48] the fused launch's count and error word
+  if (!h->fused_ready) {
+    e = hipMemsetAsync(h->d_grid.p, 0, 256, h->stream);
+    if (e != hipSuccess) return e;
+    h->fused_count = 0;
+    h->fused_ready = true;
+    h->grid_seq = 0;
+  }
   prm.fresh = 1;
   prm.win_base = 0;
   prm.x0_ready = 1;
@@ -876,7 +883,9 @@ hipError_t launch_lm_persistent(mvo_hip_context* h, SolveParams prm) {
   ra.pair_sums = h->d_pairsum.as<double>();
   ra.proj[0] = h->d_proj.as<double>();
   ra.proj[1] = h->d_proj.as<double>() + 10 * (size_t)h->W * h->P;
-  ra.gs.count = h->d_grid.as<uint32_t>();
+  ra.gs.count = h->d_grid.as<uint32_t>() + 8 * (h->grid_seq & 1u);
+  ra.next_count = h->d_grid.as<uint32_t>() + 8 * ((h->grid_seq + 1) & 1u);
+  ++h->grid_seq;
   ra.gs.error = h->d_grid.as<uint32_t>() + 32;
   ra.n_waves = h->n_waves;
   ra.n_wg = blocks;
@@ -1235,6 +1244,7 @@ int do_solve(mvo_hip_context* h);
 static int persistent_fallback(mvo_hip_context* h) {
   h->persistent_failed = true;
   h->persistent_in_flight = false;
+  h->fused_ready = false;  // (d_grid: a counter half counted, the error word raised)
   h->done_ready = false;
   h->tickets_clean = false;
   return do_solve(h);
