@@ -93,3 +93,24 @@ def test_the_kernel_of_the_usual_window_equals_the_kernel_for_any_shape(solver):
                 assert np.abs(np.asarray(fa) - np.asarray(fb)).max() < 1e-10
     finally:
         generic.close()
+
+
+def test_two_windows_per_wavefront_equal_four(solver):
+    """Batches of at most 2048 windows ride two per wavefront (rows 2 and 3 carry no window), larger ones four:
+    MVO_HIP_LM4_WPW forces either.  A window's arithmetic does not depend on its row or on its neighbours: results
+    identical, bit for bit, whatever the packing -- also for batch sizes that leave wavefronts half empty."""
+    import os
+    for n in (5, 9, 130):
+        ws = _batch(n, seed0=1300)
+        kw = dict(assembly_mode=capi.ASSEMBLY_TILED | capi.ASSEMBLY_FOUR_PER_WAVE, max_num_iterations=30)
+        out = {}
+        for wpw in ("2", "4"):
+            os.environ["MVO_HIP_LM4_WPW"] = wpw
+            try:
+                out[wpw] = _solve(solver, ws, **kw)
+            finally:
+                del os.environ["MVO_HIP_LM4_WPW"]
+        (f2, s2), (f4, s4) = out["2"], out["4"]
+        assert np.array_equal(np.asarray(f2), np.asarray(f4))
+        for a, b in zip(s2, s4):
+            assert (a.termination, a.reason, a.iterations, a.final_cost) == (b.termination, b.reason, b.iterations, b.final_cost)
