@@ -143,6 +143,7 @@ struct DevBuf {
 
 constexpr int kMaxTimedLaunches = 128;
 constexpr int kMaxOverlapChunks = 8;
+constexpr uint32_t kLm4FoldWavesPerCu = 512;  // fold wavefronts per CU in front of k_lm4 (many rounds, no ticket tails: mvo_hip_upload)
 constexpr int kOverlapChunks = 4;  // a k_lm launch over W / 4 windows takes about as long as a quarter of the fold
 // uploads with at most this many residual blocks stage their rays in the pinned arena too
 constexpr uint64_t kArenaRayLimit = 1u << 16;
@@ -189,6 +190,7 @@ struct mvo_hip_context {
   uint32_t env_waves_per_cu = 16;
   int env_overlap_chunks = 0;  // 0: the default (kOverlapChunks)
   bool env_no_host_results = false, env_no_poll = false;
+  bool env_lm4_sums = false;  // MVO_HIP_LM4_SUMS: k_lm4 behind a fold WITH ticket tails, cut as for the other kernels (round 3's plan)
   bool env_no_tails = false;  // MVO_HIP_NO_TAILS: per-pair sums by k_reduce_slots launches instead of the passes' ticket tails
   bool env_lm_generic = false;  // MVO_HIP_LM_GENERIC: k_lm<NT, 0> for every solve (no compile-time specialisation)
   bool env_no_persistent = false;  // MVO_HIP_NO_PERSISTENT: the robust path launch by launch, never k_lm<256, 6>
@@ -474,7 +476,14 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
                              !(opt->assembly_mode & (MVO_HIP_ASSEMBLY_ONE_PER_WAVE | MVO_HIP_ASSEMBLY_FOUR_PER_WAVE)) &&
                              n_obs >= 16000000ull && std::getenv("MVO_HIP_PIPELINE") != nullptr;
   // every launch of a chunked fold has to fill the chip by itself; the staggered plan's last launches cover 1/16 of the windows
-  const uint64_t max_waves = 256ull * waves_per_cu * (want_pipeline ? 16 : want_overlap ? overlap_chunks : 1);
+  // Batches that k_lm4 takes read the fold's slots themselves (do_solve): without the ticket tails the fold is the
+  // faster the finer it is cut -- many rounds of short wavefronts that fill in behind one another instead of one round
+  // that ends with its slowest wavefront (config 3, k_fold per launch: 386 us with tails at any granularity; without:
+  // 370 us at 16 wavefronts per CU, 364 / 352 / 347 / 349 / 345 us at 128 / 256 / 384 / 512 / 1024,
+  // scripts/exp/env_kstats.sh).  With tails (every other plan) finer is SLOWER: config 4 84 -> 92 / 99 us at 32 / 128.
+  const bool lm4_plan = lm4_eligible(h) && !h->env_lm4_sums;
+  const uint64_t max_waves = 256ull * (want_pipeline ? waves_per_cu * 16 : lm4_plan ? std::max(waves_per_cu, kLm4FoldWavesPerCu) :
+                                       want_overlap ? waves_per_cu * overlap_chunks : waves_per_cu);
   uint64_t want_waves = (n_obs + kMinChunk - 1) / kMinChunk;
   if (want_waves > max_waves) want_waves = max_waves;
   if (want_waves == 0) want_waves = 1;
@@ -1370,7 +1379,8 @@ int do_solve(mvo_hip_context* h) {
       HIP_TRY(launch_lm_fused(h, prm));  // fold and LM loop in one launch
     } else if (fold_blocks && !h->sums_external) {
       HIP_TRY(timed_begin());
-      HIP_TRY(launch_fold(h, false, true));
+      // (k_lm4 adds the slots of its pairs up itself: no ticket tails, see the tiling in mvo_hip_upload)
+      HIP_TRY(launch_fold(h, false, !(lm4_eligible(h) && !h->env_lm4_sums)));
       HIP_TRY(timed_end());
       ++asm_launches;
     }
@@ -1379,7 +1389,7 @@ int do_solve(mvo_hip_context* h) {
       // (records polled in the host mirror carry the fixed mark: the host clears them before every solve)
       h->lm4_marked = !h->results_on_host;
       if (h->lm4_marked) h->lm4_mark = kResultWritten + 0x10000 * (int32_t)(1 + (h->lm4_seq++ & 0xfff));
-      HIP_TRY(launch_lm4_range(h, prm, 0, h->W, s, true, h->lm4_marked));
+      HIP_TRY(launch_lm4_range(h, prm, 0, h->W, s, h->env_lm4_sums, h->lm4_marked));
       h->lm_started = true;
     } else {
       HIP_TRY(launch_lm_any(h, prm, fold_blocks != 0 || h->sums_external));
@@ -1605,7 +1615,7 @@ int mvo_hip_create(int device_ordinal, uint32_t max_windows, uint32_t max_frames
   h->device = device_ordinal;
   if (const char* e = std::getenv("MVO_HIP_WAVES_PER_CU")) {
     const int t = std::atoi(e);
-    if (t >= 1 && t <= 64) h->env_waves_per_cu = (uint32_t)t;
+    if (t >= 1 && t <= 1024) h->env_waves_per_cu = (uint32_t)t;
   }
   if (const char* e = std::getenv("MVO_HIP_OVERLAP_CHUNKS")) {
     const int t = std::atoi(e);
@@ -1614,6 +1624,7 @@ int mvo_hip_create(int device_ordinal, uint32_t max_windows, uint32_t max_frames
   h->env_no_host_results = std::getenv("MVO_HIP_NO_HOST_RESULTS") != nullptr;
   h->env_no_poll = std::getenv("MVO_HIP_NO_POLL") != nullptr;
   h->env_no_tails = std::getenv("MVO_HIP_NO_TAILS") != nullptr;
+  h->env_lm4_sums = std::getenv("MVO_HIP_LM4_SUMS") != nullptr;
   h->env_lm_generic = std::getenv("MVO_HIP_LM_GENERIC") != nullptr;
   h->env_no_persistent = std::getenv("MVO_HIP_NO_PERSISTENT") != nullptr;
   h->env_no_fused = std::getenv("MVO_HIP_NO_FUSED") != nullptr;
