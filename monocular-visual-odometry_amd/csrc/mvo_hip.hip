@@ -212,6 +212,7 @@ struct mvo_hip_context {
   int32_t* d_status = nullptr;
   int32_t* d_done = nullptr;
   LmResult* d_results = nullptr;
+  bool slots_plan = false;     // this upload: the LM kernels read the fold's slots, no ticket tails (mvo_hip_upload)
   bool sums_external = false;  // the per-pair sums in d_pairsum were put there by the caller (fused track fold)
   bool results_on_host = false;  // this solve's k_lm writes its (few) result records straight into h_results
   char* h_ctl = nullptr;  // pinned: [done: 4 int32][results]
@@ -371,6 +372,7 @@ int ensure_events(mvo_hip_context* h) {
 }
 
 bool lm4_eligible(const mvo_hip_context* h);
+bool slots_plan_static(const mvo_hip_context* h);
 
 // Unit baselines of window w's pairs at the starting point (v_initx): what k_lm publishes for a
 // candidate (pair_unit_baseline, IR.cpp:137-144, 254-255, 298-309, 466-577), here on the host so that the
@@ -475,15 +477,29 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
   const bool want_pipeline = !h->pass_mode && !h->inline_eval && lm4_eligible(h) && W >= 2048 && P <= 64 &&
                              !(opt->assembly_mode & (MVO_HIP_ASSEMBLY_ONE_PER_WAVE | MVO_HIP_ASSEMBLY_FOUR_PER_WAVE)) &&
                              n_obs >= 16000000ull && std::getenv("MVO_HIP_PIPELINE") != nullptr;
-  // every launch of a chunked fold has to fill the chip by itself; the staggered plan's last launches cover 1/16 of the windows
-  // Batches that k_lm4 takes read the fold's slots themselves (do_solve): without the ticket tails the fold is the
-  // faster the finer it is cut -- many rounds of short wavefronts that fill in behind one another instead of one round
-  // that ends with its slowest wavefront (config 3, k_fold per launch: 386 us with tails at any granularity; without:
-  // 370 us at 16 wavefronts per CU, 364 / 352 / 347 / 349 / 345 us at 128 / 256 / 384 / 512 / 1024,
-  // scripts/exp/env_kstats.sh).  With tails (every other plan) finer is SLOWER: config 4 84 -> 92 / 99 us at 32 / 128.
-  const bool lm4_plan = lm4_eligible(h) && !h->env_lm4_sums;
-  const uint64_t max_waves = 256ull * (want_pipeline ? waves_per_cu * 16 : lm4_plan ? std::max(waves_per_cu, kLm4FoldWavesPerCu) :
-                                       want_overlap ? waves_per_cu * overlap_chunks : waves_per_cu);
+  // Batches of windows with at most 64 pairs (slots_plan): k_lm4 / k_lm<64> add the slots of their pairs up themselves
+  // and the fold runs WITHOUT its ticket tails.  Without them it is the faster the finer it is cut -- many rounds of short
+  // wavefronts that fill in behind one another instead of one round that ends with its slowest wavefront (config 3,
+  // k_fold per launch: 386 us with tails at any granularity; without: 370 us at 16 wavefronts per CU, 364 / 352 / 347 /
+  // 349 / 345 us at 128 / 256 / 384 / 512 / 1024, scripts/exp/env_kstats.sh).  With tails (every other plan) finer is
+  // SLOWER: config 4 84 -> 92 / 99 us at 32 / 128.  An LM lane adds its pair's slots one after the other, so the cut
+  // stays coarse enough for a pair to have a few of them (a workgroup's share >= half the mean pair, 1/8 of the longest);
+  // windows so long that this would leave the chip short of wavefronts keep the tails.
+  const uint64_t chunk_tails_plan = std::max<uint64_t>(kMinChunk, (n_obs + 256ull * waves_per_cu - 1) / (256ull * waves_per_cu));
+  uint64_t chunk_slots_plan = 0;
+  h->slots_plan = false;
+  if (slots_plan_static(h) && !want_pipeline && n_obs > 0) {
+    uint64_t max_pair = 0;
+    for (uint32_t w = 0; w < W; ++w)
+      for (uint32_t q = 0; q < P; ++q) max_pair = std::max<uint64_t>(max_pair, obs[w].pair_offsets[q + 1] - obs[w].pair_offsets[q]);
+    const uint64_t mean_pair = n_obs / ((uint64_t)W * P);
+    chunk_slots_plan = std::max<uint64_t>({kMinChunk, (n_obs + 256ull * kLm4FoldWavesPerCu - 1) / (256ull * kLm4FoldWavesPerCu),
+                                           mean_pair / (2 * FOLD_WAVES), max_pair / (8 * FOLD_WAVES)});
+    h->slots_plan = chunk_slots_plan <= chunk_tails_plan;
+  }
+  // (every launch of a chunked fold has to fill the chip by itself; the staggered plan's last launches cover 1/16 of the windows)
+  const uint64_t max_waves = h->slots_plan ? (n_obs + chunk_slots_plan - 1) / chunk_slots_plan
+                                           : 256ull * waves_per_cu * (want_pipeline ? 16 : want_overlap ? overlap_chunks : 1);
   uint64_t want_waves = (n_obs + kMinChunk - 1) / kMinChunk;
   if (want_waves > max_waves) want_waves = max_waves;
   if (want_waves == 0) want_waves = 1;
@@ -1006,6 +1022,15 @@ bool lm4_eligible(const mvo_hip_context* h) {
   const double rounds1 = std::ceil(h->W / slots), rounds4 = std::ceil(h->W / (4.0 * slots));
   return rounds1 > 1.45 * rounds4;
 }
+// Batches of windows with at most 64 pairs, folded chip-wide: the LM kernels add the slots of their pairs up themselves,
+// the fold runs without ticket tails and is cut finer (mvo_hip_upload decides per upload: h->slots_plan).
+// MVO_HIP_LM4_SUMS: never (round 3's plan: tails, per-pair sums).
+bool slots_plan_static(const mvo_hip_context* h) {
+  if (h->pass_mode || h->inline_eval || h->env_lm4_sums || h->P > 64) return false;
+  uint32_t min_w = 1;
+  if (const char* e = std::getenv("MVO_HIP_SLOTS_MIN_W")) min_w = (uint32_t)std::atoi(e);
+  return h->W > min_w;
+}
 // marks_only: the launch covers every window of the solve and nothing else counts them: completion is checked on the
 // records' marks (h->lm4_mark, new for every solve) instead of the done counter
 hipError_t launch_lm4_range(mvo_hip_context* h, SolveParams prm, uint32_t win0, uint32_t win1, hipStream_t stream,
@@ -1380,7 +1405,7 @@ int do_solve(mvo_hip_context* h) {
     } else if (fold_blocks && !h->sums_external) {
       HIP_TRY(timed_begin());
       // (k_lm4 adds the slots of its pairs up itself: no ticket tails, see the tiling in mvo_hip_upload)
-      HIP_TRY(launch_fold(h, false, !(lm4_eligible(h) && !h->env_lm4_sums)));
+      HIP_TRY(launch_fold(h, false, !(h->slots_plan && !h->sums_external)));
       HIP_TRY(timed_end());
       ++asm_launches;
     }
@@ -1389,10 +1414,10 @@ int do_solve(mvo_hip_context* h) {
       // (records polled in the host mirror carry the fixed mark: the host clears them before every solve)
       h->lm4_marked = !h->results_on_host;
       if (h->lm4_marked) h->lm4_mark = kResultWritten + 0x10000 * (int32_t)(1 + (h->lm4_seq++ & 0xfff));
-      HIP_TRY(launch_lm4_range(h, prm, 0, h->W, s, h->env_lm4_sums, h->lm4_marked));
+      HIP_TRY(launch_lm4_range(h, prm, 0, h->W, s, !h->slots_plan || h->sums_external, h->lm4_marked));
       h->lm_started = true;
     } else {
-      HIP_TRY(launch_lm_any(h, prm, fold_blocks != 0 || h->sums_external));
+      HIP_TRY(launch_lm_any(h, prm, (fold_blocks != 0 && !h->slots_plan) || h->sums_external));
     }
     ++lm_launches;
   } else {

@@ -7,7 +7,8 @@ from mvo_amd import capi, scene
 fixed = dict(max_num_iterations=10, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
 base = [scene.config3_window(i) for i in range(32)]
 with capi.Solver(0) as s:
-    for W in (260, 384, 512, 768, 1024, 1536, 2048, 4096):
+    sizes = [int(a) for a in sys.argv[1:]] or [260, 384, 512, 768, 1024, 1536, 2048, 4096]
+    for W in sizes:
         ws = [base[i % 32] for i in range(W)]
         row = []
         for name, mode in (("auto", 0), ("four/wave", capi.ASSEMBLY_FOUR_PER_WAVE), ("one/wave", capi.ASSEMBLY_ONE_PER_WAVE)):
