@@ -612,11 +612,59 @@ __global__ __launch_bounds__(64) void k_lm4(SolveParams prm, int win_end, int un
   const int my_p0 = lane < P ? lane : 0;
   const bool my_ok0 = lane < P;
   PairIn in[LM4_WINDOWS];
+  if (unit_slots) {
 #pragma unroll
-  for (int q = 0; q < LM4_WINDOWS; ++q) {
-    const int wq = (q < wpw && wbase + q < win_end) ? wbase + q : win_end - 1;
-    pair_load(in[q], my_p0, N, M, unit_slots != 0, pairs + (size_t)wq * P, partial, (uint32_t)wq * (uint32_t)P,
-              frames + (size_t)MVO_FRAME_DOUBLES * wq * N);
+    for (int q = 0; q < LM4_WINDOWS; ++q) {
+      const int wq = (q < wpw && wbase + q < win_end) ? wbase + q : win_end - 1;
+      pair_load(in[q], my_p0, N, M, true, pairs + (size_t)wq * P, partial, (uint32_t)wq * (uint32_t)P,
+                frames + (size_t)MVO_FRAME_DOUBLES * wq * N);
+    }
+  } else {
+    // the fold's slots (no ticket tails in front of this kernel): the four windows' pair records in one round trip,
+    // then their slots side by side, i-th slot of each in one more -- every pair adds its own up in slot order
+    PairDev pd[LM4_WINDOWS];
+    uint32_t most = 0;
+#pragma unroll
+    for (int q = 0; q < LM4_WINDOWS; ++q) {
+      const int wq = (q < wpw && wbase + q < win_end) ? wbase + q : win_end - 1;
+      pd[q] = pairs[(size_t)wq * P + my_p0];
+    }
+#pragma unroll
+    for (int q = 0; q < LM4_WINDOWS; ++q) {
+      in[q].a = (int)pd[q].a;
+      in[q].b = (int)pd[q].b;
+#pragma unroll
+      for (int v = 0; v < 7; ++v) in[q].S[v] = 0.0;
+      most = max(most, pd[q].slot_end - pd[q].slot_begin);
+    }
+    for (uint32_t i = 0; i < most; ++i) {
+      double t[LM4_WINDOWS][7];
+#pragma unroll
+      for (int q = 0; q < LM4_WINDOWS; ++q) {
+        const uint32_t sl = pd[q].slot_begin + i;
+        const double* ps = partial + (size_t)(sl < pd[q].slot_end ? sl : 0u) * 8;  // (slot 0 exists: this pair or another has slots)
+#pragma unroll
+        for (int v = 0; v < 7; ++v) t[q][v] = ps[v];
+      }
+#pragma unroll
+      for (int q = 0; q < LM4_WINDOWS; ++q)
+        if (pd[q].slot_begin + i < pd[q].slot_end) {
+#pragma unroll
+          for (int v = 0; v < 7; ++v) in[q].S[v] += t[q][v];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < LM4_WINDOWS; ++q) {
+      const int wq = (q < wpw && wbase + q < win_end) ? wbase + q : win_end - 1;
+      in[q].off[0] = in[q].off[1] = in[q].off[2] = 0.0;
+      if (in[q].b >= M) {  // IR.cpp:137-144: only frame b itself
+        const double* __restrict__ f = frames + (size_t)MVO_FRAME_DOUBLES * wq * N + MVO_FRAME_DOUBLES * in[q].b;
+        const double nb = f[12];
+        in[q].off[0] = nb * f[9];
+        in[q].off[1] = nb * f[10];
+        in[q].off[2] = nb * f[11];
+      }
+    }
   }
   // both system buffers of every window start from zero (see k_lm: the elimination reads whole rows)
   for (int i = lane; i < LM4_WINDOWS * 2 * MVO_MAXC * MVO_MAXC; i += 64) {
