@@ -190,6 +190,7 @@ struct mvo_hip_context {
   uint32_t env_waves_per_cu = 16;
   int env_overlap_chunks = 0;  // 0: the default (kOverlapChunks)
   bool env_no_host_results = false, env_no_poll = false;
+  uint32_t env_slots_min_w = 1, env_slots_max_p = 64;  // MVO_HIP_SLOTS_MIN_W / _MAX_P (experiments): slots plan for W > / P <=
   bool env_lm4_sums = false;  // MVO_HIP_LM4_SUMS: k_lm4 behind a fold WITH ticket tails, cut as for the other kernels (round 3's plan)
   bool env_no_tails = false;  // MVO_HIP_NO_TAILS: per-pair sums by k_reduce_slots launches instead of the passes' ticket tails
   bool env_lm_generic = false;  // MVO_HIP_LM_GENERIC: k_lm<NT, 0> for every solve (no compile-time specialisation)
@@ -1026,10 +1027,8 @@ bool lm4_eligible(const mvo_hip_context* h) {
 // the fold runs without ticket tails and is cut finer (mvo_hip_upload decides per upload: h->slots_plan).
 // MVO_HIP_LM4_SUMS: never (round 3's plan: tails, per-pair sums).
 bool slots_plan_static(const mvo_hip_context* h) {
-  if (h->pass_mode || h->inline_eval || h->env_lm4_sums || h->P > 64) return false;
-  uint32_t min_w = 1;
-  if (const char* e = std::getenv("MVO_HIP_SLOTS_MIN_W")) min_w = (uint32_t)std::atoi(e);
-  return h->W > min_w;
+  if (h->pass_mode || h->inline_eval || h->env_lm4_sums || h->P > h->env_slots_max_p) return false;
+  return h->W > h->env_slots_min_w;
 }
 // marks_only: the launch covers every window of the solve and nothing else counts them: completion is checked on the
 // records' marks (h->lm4_mark, new for every solve) instead of the done counter
@@ -1650,6 +1649,8 @@ int mvo_hip_create(int device_ordinal, uint32_t max_windows, uint32_t max_frames
   h->env_no_poll = std::getenv("MVO_HIP_NO_POLL") != nullptr;
   h->env_no_tails = std::getenv("MVO_HIP_NO_TAILS") != nullptr;
   h->env_lm4_sums = std::getenv("MVO_HIP_LM4_SUMS") != nullptr;
+  if (const char* e = std::getenv("MVO_HIP_SLOTS_MIN_W")) h->env_slots_min_w = (uint32_t)std::atoi(e);
+  if (const char* e = std::getenv("MVO_HIP_SLOTS_MAX_P")) h->env_slots_max_p = (uint32_t)std::atoi(e);
   h->env_lm_generic = std::getenv("MVO_HIP_LM_GENERIC") != nullptr;
   h->env_no_persistent = std::getenv("MVO_HIP_NO_PERSISTENT") != nullptr;
   h->env_no_fused = std::getenv("MVO_HIP_NO_FUSED") != nullptr;
