@@ -826,6 +826,7 @@ def main():
             else:
                 all_ws, _, _ = build_workload(args.workload, 0, 1, "single")
             solver.upload(all_ws, opt)
+            solver.set_profiling(False)  # as the timed region runs three steps in four: no event records
             for _ in range(2):
                 solver.solve()
             k = max(3, min(args.steps, 10))
@@ -873,9 +874,10 @@ def main():
         # N > 1 default workload measured on this one GPU (same code path as `--workload config3`).
         base_ws, base_opt, base_desc = build_workload("config3", 0, 1, "single")
         solver.upload(base_ws, base_opt)
-        for _ in range(2):
+        solver.set_profiling(False)  # the library's default; `--workload config3` records events on every 4th step only
+        for _ in range(3):
             solver.solve()
-        k = 5
+        k = 10
         t1 = time.perf_counter()
         for _ in range(k):
             solver.solve()
