@@ -53,7 +53,14 @@ struct SolveParams {
                         // in `proj` (project_pair8, mvo_kernels.h)
   int32_t cls_ready;    // ... observation-partitioned: the class totals of the evaluation, summed over the ranks, are
                         // in `cls_in` (k_class_sums + all-reduce)
+  // One window of at most MVO_SMALL_PAIRS frame pairs that evaluates its own observations (the reference's shipped
+  // window: three): the pairs' offsets into the ray arrays travel with the kernel arguments, so the first loads of the
+  // launch are the rays themselves and not a table whose entries say where they are (one cold round trip, ~0.8 us of
+  // a 26-us call).  small_tab = 0: the pair table in memory.
+  int32_t small_tab;
+  uint32_t small_offs[9];  // pair p: residual blocks small_offs[p] .. small_offs[p + 1]
 };
+#define MVO_SMALL_PAIRS 8
 #define MVO_CLS_DOUBLES 352  // per window: cls[MAXM * (MAXM + 1)][10], kk[MAXM][10], padded to a multiple of 4
 
 struct TraceRec {  // == mvo_hip_iteration

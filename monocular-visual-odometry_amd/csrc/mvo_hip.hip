@@ -362,6 +362,13 @@ SolveParams make_params(const mvo_hip_context* h) {
   prm.M = (int32_t)h->M;
   prm.N = (int32_t)h->N;
   prm.P = (int32_t)h->P;
+  // one small window that evaluates its own observations: where each pair's rays lie goes with the kernel arguments
+  prm.small_tab = 0;
+  if (h->inline_eval && h->W == 1 && h->P <= MVO_SMALL_PAIRS && h->h_pairs.size() == h->P && !h->env_lm_generic) {
+    prm.small_tab = 1;
+    for (uint32_t p = 0; p < h->P; ++p) prm.small_offs[p] = h->h_pairs[p].src_start;
+    prm.small_offs[h->P] = h->P ? h->h_pairs[h->P - 1].src_start + h->h_pairs[h->P - 1].count : 0;
+  }
   return prm;
 }
 

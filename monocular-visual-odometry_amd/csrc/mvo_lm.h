@@ -1102,14 +1102,31 @@ __device__ __forceinline__ int sym6(int r, int c) {
 // LDS_OUT (k_lm<64>): the sums stay in LDS (lds_sums) -- the wavefront that wrote them reads them right
 // back, a store -> load round trip through the L2 per evaluation otherwise.
 template <int MODE, int NT, bool LDS_OUT = false>
-__device__ __forceinline__ void inline_pass(const LmShared& sh, const PairDev* __restrict__ wp, int P, int M,
-                                            const double* __restrict__ fr, const double* __restrict__ m0,
-                                            const double* __restrict__ m1, double* pair_sums,
-                                            double* lds_sums = nullptr) {
+__device__ __forceinline__ void inline_pass(const LmShared& sh, const SolveParams& prm, const PairDev* __restrict__ wp,
+                                            int P, int M, const double* __restrict__ fr,
+                                            const double* __restrict__ m0, const double* __restrict__ m1,
+                                            double* pair_sums, double* lds_sums = nullptr) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   for (int p = wave; p < P; p += NT / 64) {
-    const PairDev pd = wp[p];
+    PairDev pd;
+    if (prm.small_tab) {  // (uniform) the pair's place in the ray arrays from the kernel arguments, (a, b) by arithmetic
+      uint32_t s0 = 0, s1 = 0;
+#pragma unroll
+      for (int k = 0; k < MVO_SMALL_PAIRS; ++k) {
+        s0 = p == k ? prm.small_offs[k] : s0;
+        s1 = p == k ? prm.small_offs[k + 1] : s1;
+      }
+      int a, b;
+      pair_ab(prm.N, M, p, a, b);
+      pd.a = (uint32_t)a;
+      pd.b = (uint32_t)b;
+      pd.src_start = s0;
+      pd.count = s1 - s0;
+      pd.slot_begin = pd.slot_end = 0;
+    } else {
+      pd = wp[p];
+    }
     const double* __restrict__ R0 = fr + MVO_FRAME_DOUBLES * pd.a;        // IR.cpp:172
     const double* __restrict__ R1 = fr + MVO_FRAME_DOUBLES * (pd.b + 1);  // IR.cpp:171
     const double a0 = R0[0], a1 = R0[1], a2 = R0[2], a3 = R0[3], a4 = R0[4], a5 = R0[5], a6 = R0[6], a7 = R0[7],
@@ -1434,8 +1451,8 @@ __device__ __forceinline__ void lm_class_wave(LmShared& sh, const SolveParams& p
   if (solver_wave) lm_solver_init(slv, sh, lane);
   while (!need_pass) {
     if (prm.inline_eval && prm.pass_mode) {
-      if (prm.use_loss) inline_pass<2, NT>(sh, wp, P, M, fr, m0, m1, my_sums);
-      else inline_pass<1, NT>(sh, wp, P, M, fr, m0, m1, my_sums);
+      if (prm.use_loss) inline_pass<2, NT>(sh, prm, wp, P, M, fr, m0, m1, my_sums);
+      else inline_pass<1, NT>(sh, prm, wp, P, M, fr, m0, m1, my_sums);
       __syncthreads();  // B0
     }
     if (!have_in) {
@@ -1772,7 +1789,7 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
   }
   double* my_sums = pair_sums + (size_t)win.pair_off * 8;
   if (prm.inline_eval && !prm.pass_mode) {  // no loss: the moments are folded once, here
-    inline_pass<0, NT, !LARGE>(sh, wp, P, M, fr, m0, m1, my_sums, inl_sums);
+    inline_pass<0, NT, !LARGE>(sh, prm, wp, P, M, fr, m0, m1, my_sums, inl_sums);
     __syncthreads();
   }
 
@@ -1812,8 +1829,8 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
     MVO_STAMP(0);
     // ---------------- evaluation at z: assemble J^T J, J^T r, cost ----------------
     if (prm.inline_eval && prm.pass_mode) {  // one observation pass per evaluation, in this workgroup
-      if (prm.use_loss) inline_pass<2, NT, !LARGE>(sh, wp, P, M, fr, m0, m1, my_sums, inl_sums);
-      else inline_pass<1, NT, !LARGE>(sh, wp, P, M, fr, m0, m1, my_sums, inl_sums);
+      if (prm.use_loss) inline_pass<2, NT, !LARGE>(sh, prm, wp, P, M, fr, m0, m1, my_sums, inl_sums);
+      else inline_pass<1, NT, !LARGE>(sh, prm, wp, P, M, fr, m0, m1, my_sums, inl_sums);
       __syncthreads();  // B0
     }
     // (1) per frame pair: projected moments.  Without a loss the moments never change: the inputs are
