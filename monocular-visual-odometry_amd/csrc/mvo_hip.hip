@@ -191,6 +191,7 @@ struct mvo_hip_context {
   int env_overlap_chunks = 0;  // 0: the default (kOverlapChunks)
   bool env_no_host_results = false, env_no_poll = false;
   uint32_t env_slots_min_w = 1, env_slots_max_p = 64;  // MVO_HIP_SLOTS_MIN_W / _MAX_P (experiments): slots plan for W > / P <=
+  bool env_arena_copy = false;  // MVO_HIP_ARENA_COPY: a small window's arena is copied to the device like any other
   bool env_lm4_sums = false;  // MVO_HIP_LM4_SUMS: k_lm4 behind a fold WITH ticket tails, cut as for the other kernels (round 3's plan)
   bool env_no_tails = false;  // MVO_HIP_NO_TAILS: per-pair sums by k_reduce_slots launches instead of the passes' ticket tails
   bool env_lm_generic = false;  // MVO_HIP_LM_GENERIC: k_lm<NT, 0> for every solve (no compile-time specialisation)
@@ -346,6 +347,10 @@ int validate(uint32_t n_windows, const void* frames, uint32_t M, uint32_t N, con
   return MVO_HIP_OK;
 }
 
+// one window of at most MVO_SMALL_PAIRS frame pairs that folds its own observations (the reference's shipped window)
+bool small_window(const mvo_hip_context* h) {
+  return h->inline_eval && h->W == 1 && h->P <= MVO_SMALL_PAIRS && !h->env_lm_generic;
+}
 SolveParams make_params(const mvo_hip_context* h) {
   SolveParams prm{};
   prm.ftol = h->opt.function_tolerance;
@@ -364,7 +369,7 @@ SolveParams make_params(const mvo_hip_context* h) {
   prm.P = (int32_t)h->P;
   // one small window that evaluates its own observations: where each pair's rays lie goes with the kernel arguments
   prm.small_tab = 0;
-  if (h->inline_eval && h->W == 1 && h->P <= MVO_SMALL_PAIRS && h->h_pairs.size() == h->P && !h->env_lm_generic) {
+  if (small_window(h) && h->h_pairs.size() == h->P) {
     prm.small_tab = 1;
     for (uint32_t p = 0; p < h->P; ++p) prm.small_offs[p] = h->h_pairs[p].src_start;
     prm.small_offs[h->P] = h->P ? h->h_pairs[h->P - 1].src_start + h->h_pairs[h->P - 1].count : 0;
@@ -731,7 +736,14 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
   }
 
   char* ha = h->h_arena;
-  char* da = h->d_arena.as<char>();
+  // One small window without a loss (small_window: the reference's shipped call): the kernel reads frames, starting
+  // point and rays WHERE THE HOST WROTE THEM -- the arena is pinned and mapped into the device's address space, the
+  // pairs' offsets travel with the kernel arguments (SolveParams::small_offs), so the launch's first loads are one
+  // round trip over PCIe and there is no copy command in front of it.  With a loss the rays are read once per
+  // evaluation: copied.  MVO_HIP_ARENA_COPY: always copied.
+  const bool arena_in_place = small_window(h) && !h->pass_mode && rays_in_arena && !rays_on_device && !no_rays &&
+                              !h->env_arena_copy && arena_bytes <= (64u << 10);
+  char* da = arena_in_place ? ha : h->d_arena.as<char>();
   std::memcpy(ha + o_frames, frames, sizeof(mvo_hip_frame) * (size_t)W * N);
   std::memcpy(ha + o_initx, initx.data(), sizeof(double) * initx.size());
   std::memcpy(ha + o_wins, wins.data(), sizeof(WinDev) * W);
@@ -774,7 +786,8 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
     }
     pos += cnt;
   }
-  HIP_TRY(hipMemcpyAsync(da, ha, rays_on_device && rays_in_arena ? o_m0 : arena_bytes, hipMemcpyHostToDevice, s));
+  if (!arena_in_place)
+    HIP_TRY(hipMemcpyAsync(da, ha, rays_on_device && rays_in_arena ? o_m0 : arena_bytes, hipMemcpyHostToDevice, s));
   if (rays_in_arena || rays_on_device || rays_pinned) {
     h->copy_pending = true;  // pinned source: the copy is asynchronous and the solve is queued behind it
   } else {
@@ -1655,6 +1668,7 @@ int mvo_hip_create(int device_ordinal, uint32_t max_windows, uint32_t max_frames
   h->env_no_host_results = std::getenv("MVO_HIP_NO_HOST_RESULTS") != nullptr;
   h->env_no_poll = std::getenv("MVO_HIP_NO_POLL") != nullptr;
   h->env_no_tails = std::getenv("MVO_HIP_NO_TAILS") != nullptr;
+  h->env_arena_copy = std::getenv("MVO_HIP_ARENA_COPY") != nullptr;
   h->env_lm4_sums = std::getenv("MVO_HIP_LM4_SUMS") != nullptr;
   if (const char* e = std::getenv("MVO_HIP_SLOTS_MIN_W")) h->env_slots_min_w = (uint32_t)std::atoi(e);
   if (const char* e = std::getenv("MVO_HIP_SLOTS_MAX_P")) h->env_slots_max_p = (uint32_t)std::atoi(e);
