@@ -347,9 +347,9 @@ int validate(uint32_t n_windows, const void* frames, uint32_t M, uint32_t N, con
   return MVO_HIP_OK;
 }
 
-// one window of at most MVO_SMALL_PAIRS frame pairs that folds its own observations (the reference's shipped window)
+// one window of at most MVO_SMALL_PAIRS frame pairs, no loss, that folds its own observations (the reference's shipped window)
 bool small_window(const mvo_hip_context* h) {
-  return h->inline_eval && h->W == 1 && h->P <= MVO_SMALL_PAIRS && !h->env_lm_generic;
+  return h->inline_eval && !h->pass_mode && h->W == 1 && h->P <= MVO_SMALL_PAIRS && !h->env_lm_generic;
 }
 SolveParams make_params(const mvo_hip_context* h) {
   SolveParams prm{};
@@ -741,7 +741,7 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
   // pairs' offsets travel with the kernel arguments (SolveParams::small_offs), so the launch's first loads are one
   // round trip over PCIe and there is no copy command in front of it.  With a loss the rays are read once per
   // evaluation: copied.  MVO_HIP_ARENA_COPY: always copied.
-  const bool arena_in_place = small_window(h) && !h->pass_mode && rays_in_arena && !rays_on_device && !no_rays &&
+  const bool arena_in_place = small_window(h) && rays_in_arena && !rays_on_device && !no_rays &&
                               !h->env_arena_copy && arena_bytes <= (64u << 10);
   char* da = arena_in_place ? ha : h->d_arena.as<char>();
   std::memcpy(ha + o_frames, frames, sizeof(mvo_hip_frame) * (size_t)W * N);
