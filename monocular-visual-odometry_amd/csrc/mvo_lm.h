@@ -1704,16 +1704,6 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
   const double* __restrict__ fr = frames + (size_t)MVO_FRAME_DOUBLES * win.frame_off;
   const PairDev* __restrict__ wp = pairs + win.pair_off;
 
-  // The launch's first global loads, all issued before anything waits: the starting point (used behind the first
-  // barrier) and, for a window that folds its own observations without a loss, the fold itself (below, in front of that
-  // barrier) -- one round trip for both instead of two in a row (they are PCIe round trips when a small window's arena
-  // is read in place, mvo_hip_upload).
-  double x0r[4] = {0.0, 0.0, 0.0, 0.0};
-  if (wave0 && lane < M) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) x0r[e] = init_x[((size_t)w * MVO_MAXM + lane) * 4 + e];
-  }
-  double* my_sums = pair_sums + (size_t)win.pair_off * 8;
   // solver state HBM -> LDS (all threads), then the point to evaluate is published by wave 0
   for (int i = tid; i < (int)(sizeof(LmState) / 8); i += NT)
     reinterpret_cast<double*>(&sh.st)[i] = fresh ? 0.0 : reinterpret_cast<const double*>(gst)[i];
@@ -1736,8 +1726,6 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
       sfoff[3 * b + 1] = nb * f[10];
       sfoff[3 * b + 2] = nb * f[11];
     }
-  // no loss: the moments are folded once, here (a solve of this kind is ONE launch: the window has not terminated)
-  if (prm.inline_eval && !prm.pass_mode) inline_pass<0, NT, !LARGE>(sh, prm, wp, P, M, fr, m0, m1, my_sums, inl_sums);
   __syncthreads();
   if (sh.st.status != 0) return;  // a window that has terminated (uniform)
   LmRegs r;      // wavefront 0: the solver state, in registers until the launch ends
@@ -1747,10 +1735,10 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
     const int k = lane < M ? lane : 0;
     if (st.phase == PH_START && lane < M) {
       // IR.cpp:95-109: vec_k from the frame, t_k = reverseScale(scale_k) (host libm, uploaded)
-      st.x_vec[k][0] = x0r[0];
-      st.x_vec[k][1] = x0r[1];
-      st.x_vec[k][2] = x0r[2];
-      st.x_t[k] = x0r[3];
+      st.x_vec[k][0] = init_x[((size_t)w * MVO_MAXM + k) * 4 + 0];
+      st.x_vec[k][1] = init_x[((size_t)w * MVO_MAXM + k) * 4 + 1];
+      st.x_vec[k][2] = init_x[((size_t)w * MVO_MAXM + k) * 4 + 2];
+      st.x_t[k] = init_x[((size_t)w * MVO_MAXM + k) * 4 + 3];
     }
     if (st.phase != PH_EVAL_CAND) lm_publish_point(sh, prm, M, lane, st.x_vec[k], st.x_t[k]);
     else lm_publish_point(sh, prm, M, lane, st.c_vec[k], st.c_t[k]);
@@ -1798,6 +1786,11 @@ __global__ __launch_bounds__(NT) void k_lm(SolveParams prm, int unit_slots, cons
     r.phase = PH_EVAL_X0;
     // x0_ready: the fold was the pass at the starting point (k_fold<.., PASS0>): its sums are there
     need_pass = prm.pass_mode != 0 && !prm.inline_eval && !prm.x0_ready;
+  }
+  double* my_sums = pair_sums + (size_t)win.pair_off * 8;
+  if (prm.inline_eval && !prm.pass_mode) {  // no loss: the moments are folded once, here
+    inline_pass<0, NT, !LARGE>(sh, prm, wp, P, M, fr, m0, m1, my_sums, inl_sums);
+    __syncthreads();
   }
 
   // ---- who evaluates which frame pair (fixed for the launch) ---------------------------------
