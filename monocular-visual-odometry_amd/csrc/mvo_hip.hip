@@ -149,6 +149,7 @@ constexpr int kOverlapChunks = 4;  // a k_lm launch over W / 4 windows takes abo
 constexpr uint64_t kArenaRayLimit = 1u << 16;
 // windows with at most this many residual blocks are evaluated inside k_lm
 constexpr uint64_t kInlineWindowLimit = 8192;
+constexpr uint64_t kInlineFusedLimit = 3072;  // ... when the alternative is the fused fold + LM launch (mvo_hip_upload)
 
 }  // namespace
 
@@ -191,6 +192,7 @@ struct mvo_hip_context {
   int env_overlap_chunks = 0;  // 0: the default (kOverlapChunks)
   bool env_no_host_results = false, env_no_poll = false;
   uint32_t env_slots_min_w = 1, env_slots_max_p = 64;  // MVO_HIP_SLOTS_MIN_W / _MAX_P (experiments): slots plan for W > / P <=
+  bool one_shot = false;        // set by mvo_hip_refine* around their upload: the upload is solved exactly once
   bool env_arena_copy = false;  // MVO_HIP_ARENA_COPY: a small window's arena is copied to the device like any other
   bool env_lm4_sums = false;  // MVO_HIP_LM4_SUMS: k_lm4 behind a fold WITH ticket tails, cut as for the other kernels (round 3's plan)
   bool env_no_tails = false;  // MVO_HIP_NO_TAILS: per-pair sums by k_reduce_slots launches instead of the passes' ticket tails
@@ -460,7 +462,15 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
     // quarter of the LM wavefronts beat a fold per window inside its own workgroup
     h->inline_eval = false;
     const bool four_per_wave = lm4_eligible(h);
-    h->inline_eval = max_win_obs <= kInlineWindowLimit && !(opt->assembly_mode & MVO_HIP_ASSEMBLY_TILED) && !four_per_wave;
+    // One window without a loss that the fused launch can take (fold chip-wide and LM loop in ONE launch, fused_ok):
+    // that launch is ahead from ~3 k residual blocks on (N = 10, M = 5, fixed 10 iterations, no event records: 2100 blocks
+    // 51.1 us inline against 52.6, 4200: 53.8 against 51.0, 8050: 56.4 against 50.3; 135 pairs, 8100 blocks: 67.8 against
+    // 54.0 -- scripts/exp/inline_vs_fused.py).  (Event records asked for AFTER the upload make it two launches.)
+    const bool fused_likely = W == 1 && !h->pass_mode && !opt->fix_length && h->trace_cap == 0 && N - 1 - M <= 32 &&
+                              !h->env_no_fused && !h->fused_failed && !h->env_lm_generic && !h->env_no_tails &&
+                              !h->profiling && n_obs >= 16ull * P;
+    const uint64_t inline_limit = fused_likely ? kInlineFusedLimit : kInlineWindowLimit;
+    h->inline_eval = max_win_obs <= inline_limit && !(opt->assembly_mode & MVO_HIP_ASSEMBLY_TILED) && !four_per_wave;
   }
   // One chunk of consecutive residual blocks per wavefront, all wavefronts resident at once:
   // waves_per_cu * 256 CUs of them, but at least kMinChunk blocks each so that small problems
@@ -741,8 +751,14 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
   // pairs' offsets travel with the kernel arguments (SolveParams::small_offs), so the launch's first loads are one
   // round trip over PCIe and there is no copy command in front of it.  With a loss the rays are read once per
   // evaluation: copied.  MVO_HIP_ARENA_COPY: always copied.
-  const bool arena_in_place = small_window(h) && rays_in_arena && !rays_on_device && !no_rays &&
-                              !h->env_arena_copy && arena_bytes <= (64u << 10);
+  // Only for the one-shot calls (mvo_hip_refine*: upload, ONE solve, download -- an upload that is solved many times
+  // is better off in HBM) and only when every pair's rays are ONE load per lane of the wavefront that folds the pair
+  // (<= 64 residual blocks: a second trip would be a second PCIe round trip; 900 blocks in three pairs measured 45.6 us
+  // per solve in place against 41.3 us through the chip-wide fold, scripts/exp/inline_vs_fused.py).
+  bool one_trip = true;
+  for (const PairDev& pd : pairs) one_trip = one_trip && pd.count <= 64;
+  const bool arena_in_place = h->one_shot && small_window(h) && one_trip && rays_in_arena && !rays_on_device &&
+                              !no_rays && !h->env_arena_copy && arena_bytes <= (64u << 10);
   char* da = arena_in_place ? ha : h->d_arena.as<char>();
   std::memcpy(ha + o_frames, frames, sizeof(mvo_hip_frame) * (size_t)W * N);
   std::memcpy(ha + o_initx, initx.data(), sizeof(double) * initx.size());
@@ -1771,7 +1787,9 @@ int mvo_hip_refine_batch(mvo_hip_handle h, uint32_t n_windows, mvo_hip_frame* fr
                          const mvo_hip_options* options, const mvo_hip_observations* observations,
                          mvo_hip_summary* summaries) {
   if (!h) return MVO_HIP_ERR_INVALID_ARGUMENT;
+  h->one_shot = true;
   int rc = do_upload(h, n_windows, frames, M, N, options, observations);
+  h->one_shot = false;
   if (rc != MVO_HIP_OK) return rc;
   rc = do_solve(h);
   if (rc != MVO_HIP_OK) return rc;
@@ -1839,7 +1857,9 @@ int mvo_hip_refine_staged(mvo_hip_handle h, mvo_hip_frame* frames, uint32_t M, u
   obs.pair_offsets = h->h_st_offs;
   obs.m0 = h->h_st_m0;
   obs.m1 = h->h_st_m1;
+  h->one_shot = true;
   int rc = do_upload(h, 1, frames, M, N, options, &obs, false, false, true);
+  h->one_shot = false;
   if (rc != MVO_HIP_OK) return rc;
   rc = do_solve(h);
   if (rc != MVO_HIP_OK) return rc;
