@@ -92,3 +92,21 @@ def test_a_wait_that_gives_up_falls_back_on_two_launches(solver):
         _same(fa, sa, fb, sb, w.M)
     finally:
         failing.close()
+
+
+def test_a_window_of_a_few_thousand_blocks_takes_the_fused_launch_by_default(oracle):
+    """Between 3072 and 8192 residual blocks a single window without a loss is folded chip-wide inside the fused launch
+    (no event records at upload time) instead of by its own workgroup: one launch, no assembly launch, same results as
+    the inline fold of a handle that records events (to rounding: the sums are cut differently) and as the oracle."""
+    w = scene.make_window(10, 5, 150, seed=5400)
+    assert 3072 < w.n_residual_blocks <= 8192
+    opt = capi.make_options(max_num_iterations=30)
+    with capi.Solver(0, profiling=False) as quiet, capi.Solver(0, profiling=True) as timed:
+        fa, sa = quiet.refine(w, opt)
+        assert quiet.timing()["lm_launches"] == 1 and quiet.timing()["assembly_launches"] == 0
+        fb, sb = timed.refine(w, opt)
+    fo, so, _ = oracle.refine(w, oracle.make_options(max_num_iterations=30))
+    for f, s in ((fa, sa), (fb, sb)):
+        assert (s.termination, s.reason, s.iterations) == (so.termination, so.reason, so.iterations)
+        assert abs(s.final_cost - so.final_cost) <= 1e-9 * so.initial_cost
+        assert np.abs(refined(f, w.M) - refined(fo, w.M)).max() < 1e-6
