@@ -191,6 +191,7 @@ struct mvo_hip_context {
   uint32_t env_waves_per_cu = 16;
   int env_overlap_chunks = 0;  // 0: the default (kOverlapChunks)
   bool env_no_host_results = false, env_no_poll = false;
+  uint32_t env_host_results_max_w = 640;  // MVO_HIP_HOST_RESULTS_MAX_W
   uint32_t env_slots_min_w = 1, env_slots_max_p = 64;  // MVO_HIP_SLOTS_MIN_W / _MAX_P (experiments): slots plan for W > / P <=
   bool one_shot = false;        // set by mvo_hip_refine* around their upload: the upload is solved exactly once
   bool env_arena_copy = false;  // MVO_HIP_ARENA_COPY: a small window's arena is copied to the device like any other
@@ -469,7 +470,13 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
     const bool fused_likely = W == 1 && !h->pass_mode && !opt->fix_length && h->trace_cap == 0 && N - 1 - M <= 32 &&
                               !h->env_no_fused && !h->fused_failed && !h->env_lm_generic && !h->env_no_tails &&
                               !h->profiling && n_obs >= 16ull * P;
-    const uint64_t inline_limit = fused_likely ? kInlineFusedLimit : kInlineWindowLimit;
+    // Batches without a loss of windows with at most 64 pairs (the slots plan's domain, below): the chip-wide fold without
+    // tails is level with the inline fold or ahead from ~3 k blocks per window on (scripts/exp/batch_inline_vs_tiled.py,
+    // call time inline / tiled: 64 windows of 1050 / 3500 / 7000 blocks 54.2 / 60.3, 57.3 / 54.4, 60.0 / 53.7 us), and beyond
+    // one window per CU the inline fold is one wavefront per window: 512 windows 106.8 / 102.8, 129.2 / 103.4, 145.7 / 112.3.
+    const bool slots_batch = W > 1 && !h->pass_mode && P <= 64;
+    const uint64_t inline_limit = fused_likely ? kInlineFusedLimit
+                                  : slots_batch ? (W > 256 ? 0 : kInlineFusedLimit) : kInlineWindowLimit;
     h->inline_eval = max_win_obs <= inline_limit && !(opt->assembly_mode & MVO_HIP_ASSEMBLY_TILED) && !four_per_wave;
   }
   // One chunk of consecutive residual blocks per wavefront, all wavefronts resident at once:
@@ -1366,9 +1373,12 @@ int do_solve(mvo_hip_context* h) {
   h->solved = false;
   h->lm4_marked = false;
   const uint32_t done_base = h->done_base;
-  // Up to 64 windows the result records (208 B each) are written by k_lm straight into the pinned host
-  // mirror: one command less on the stream (~4 us of a 45-us default-size solve).
-  h->results_on_host = h->W <= 64 && !h->env_no_host_results;  // MVO_HIP_NO_HOST_RESULTS
+  // Up to 640 windows (the batches k_lm<256> / k_lm<64> take; MVO_HIP_HOST_RESULTS_MAX_W) the result records (200 B
+  // each) are written by k_lm straight into the pinned host mirror: no copy command and no wait for the stream behind
+  // the kernel (~4 us of a 45-us default-size solve; 128 / 256 / 512 windows: 71 -> 59, 79 -> 69, 101.6 -> 94.4 us per
+  // call; the limit was 64 until the end of round 3).  Beyond, k_lm4's marks-only epilogue and ONE copy are the
+  // faster (1024 windows: level; 4096: 502 us copied against 524).
+  h->results_on_host = h->W <= h->env_host_results_max_w && !h->env_no_host_results;  // MVO_HIP_NO_HOST_RESULTS
   if (h->results_on_host)
     for (uint32_t w = 0; w < h->W; ++w) h->h_results[w].pad = 0;
 
@@ -1682,6 +1692,7 @@ int mvo_hip_create(int device_ordinal, uint32_t max_windows, uint32_t max_frames
     if (t >= 2 && t <= kMaxOverlapChunks) h->env_overlap_chunks = t;
   }
   h->env_no_host_results = std::getenv("MVO_HIP_NO_HOST_RESULTS") != nullptr;
+  if (const char* e = std::getenv("MVO_HIP_HOST_RESULTS_MAX_W")) h->env_host_results_max_w = (uint32_t)std::atoi(e);
   h->env_no_poll = std::getenv("MVO_HIP_NO_POLL") != nullptr;
   h->env_no_tails = std::getenv("MVO_HIP_NO_TAILS") != nullptr;
   h->env_arena_copy = std::getenv("MVO_HIP_ARENA_COPY") != nullptr;

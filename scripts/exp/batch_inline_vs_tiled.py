@@ -7,9 +7,9 @@ import numpy as np
 from mvo_amd import capi, scene
 fixed = dict(max_num_iterations=10, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
 with capi.Solver(0, profiling=False) as s:
-    for L in (30, 100, 200):
+    for L in [int(a) for a in sys.argv[1:]] or (30, 100, 200):
         base = [scene.make_window(10, 5, L, seed=900 + i) for i in range(16)]
-        for W in (2, 8, 32, 64, 128, 256, 512):
+        for W in (32, 64, 128, 256, 512, 1024, 4096):
             ws = [base[i % 16] for i in range(W)]
             row = []
             for name, mode in (("inline", 0), ("tiled", capi.ASSEMBLY_TILED)):
