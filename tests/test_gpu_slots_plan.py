@@ -81,3 +81,29 @@ def test_pairs_without_observations_in_the_batch(solver, mode):
         _close(sa, sb, fa, fb, 5)
     finally:
         sums.close()
+
+
+@pytest.mark.parametrize("n", [65, 300, 640])
+def test_records_written_into_the_host_mirror_equal_copied_records(solver, n):
+    """Up to 640 windows k_lm<256> / k_lm<64> write the result records and their marks into the pinned host mirror and
+    the host polls the marks (64 windows until the end of round 3); a handle created under MVO_HIP_NO_HOST_RESULTS has
+    them copied by the stream.  Same kernels, same data: identical results.  (mvo_hip_refine_batch; the write-back of
+    IterativeRefinement.cpp:236-252 per window.)"""
+    base = [scene.config3_window(i) for i in range(8)]
+    ws = [base[i % 8] for i in range(n)]
+    os.environ["MVO_HIP_NO_HOST_RESULTS"] = "1"
+    try:
+        copied = capi.Solver(0)
+    finally:
+        del os.environ["MVO_HIP_NO_HOST_RESULTS"]
+    try:
+        opt = capi.make_options(max_num_iterations=50, function_tolerance=1e-6, gradient_tolerance=1e-10,
+                                parameter_tolerance=1e-8)
+        fa, sa = solver.refine_batch(ws, opt)
+        fb, sb = copied.refine_batch(ws, opt)
+        assert np.array_equal(np.asarray(fa), np.asarray(fb))
+        for a, b in zip(sa, sb):
+            assert (a.termination, a.reason, a.iterations, a.initial_cost, a.final_cost) == \
+                   (b.termination, b.reason, b.iterations, b.initial_cost, b.final_cost)
+    finally:
+        copied.close()
