@@ -191,7 +191,7 @@ struct mvo_hip_context {
   uint32_t env_waves_per_cu = 16;
   int env_overlap_chunks = 0;  // 0: the default (kOverlapChunks)
   bool env_no_host_results = false, env_no_poll = false;
-  uint32_t env_host_results_max_w = 640;  // MVO_HIP_HOST_RESULTS_MAX_W
+  uint32_t env_host_results_max_w = 1024;  // MVO_HIP_HOST_RESULTS_MAX_W
   uint32_t env_slots_min_w = 1, env_slots_max_p = 64;  // MVO_HIP_SLOTS_MIN_W / _MAX_P (experiments): slots plan for W > / P <=
   bool one_shot = false;        // set by mvo_hip_refine* around their upload: the upload is solved exactly once
   bool env_arena_copy = false;  // MVO_HIP_ARENA_COPY: a small window's arena is copied to the device like any other
@@ -1373,11 +1373,12 @@ int do_solve(mvo_hip_context* h) {
   h->solved = false;
   h->lm4_marked = false;
   const uint32_t done_base = h->done_base;
-  // Up to 640 windows (the batches k_lm<256> / k_lm<64> take; MVO_HIP_HOST_RESULTS_MAX_W) the result records (200 B
-  // each) are written by k_lm straight into the pinned host mirror: no copy command and no wait for the stream behind
-  // the kernel (~4 us of a 45-us default-size solve; 128 / 256 / 512 windows: 71 -> 59, 79 -> 69, 101.6 -> 94.4 us per
-  // call; the limit was 64 until the end of round 3).  Beyond, k_lm4's marks-only epilogue and ONE copy are the
-  // faster (1024 windows: level; 4096: 502 us copied against 524).
+  // Up to 1024 windows (MVO_HIP_HOST_RESULTS_MAX_W) the result records (200 B each) are written by the LM kernel
+  // straight into the pinned host mirror: no copy command and no wait for the stream behind the kernel (~4 us of a
+  // 45-us default-size solve; config-3 windows, call time: 128 / 256 / 512 windows 75.0 -> 63.0, 87.8 -> 77.3, 120.9 ->
+  // 113.8 us, 704 / 768 / 896 / 1024 windows 153.1 -> 139.8, 158.2 -> 147.1, 169.8 -> 162.4, 181.8 -> 177.6; the limit
+  // was 64 until the end of round 3).  Beyond, k_lm4's marks-only epilogue and ONE copy are the faster (1536 windows:
+  // 229.9 us copied against 232.3, 2048: 277.4 against 288.0, 4096: 502 against 524).
   h->results_on_host = h->W <= h->env_host_results_max_w && !h->env_no_host_results;  // MVO_HIP_NO_HOST_RESULTS
   if (h->results_on_host)
     for (uint32_t w = 0; w < h->W; ++w) h->h_results[w].pad = 0;

@@ -83,9 +83,9 @@ def test_pairs_without_observations_in_the_batch(solver, mode):
         sums.close()
 
 
-@pytest.mark.parametrize("n", [65, 300, 640])
+@pytest.mark.parametrize("n", [65, 300, 640, 1000])
 def test_records_written_into_the_host_mirror_equal_copied_records(solver, n):
-    """Up to 640 windows k_lm<256> / k_lm<64> write the result records and their marks into the pinned host mirror and
+    """Up to 1024 windows the LM kernels write the result records and their marks into the pinned host mirror and
     the host polls the marks (64 windows until the end of round 3); a handle created under MVO_HIP_NO_HOST_RESULTS has
     them copied by the stream.  Same kernels, same data: identical results.  (mvo_hip_refine_batch; the write-back of
     IterativeRefinement.cpp:236-252 per window.)"""
