@@ -1379,7 +1379,9 @@ int do_solve(mvo_hip_context* h) {
   // 113.8 us, 704 / 768 / 896 / 1024 windows 153.1 -> 139.8, 158.2 -> 147.1, 169.8 -> 162.4, 181.8 -> 177.6; the limit
   // was 64 until the end of round 3).  Beyond, k_lm4's marks-only epilogue and ONE copy are the faster (1536 windows:
   // 229.9 us copied against 232.3, 2048: 277.4 against 288.0, 4096: 502 against 524).
-  h->results_on_host = h->W <= h->env_host_results_max_w && !h->env_no_host_results;  // MVO_HIP_NO_HOST_RESULTS
+  // (the chunked experiment paths -- MVO_HIP_OVERLAP, MVO_HIP_PIPELINE -- count finished windows and copy the records)
+  h->results_on_host = h->W <= h->env_host_results_max_w && !h->env_no_host_results &&  // MVO_HIP_NO_HOST_RESULTS
+                       !(h->n_chunks > 1 && !h->pass_mode && !h->inline_eval);
   if (h->results_on_host)
     for (uint32_t w = 0; w < h->W; ++w) h->h_results[w].pad = 0;
 
