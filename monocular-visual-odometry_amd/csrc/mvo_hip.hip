@@ -194,6 +194,7 @@ struct mvo_hip_context {
   uint32_t env_host_results_max_w = 1024;  // MVO_HIP_HOST_RESULTS_MAX_W
   uint32_t env_slots_min_w = 1, env_slots_max_p = 64;  // MVO_HIP_SLOTS_MIN_W / _MAX_P (experiments): slots plan for W > / P <=
   bool one_shot = false;        // set by mvo_hip_refine* around their upload: the upload is solved exactly once
+  int env_fused_max_blocks = 256;  // MVO_HIP_FUSED_MAX_BLOCKS: fold workgroups up to which fold and LM loop are one launch
   bool env_arena_copy = false;  // MVO_HIP_ARENA_COPY: a small window's arena is copied to the device like any other
   bool env_lm4_sums = false;  // MVO_HIP_LM4_SUMS: k_lm4 behind a fold WITH ticket tails, cut as for the other kernels (round 3's plan)
   bool env_no_tails = false;  // MVO_HIP_NO_TAILS: per-pair sums by k_reduce_slots launches instead of the passes' ticket tails
@@ -981,7 +982,7 @@ bool fused_ok(const mvo_hip_context* h, const SolveParams& prm) {
   if (h->W != 1 || h->pass_mode || h->inline_eval || h->sums_external || prm.trace_cap != 0) return false;
   if (lm_spec(prm, false) != 3) return false;
   const uint32_t blocks = (h->n_waves + FOLD_WAVES - 1) / FOLD_WAVES;
-  return blocks >= 1 && (int)blocks <= h->n_cus / 2 && h->max_block_tiles <= (uint32_t)kRobustMaxTiles &&
+  return blocks >= 1 && (int)blocks <= h->env_fused_max_blocks && h->max_block_tiles <= (uint32_t)kRobustMaxTiles &&
          h->h_pairs.size() == h->P;
 }
 hipError_t launch_lm_fused(mvo_hip_context* h, SolveParams prm) {
@@ -1699,6 +1700,7 @@ int mvo_hip_create(int device_ordinal, uint32_t max_windows, uint32_t max_frames
   h->env_no_poll = std::getenv("MVO_HIP_NO_POLL") != nullptr;
   h->env_no_tails = std::getenv("MVO_HIP_NO_TAILS") != nullptr;
   h->env_arena_copy = std::getenv("MVO_HIP_ARENA_COPY") != nullptr;
+
   h->env_lm4_sums = std::getenv("MVO_HIP_LM4_SUMS") != nullptr;
   if (const char* e = std::getenv("MVO_HIP_SLOTS_MIN_W")) h->env_slots_min_w = (uint32_t)std::atoi(e);
   if (const char* e = std::getenv("MVO_HIP_SLOTS_MAX_P")) h->env_slots_max_p = (uint32_t)std::atoi(e);
@@ -1711,6 +1713,10 @@ int mvo_hip_create(int device_ordinal, uint32_t max_windows, uint32_t max_frames
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess) h->n_cus = cus;
   }
+  // fold and LM loop as one launch up to one fold workgroup per CU (scripts/exp/fused_limit.py, config 2's shape, one
+  // launch / two: 120 k blocks 51.0 / 51.6 us, 168 k 50.7 / 51.6, 239 k 51.1 / 52.0, 359 k 55.5 / 53.2, 726 k 64.3 / 57.8)
+  h->env_fused_max_blocks = h->n_cus;
+  if (const char* e = std::getenv("MVO_HIP_FUSED_MAX_BLOCKS")) h->env_fused_max_blocks = std::atoi(e);
   if (hipSetDevice(device_ordinal) != hipSuccess ||
       hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
       mvo_noalloc_resolve(device_ordinal) != hipSuccess) {  // the library's set-up call: scratch address, once per device
