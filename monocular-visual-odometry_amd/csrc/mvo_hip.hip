@@ -475,10 +475,21 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
     // tails is level with the inline fold or ahead from ~3 k blocks per window on (scripts/exp/batch_inline_vs_tiled.py,
     // call time inline / tiled: 64 windows of 1050 / 3500 / 7000 blocks 54.2 / 60.3, 57.3 / 54.4, 60.0 / 53.7 us), and beyond
     // one window per CU the inline fold is one wavefront per window: 512 windows 106.8 / 102.8, 129.2 / 103.4, 145.7 / 112.3.
+    // One window UNDER THE LOSS that the persistent robust solver can take (robust_persistent_ok): the inline pass is one
+    // wavefront per PAIR and evaluation, the persistent solver a workgroup per 1024 blocks -- scripts/exp/
+    // inline_vs_persistent_loss.py, fixed 10 iterations, inline / persistent, us per solve: 3 pairs, 180 blocks 59.9 / 101.0;
+    // 7, 1400: 95.5 / 116.0; 11, 3300: 113.6 / 106.3; 18, 1080: 122.8 / 137.3; 18, 5400: 174.5 / 121.2; 22, 6600: 200.9 /
+    // 133.7; 30, 1800: 165.4 / 148.8; 35, 1050: 181.2 / 175.5; 35, 8050: 275.5 / 142.7; 85, 5100: 360.8 / 162.0; 135, 8100:
+    // 545.6 / 171.4.  Inline stays for few pairs or few blocks.
+    const bool persistent_likely = W == 1 && opt->use_loss_function && !opt->fix_length && h->trace_cap == 0 &&
+                                   !h->env_no_persistent && !h->persistent_failed && !h->env_lm_generic &&
+                                   !h->env_no_tails && P <= (uint32_t)kRobustMaxPairs;
+    const bool persistent_ahead = persistent_likely && ((P >= 10 && n_obs >= 2048) || (P >= 28 && n_obs >= 1536));
     const bool slots_batch = W > 1 && !h->pass_mode && P <= 64;
     const uint64_t inline_limit = fused_likely ? kInlineFusedLimit
                                   : slots_batch ? (W > 256 ? 0 : kInlineFusedLimit) : kInlineWindowLimit;
-    h->inline_eval = max_win_obs <= inline_limit && !(opt->assembly_mode & MVO_HIP_ASSEMBLY_TILED) && !four_per_wave;
+    h->inline_eval = max_win_obs <= inline_limit && !(opt->assembly_mode & MVO_HIP_ASSEMBLY_TILED) && !four_per_wave &&
+                     !persistent_ahead;
   }
   // One chunk of consecutive residual blocks per wavefront, all wavefronts resident at once:
   // waves_per_cu * 256 CUs of them, but at least kMinChunk blocks each so that small problems
