@@ -149,6 +149,7 @@ constexpr int kOverlapChunks = 4;  // a k_lm launch over W / 4 windows takes abo
 constexpr uint64_t kArenaRayLimit = 1u << 16;
 // windows with at most this many residual blocks are evaluated inside k_lm
 constexpr uint64_t kInlineWindowLimit = 8192;
+constexpr uint64_t kInlinePassBatchLimit = 2048;  // ... batches under the loss, up to one window per CU (mvo_hip_upload)
 constexpr uint64_t kInlineFusedLimit = 3072;  // ... when the alternative is the fused fold + LM launch (mvo_hip_upload)
 
 }  // namespace
@@ -486,8 +487,15 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
                                    !h->env_no_tails && P <= (uint32_t)kRobustMaxPairs;
     const bool persistent_ahead = persistent_likely && ((P >= 10 && n_obs >= 2048) || (P >= 28 && n_obs >= 1536));
     const bool slots_batch = W > 1 && !h->pass_mode && P <= 64;
+    // Batches under the loss (an observation pass per evaluation): inline passes are one wavefront per pair and
+    // evaluation inside the window's workgroup -- or inside its ONE wavefront beyond a window per CU
+    // (scripts/exp/batch_inline_vs_tiled_loss.py, call time inline / tiled: 64 windows of 1050 / 3500 blocks 186.9 / 283.9,
+    // 233.6 / 204.8 us; 256 windows 195.3 / 331.7, 300.6 / 288.5; 512 windows 610.1 / 423.7, 962.0 / 385.8; 1024 windows
+    // 682.5 / 525.3, 1014.9 / 549.5).
+    const bool pass_batch = W > 1 && h->pass_mode;
     const uint64_t inline_limit = fused_likely ? kInlineFusedLimit
-                                  : slots_batch ? (W > 256 ? 0 : kInlineFusedLimit) : kInlineWindowLimit;
+                                  : slots_batch ? (W > 256 ? 0 : kInlineFusedLimit)
+                                  : pass_batch ? (W > 256 ? 0 : kInlinePassBatchLimit) : kInlineWindowLimit;
     h->inline_eval = max_win_obs <= inline_limit && !(opt->assembly_mode & MVO_HIP_ASSEMBLY_TILED) && !four_per_wave &&
                      !persistent_ahead;
   }
