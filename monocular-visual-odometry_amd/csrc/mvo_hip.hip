@@ -787,6 +787,11 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
   const bool arena_in_place = h->one_shot && small_window(h) && one_trip && rays_in_arena && !rays_on_device &&
                               !no_rays && !h->env_arena_copy && arena_bytes <= (64u << 10);
   char* da = arena_in_place ? ha : h->d_arena.as<char>();
+  // One-shot call, one window folded chip-wide, rays gathered into the arena (<= kArenaRayLimit blocks): the fold reads
+  // every ray exactly once, so it reads them in the arena, over PCIe, and only the tables are copied (as the staged
+  // path does for longer windows: zero_copy below).
+  const bool rays_in_place = h->one_shot && W == 1 && !h->inline_eval && rays_in_arena && !rays_on_device && !no_rays &&
+                             !arena_in_place && !h->env_arena_copy;
   std::memcpy(ha + o_frames, frames, sizeof(mvo_hip_frame) * (size_t)W * N);
   std::memcpy(ha + o_initx, initx.data(), sizeof(double) * initx.size());
   std::memcpy(ha + o_wins, wins.data(), sizeof(WinDev) * W);
@@ -804,8 +809,8 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
   h->t.pairs_unit = reinterpret_cast<PairDev*>(da + o_unit);
   h->t.tiles = reinterpret_cast<TileDev*>(da + o_tiles);
   h->t.wave_tiles = reinterpret_cast<uint32_t*>(da + o_wave);
-  h->t.m0 = rays_in_arena ? reinterpret_cast<double*>(da + o_m0) : h->d_m0.as<double>();
-  h->t.m1 = rays_in_arena ? reinterpret_cast<double*>(da + o_m1) : h->d_m1.as<double>();
+  h->t.m0 = rays_in_arena ? reinterpret_cast<double*>((rays_in_place ? ha : da) + o_m0) : h->d_m0.as<double>();
+  h->t.m1 = rays_in_arena ? reinterpret_cast<double*>((rays_in_place ? ha : da) + o_m1) : h->d_m1.as<double>();
   // Rays in the handle's pinned staging block, too many for the arena: the fold reads them exactly once, so
   // it reads them where they are, over PCIe (pinned host memory is mapped into the device's address
   // space) -- no copy command at all; measured against hipMemcpyAsync from the same block in
@@ -830,7 +835,8 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
     pos += cnt;
   }
   if (!arena_in_place)
-    HIP_TRY(hipMemcpyAsync(da, ha, rays_on_device && rays_in_arena ? o_m0 : arena_bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(da, ha, (rays_on_device && rays_in_arena) || rays_in_place ? o_m0 : arena_bytes,
+                           hipMemcpyHostToDevice, s));
   if (rays_in_arena || rays_on_device || rays_pinned) {
     h->copy_pending = true;  // pinned source: the copy is asynchronous and the solve is queued behind it
   } else {
