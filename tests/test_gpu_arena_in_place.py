@@ -84,3 +84,21 @@ def test_split_phase_solves_again_from_the_arena(solver):
     f1, s1 = solver.refine(w, capi.make_options(**SHIPPED))
     _same(f1, s1, f0, s0[0], w.M)
     assert np.abs(refined(f0, w.M)).max() > 0.0
+
+
+@pytest.mark.parametrize("loss", [False, True])
+def test_rays_of_a_mid_size_window_read_in_the_arena_by_the_fold(solver, loss):
+    """One-shot call, one window folded chip-wide with at most 65536 residual blocks: the fold reads the gathered rays in
+    the pinned arena (every ray exactly once) and only the tables are copied.  Different windows one after the other
+    through the same handle, bit for bit against a copying handle."""
+    copy = _copy_handle()
+    try:
+        ws = [scene.make_window(10, 5, 300 + 40 * (i % 5), seed=8300 + i) for i in range(12)]
+        opt = capi.make_options(use_loss_function=loss, **SHIPPED)
+        want = [copy.refine(w, opt) for w in ws]
+        for _ in range(2):
+            for w, (fb, sb) in zip(ws, want):
+                fa, sa = solver.refine(w, opt)
+                _same(fa, sa, fb, sb, w.M)
+    finally:
+        copy.close()
