@@ -787,10 +787,10 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
   const bool arena_in_place = h->one_shot && small_window(h) && one_trip && rays_in_arena && !rays_on_device &&
                               !no_rays && !h->env_arena_copy && arena_bytes <= (64u << 10);
   char* da = arena_in_place ? ha : h->d_arena.as<char>();
-  // One-shot call, one window folded chip-wide, rays gathered into the arena (<= kArenaRayLimit blocks): the fold reads
+  // One-shot call, windows folded chip-wide, rays gathered into the arena (<= kArenaRayLimit blocks): the fold reads
   // every ray exactly once, so it reads them in the arena, over PCIe, and only the tables are copied (as the staged
   // path does for longer windows: zero_copy below).
-  const bool rays_in_place = h->one_shot && W == 1 && !h->inline_eval && rays_in_arena && !rays_on_device && !no_rays &&
+  const bool rays_in_place = h->one_shot && !h->inline_eval && rays_in_arena && !rays_on_device && !no_rays &&
                              !arena_in_place && !h->env_arena_copy;
   std::memcpy(ha + o_frames, frames, sizeof(mvo_hip_frame) * (size_t)W * N);
   std::memcpy(ha + o_initx, initx.data(), sizeof(double) * initx.size());
