@@ -690,7 +690,10 @@ int do_upload(mvo_hip_context* h, uint32_t W, const mvo_hip_frame* frames, uint3
   }
 
   // ---- lay the tables out in the arena; rays join them when they are few (one copy in all)
-  const bool rays_in_arena = n_obs <= kArenaRayLimit && !no_rays;
+  // (rays already in the handle's pinned staging block and a window folded chip-wide: the fold reads them there --
+  // zero_copy below --, a gather into the arena would be one more pass over them)
+  const bool rays_in_arena = n_obs <= kArenaRayLimit && !no_rays &&
+                             !(rays_pinned && W == 1 && !h->inline_eval && !std::getenv("MVO_HIP_STAGED_COPY"));
   size_t off = 0;
   auto place = [&off](size_t bytes) {
     const size_t o = off;
