@@ -1409,7 +1409,9 @@ int do_solve(mvo_hip_context* h) {
   // was 64 until the end of round 3).  Beyond, k_lm4's marks-only epilogue and ONE copy are the faster (1536 windows:
   // 229.9 us copied against 232.3, 2048: 277.4 against 288.0, 4096: 502 against 524).
   // (the chunked experiment paths -- MVO_HIP_OVERLAP, MVO_HIP_PIPELINE -- count finished windows and copy the records)
-  h->results_on_host = h->W <= h->env_host_results_max_w && !h->env_no_host_results &&  // MVO_HIP_NO_HOST_RESULTS
+  // (measured without a loss; under one -- a launch per evaluation, solves of several hundred us -- the limit stays 64)
+  h->results_on_host = h->W <= (h->pass_mode ? std::min<uint32_t>(64, h->env_host_results_max_w) : h->env_host_results_max_w) &&
+                       !h->env_no_host_results &&  // MVO_HIP_NO_HOST_RESULTS
                        !(h->n_chunks > 1 && !h->pass_mode && !h->inline_eval);
   if (h->results_on_host)
     for (uint32_t w = 0; w < h->W; ++w) h->h_results[w].pad = 0;
