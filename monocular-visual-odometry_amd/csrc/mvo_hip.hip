@@ -192,6 +192,7 @@ struct mvo_hip_context {
   uint32_t env_waves_per_cu = 16;
   int env_overlap_chunks = 0;  // 0: the default (kOverlapChunks)
   bool env_no_host_results = false, env_no_poll = false;
+  uint32_t env_host_results_max_w_loss = 1024;  // ... under the loss (the same variable sets both)
   uint32_t env_host_results_max_w = 1024;  // MVO_HIP_HOST_RESULTS_MAX_W
   uint32_t env_slots_min_w = 1, env_slots_max_p = 64;  // MVO_HIP_SLOTS_MIN_W / _MAX_P (experiments): slots plan for W > / P <=
   bool one_shot = false;        // set by mvo_hip_refine* around their upload: the upload is solved exactly once
@@ -1409,8 +1410,10 @@ int do_solve(mvo_hip_context* h) {
   // was 64 until the end of round 3).  Beyond, k_lm4's marks-only epilogue and ONE copy are the faster (1536 windows:
   // 229.9 us copied against 232.3, 2048: 277.4 against 288.0, 4096: 502 against 524).
   // (the chunked experiment paths -- MVO_HIP_OVERLAP, MVO_HIP_PIPELINE -- count finished windows and copy the records)
-  // (measured without a loss; under one -- a launch per evaluation, solves of several hundred us -- the limit stays 64)
-  h->results_on_host = h->W <= (h->pass_mode ? std::min<uint32_t>(64, h->env_host_results_max_w) : h->env_host_results_max_w) &&
+  // (under the loss -- a launch per evaluation -- the same: 128 / 512 / 1024 windows of 10 500 blocks 289.8 -> 267.5,
+  // 533.2 -> 516.2, 896.1 -> 885.6 us per call, scripts/exp/batch_inline_vs_tiled_loss.py; a solve longer than the
+  // 0.5 ms the host polls for ends in a wait for the stream as before, still without the copy command)
+  h->results_on_host = h->W <= (h->pass_mode ? h->env_host_results_max_w_loss : h->env_host_results_max_w) &&
                        !h->env_no_host_results &&  // MVO_HIP_NO_HOST_RESULTS
                        !(h->n_chunks > 1 && !h->pass_mode && !h->inline_eval);
   if (h->results_on_host)
@@ -1726,7 +1729,8 @@ int mvo_hip_create(int device_ordinal, uint32_t max_windows, uint32_t max_frames
     if (t >= 2 && t <= kMaxOverlapChunks) h->env_overlap_chunks = t;
   }
   h->env_no_host_results = std::getenv("MVO_HIP_NO_HOST_RESULTS") != nullptr;
-  if (const char* e = std::getenv("MVO_HIP_HOST_RESULTS_MAX_W")) h->env_host_results_max_w = (uint32_t)std::atoi(e);
+  if (const char* e = std::getenv("MVO_HIP_HOST_RESULTS_MAX_W"))
+    h->env_host_results_max_w = h->env_host_results_max_w_loss = (uint32_t)std::atoi(e);
   h->env_no_poll = std::getenv("MVO_HIP_NO_POLL") != nullptr;
   h->env_no_tails = std::getenv("MVO_HIP_NO_TAILS") != nullptr;
   h->env_arena_copy = std::getenv("MVO_HIP_ARENA_COPY") != nullptr;

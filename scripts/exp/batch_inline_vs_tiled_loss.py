@@ -9,7 +9,7 @@ fixed = dict(use_loss_function=True, max_num_iterations=10, function_tolerance=0
 with capi.Solver(0, profiling=False) as s:
     for L in [int(a) for a in sys.argv[1:]] or (30, 100, 200):
         base = [scene.make_window(10, 5, L, seed=900 + i) for i in range(16)]
-        for W in (2, 8, 64, 256, 512, 1024):
+        for W in (64, 128, 256, 512, 1024):
             ws = [base[i % 16] for i in range(W)]
             row = []
             for name, mode in (("inline", 0), ("tiled", capi.ASSEMBLY_TILED)):
